@@ -1,0 +1,77 @@
+/* oracle/pom_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's mode-split time step (advance.f + the solver.f
+ * kernels + the bcond/bcondorl/restore_interior branches that run inside it).  It exists to CHECK
+ * the HIP path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (extpom_amd/, libpomgpu.so) never links, imports or calls anything in oracle/.
+ *
+ * Pinning: tests/test_oracle_vs_reference.py runs this restatement and the flang-compiled,
+ * unmodified reference (oracle/_ref, built by oracle/build_ref.sh) on identical inputs and
+ * requires BIT-IDENTICAL COMMON blocks; tests/golden/ holds digests of reference runs so the
+ * pin also holds where /root/reference is absent.
+ */
+#ifndef POM_ORACLE_H
+#define POM_ORACLE_H
+#include <stddef.h>
+#include "pom_layout.h"
+
+#define POMO_MAXREC 8
+#define POMO_NSCR 16
+
+typedef struct pomo_tile {
+  int im_, jm_, kb_;         /* active extents im, jm, kb (blksiz) */
+  int iml, jml;              /* leading dimensions im_local, jm_local */
+  int nw_, ne_, ns_, nn_;    /* neighbour ranks n_west n_east n_south n_north, -1 = physical edge (blkpar) */
+  int lramp;                 /* blklog */
+  size_t n2, n3;             /* iml*jml, iml*jml*kb */
+  pom_blkcon *con;           /* blkcon record (caller-owned) */
+  double *blk1d, *blk2d, *blk3d, *bdry; /* COMMON-layout storage (caller-owned) */
+  double *bd[80];            /* base pointer of each bdry member (filled by pomo_bind) */
+  /* relaxation targets served to restore_interior, records 1..POMO_MAXREC, (im,jm,kb) each */
+  const double *rec_t[POMO_MAXREC + 1], *rec_s[POMO_MAXREC + 1];
+  /* halo-exchange hooks (NULL = single tile, i.e. all neighbours -1: parallel_mpi.f:171-236) */
+  void (*exch2d)(void *user, double *a, int nx, int ny);
+  void (*exch3d)(void *user, double *a, int nx, int ny, int nz);
+  void *user;
+  /* outputs of check_velocity */
+  double vamax; int imax, jmax;
+  /* scratch for the reference's automatic arrays */
+  double *scr[POMO_NSCR];
+} pomo_tile;
+
+/* bind storage; returns 0 or -1 on allocation failure */
+int  pomo_bind(pomo_tile *t, int im, int jm, int kb, int iml, int jml, pom_blkcon *con,
+               double *blk1d, double *blk2d, double *blk3d, double *bdry);
+void pomo_release(pomo_tile *t);
+size_t pomo_tile_size(void);
+
+/* the reference's entry points, same names and argument meaning */
+void pomo_advave(pomo_tile *t);
+void pomo_advct(pomo_tile *t);
+void pomo_advq(pomo_tile *t, double *qb, double *q, double *qf);
+void pomo_advt1(pomo_tile *t, double *fb, double *f, double *fclim, double *ff);
+void pomo_advt2(pomo_tile *t, double *fb, double *f, double *fclim, double *ff);
+void pomo_advu(pomo_tile *t);
+void pomo_advv(pomo_tile *t);
+void pomo_baropg(pomo_tile *t);
+void pomo_dens(pomo_tile *t, double *si, double *ti, double *rhoo);
+void pomo_profq(pomo_tile *t);
+void pomo_proft(pomo_tile *t, double *f, double *wfsurf, double *fsurf, int nbc);
+void pomo_profu(pomo_tile *t);
+void pomo_profv(pomo_tile *t);
+void pomo_vertvl(pomo_tile *t);
+void pomo_realvertvl(pomo_tile *t);
+void pomo_bcond(pomo_tile *t, int idx);
+void pomo_bcondorl(pomo_tile *t, int idx);
+void pomo_restore_interior(pomo_tile *t);
+void pomo_get_time(pomo_tile *t);
+void pomo_lateral_viscosity(pomo_tile *t);
+void pomo_mode_interaction(pomo_tile *t);
+void pomo_mode_external(pomo_tile *t);
+void pomo_mode_internal(pomo_tile *t);
+void pomo_check_velocity(pomo_tile *t);
+/* hot-path sequence of advance (advance.f:6-59) for the step con->iint */
+void pomo_advance(pomo_tile *t);
+/* nsteps x { iint += 1; advance } */
+void pomo_run(pomo_tile *t, int nsteps);
+#endif

@@ -1,0 +1,133 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes wrapper of the plain-C restatement (oracle/libpomoracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The oracle works IN PLACE on a PomState's COMMON-layout buffers.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(HERE, "libpomoracle.so")
+    src = os.path.join(HERE, "pom_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "libpomoracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.pomo_tile_size.restype = ctypes.c_size_t
+    return _LIB
+
+
+_EXCH2 = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int)
+_EXCH3 = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                          ctypes.c_int)
+
+
+class OracleTile:
+    """Binds a PomState to the C oracle; every pomo_* entry point is reachable through call()."""
+
+    def __init__(self, st, exch2d=None, exch3d=None):
+        self.st = st
+        L = self.L = lib()
+        self._buf = ctypes.create_string_buffer(L.pomo_tile_size())
+        self.t = ctypes.cast(self._buf, ctypes.c_void_p)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = L.pomo_bind(self.t, st.im, st.jm, st.kb, st.im_local, st.jm_local, p(st.con), p(st.blk1d),
+                         p(st.blk2d), p(st.blk3d), p(st.bdry))
+        if rc != 0:
+            raise MemoryError("pomo_bind failed")
+        # struct head: im_, jm_, kb_, iml, jml, nw_, ne_, ns_, nn_, lramp  (ints)
+        head = (ctypes.c_int * 10).from_buffer(self._buf)
+        head[5], head[6], head[7], head[8] = st.n_west, st.n_east, st.n_south, st.n_north
+        head[9] = 1 if getattr(st, "lramp", False) else 0
+        self._head = head
+        # field offsets inside pomo_tile (see pom_oracle.h); computed from the declared layout
+        ptr = ctypes.sizeof(ctypes.c_void_p)
+        off = 10 * 4
+        off = (off + 7) // 8 * 8
+        off += 2 * 8            # n2, n3
+        off += ptr              # con
+        off += 4 * ptr          # blk1d..bdry
+        off += 80 * ptr         # bd[]
+        self._off_rec_t = off
+        self._off_rec_s = off + 9 * ptr
+        off += 18 * ptr
+        self._off_ex2, self._off_ex3, self._off_user = off, off + ptr, off + 2 * ptr
+        off += 3 * ptr
+        self._off_vamax = off
+        self._recs = []
+        for n, (tr, sr) in enumerate(getattr(st, "restore_records", []), start=1):
+            tr = np.ascontiguousarray(tr, dtype=np.float64)
+            sr = np.ascontiguousarray(sr, dtype=np.float64)
+            self._recs.append((tr, sr))
+            self._poke(self._off_rec_t + n * ptr, tr.ctypes.data)
+            self._poke(self._off_rec_s + n * ptr, sr.ctypes.data)
+        self._cb = []
+        if exch2d is not None:
+            cb = _EXCH2(lambda user, a, nx, ny: exch2d(np.ctypeslib.as_array(a, shape=(ny, nx))))
+            self._cb.append(cb)
+            self._poke(self._off_ex2, ctypes.cast(cb, ctypes.c_void_p).value)
+        if exch3d is not None:
+            cb = _EXCH3(lambda user, a, nx, ny, nz: exch3d(np.ctypeslib.as_array(a, shape=(nz, ny, nx))))
+            self._cb.append(cb)
+            self._poke(self._off_ex3, ctypes.cast(cb, ctypes.c_void_p).value)
+
+    def _poke(self, off, value):
+        ctypes.c_void_p.from_buffer(self._buf, off).value = value
+
+    def __del__(self):
+        try:
+            self.L.pomo_release(self.t)
+        except Exception:
+            pass
+
+    # ---- calls ---------------------------------------------------------------------------
+    def a3(self, name):
+        return ctypes.c_void_p(self.st.field(name).ctypes.data)
+
+    a2 = a3
+
+    def call(self, name, *args):
+        fn = getattr(self.L, "pomo_" + name)
+        fn.restype = None
+        fn(self.t, *args)
+
+    def advance(self):
+        self.call("advance")
+
+    def run(self, nsteps):
+        self.call("run", ctypes.c_int(nsteps))
+        return self.st
+
+    @property
+    def vamax(self):
+        v = ctypes.c_double.from_buffer(self._buf, self._off_vamax).value
+        ij = (ctypes.c_int * 2).from_buffer(self._buf, self._off_vamax + 8)
+        return v, ij[0], ij[1]
+
+
+def oracle_finish_initial(st):
+    """finish_initial() with the oracle's dens / baropg."""
+    from extpom_amd.cases import finish_initial
+    ot = OracleTile(st)
+
+    def dens(s, si, ti, rho):
+        ot.call("dens", ot.a3(si), ot.a3(ti), ot.a3(rho))
+
+    def baropg(s):
+        ot.call("baropg")
+
+    return finish_initial(st, dens, baropg)

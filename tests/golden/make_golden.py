@@ -1,0 +1,75 @@
+"""Generates tests/golden/seamount_65x49x21.json (+ .npz planes) by running the REFERENCE itself
+(oracle/_ref/libpomref_65x49x21.so, built from the unmodified sources by oracle/build_ref.sh) on
+the inputs of extpom_amd.cases.  Run from the repo root in a container that has /root/reference:
+
+    oracle/build_ref.sh 65 49 21 && python tests/golden/make_golden.py
+
+The fixture holds, per configuration and checkpoint step, the SHA-256 of every restart-list field
+(the prognostic state, reference io_pnetcdf.F:1724-1886) exactly as the reference left it in its
+COMMON blocks, and float64 planes of a few fields for tolerance-based (GPU) comparisons.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from extpom_amd.cases import make_case  # noqa: E402
+from extpom_amd.layout import RESTART_2D, RESTART_3D  # noqa: E402
+from oracle.refharness import RefLib, ref_finish_initial  # noqa: E402
+
+IM, JM, KB = 65, 49, 21
+CONFIGS = {
+    # name: (case, namelist overrides, checkpoints)
+    "seamount_default": ("seamount", dict(dte=6.0, isplit=30), [1, 2, 3, 10, 100]),
+    "seamount_nadv1": ("seamount", dict(dte=6.0, isplit=30, nadv=1), [3, 20]),
+    "seamount_nitera2": ("seamount", dict(dte=6.0, isplit=30, nitera=2), [3, 20]),
+    "seamount_mode2": ("seamount", dict(dte=6.0, isplit=30, mode=2), [3, 20]),
+    "seamount_mode4": ("seamount", dict(dte=6.0, isplit=30, mode=4), [3, 20]),
+    "seamount_nbct2": ("seamount", dict(dte=6.0, isplit=30, nbct=2), [3, 10]),
+    "seamount_nbc3": ("seamount", dict(dte=6.0, isplit=30, nbct=3, nbcs=3), [3, 20]),
+    "island_default": ("island", dict(dte=6.0, isplit=30), [3, 40]),
+    "basin_default": ("basin", dict(dte=6.0, isplit=30), [3, 40]),
+    "basin_alpha": ("basin", dict(dte=6.0, isplit=10, alpha=0.225), [3, 20]),
+}
+PLANES = {"seamount_default": [10, 100], "island_default": [40], "basin_default": [40]}
+PLANE_FIELDS = ["el", "et", "ua", "va", "u", "v", "t", "s", "q2", "km", "rho", "w"]
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).hexdigest()
+
+
+def main():
+    out = {"grid": [IM, JM, KB], "fields": RESTART_2D + RESTART_3D, "configs": {}}
+    planes = {}
+    for name, (case, nml, checkpoints) in CONFIGS.items():
+        st = make_case(case, IM, JM, KB, **nml)
+        ref_finish_initial(st)
+        cfg = {"case": case, "nml": nml, "init": {f: digest(st.field(f)) for f in RESTART_2D + RESTART_3D},
+               "steps": {}}
+        lib = RefLib(IM, JM, KB)
+        lib.put(st)
+        for n in range(1, max(checkpoints) + 1):
+            lib.con["iint"][0] = n
+            lib.advance()
+            if n in checkpoints:
+                lib.get(st)
+                cfg["steps"][str(n)] = {f: digest(st.field(f)) for f in RESTART_2D + RESTART_3D}
+                if n in PLANES.get(name, []):
+                    for f in PLANE_FIELDS:
+                        a = st.field(f)
+                        planes[f"{name}/{n}/{f}"] = (a if a.ndim == 2 else a[[0, KB // 2, KB - 2]]).copy()
+        out["configs"][name] = cfg
+        print(name, "done", flush=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "seamount_65x49x21.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(here, "seamount_65x49x21_planes.npz"), **planes)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""The CPU oracle against the reference build itself (oracle/_ref, only where /root/reference was
+available to oracle/build_ref.sh).  ALL COMMON-block arrays -- not only the restart list -- must be
+bit-identical after every step, and so must each hot-path routine called on its own."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from extpom_amd.cases import make_case
+from extpom_amd.layout import BLK2D, BLK3D
+from oracle.pyoracle import OracleTile
+from oracle.refharness import RefLib, have_ref, ref_finish_initial
+
+pytestmark = pytest.mark.skipif(not have_ref(65, 49, 21), reason="oracle/_ref not built (no /root/reference)")
+
+
+def _diff(a, b):
+    bad = [n for n in BLK2D + BLK3D if not np.array_equal(a.field(n), b.field(n))]
+    if not np.array_equal(a.bdry, b.bdry):
+        bad.append("bdry")
+    bad += ["con." + n for n in a.con.dtype.names if a.con[n][0] != b.con[n][0]]
+    return bad
+
+
+@pytest.mark.parametrize("case,nml", [("seamount", dict(dte=6.0, isplit=30)),
+                                      ("island", dict(dte=6.0, isplit=30, nadv=1)),
+                                      ("basin", dict(dte=6.0, isplit=10, nitera=2))])
+def test_full_state_bit_identical(case, nml):
+    a = make_case(case, 65, 49, 21, **nml)
+    ref_finish_initial(a)
+    b = a.copy()
+    lib = RefLib(65, 49, 21)
+    lib.put(a)
+    ot = OracleTile(b)
+    for n in range(1, 13):
+        lib.con["iint"][0] = n
+        lib.advance()
+        lib.get(a)
+        ot.run(1)
+        assert not _diff(a, b), f"step {n}: {_diff(a, b)}"
+
+
+def test_each_routine_bit_identical():
+    """call the reference's routines one by one on a warm state (step 3: all branches live)"""
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    ref_finish_initial(a)
+    lib = RefLib(65, 49, 21)
+    lib.put(a)
+    for n in range(1, 4):
+        lib.con["iint"][0] = n
+        lib.advance()
+    lib.get(a)
+    a.iint = 4
+    a.iext = 7
+
+    def both(name, ref_args=(), or_args=()):
+        x, y = a.copy(), a.copy()
+        lib.put(x)
+        lib.call(name, *ref_args(lib) if callable(ref_args) else ref_args)
+        lib.get(x)
+        ot = OracleTile(y)
+        ot.call(name, *or_args(ot) if callable(or_args) else or_args)
+        assert not _diff(x, y), f"{name}: {_diff(x, y)}"
+
+    i = lambda v: ctypes.byref(ctypes.c_int(v))
+    for name in ("advave", "advct", "advu", "advv", "baropg", "profq", "profu", "profv", "vertvl", "realvertvl",
+                 "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "check_velocity"):
+        both(name)
+    both("advq", lambda l: (l.f3("q2b"), l.f3("q2"), l.f3("uf")), lambda o: (o.a3("q2b"), o.a3("q2"), o.a3("uf")))
+    for r in ("advt1", "advt2"):
+        both(r, lambda l: (l.f3("tb"), l.f3("t"), l.f3("tclim"), l.f3("uf")),
+             lambda o: (o.a3("tb"), o.a3("t"), o.a3("tclim"), o.a3("uf")))
+    both("dens", lambda l: (l.f3("s"), l.f3("t"), l.f3("rho")), lambda o: (o.a3("s"), o.a3("t"), o.a3("rho")))
+    for nbc in (1, 2, 3, 4):
+        both("proft", lambda l: (l.f3("uf"), l.f2("wtsurf"), l.f2("tsurf"), i(nbc)),
+             lambda o: (o.a3("uf"), o.a2("wtsurf"), o.a2("tsurf"), ctypes.c_int(nbc)))
+    for idx in (1, 2, 4, 5, 6):
+        both("bcond", (i(idx),), (ctypes.c_int(idx),))
+    for idx in (3, 5):
+        both("bcondorl", (i(idx),), (ctypes.c_int(idx),))
