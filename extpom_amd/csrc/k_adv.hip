@@ -1,0 +1,557 @@
+// k_adv.hip -- horizontal stencil kernels of the internal (3-D baroclinic) mode:
+// advct, the Smagorinsky aam loop, advq, advt1, advt2 + smol_adif, dens, restore_interior,
+// realvertvl and the Asselin-filter / time-rotation passes.
+//
+// Thread map: one thread per cell, threadIdx.x along i (the contiguous dimension of every array),
+// blockIdx.z = sigma level.  Each wavefront therefore reads and writes whole 512-byte row
+// segments; i+-1 neighbours come from the same cache lines, j+-1 neighbours from the rows the
+// adjacent wavefronts of the block have just touched (L1/L2 resident).  All kernels are
+// HBM-bound: a few flops per 8-byte word, divisions being the only expensive operation.
+#include "pomgpu_internal.hpp"
+
+#define dt_(i, j) F2(dt, i, j)
+#define dx_(i, j) F2(dx, i, j)
+#define dy_(i, j) F2(dy, i, j)
+#define h_(i, j) F2(h, i, j)
+#define u_(i, j, k) F3(u, i, j, k)
+#define v_(i, j, k) F3(v, i, j, k)
+#define ub_(i, j, k) F3(ub, i, j, k)
+#define vb_(i, j, k) F3(vb, i, j, k)
+#define w_(i, j, k) F3(w, i, j, k)
+#define aam_(i, j, k) F3(aam, i, j, k)
+
+#define CELL3                                  \
+  const int i = TID_I, j = TID_J, k = TID_K;   \
+  if (i > P.iml || j > P.jml || k > P.kb) return;
+
+// ---------------------------------------------------------------------------------------------
+// advct phase a: curv, and the fluxes of the x-momentum equation -- solver.f:213-277
+// scratch: s3[0]=curv  s3[1]=xflux  s3[2]=yflux
+__global__ void k_advct_a(KP P) {
+  CELL3
+  if (i > P.im || j > P.jm) return;
+  double cv = 0., xf = 0., yf = 0.;
+  if (k <= P.kbm1) {
+    const bool iin = (i >= 2 && i <= P.imm1);
+    if (iin && j >= 2 && j <= P.jmm1)
+      cv = .25 * ((v_(i, j + 1, k) + v_(i, j, k)) * (dy_(i + 1, j) - dy_(i - 1, j)) -
+                  (u_(i + 1, j, k) + u_(i, j, k)) * (dx_(i, j + 1) - dx_(i, j - 1))) / (dx_(i, j) * dy_(i, j));
+    if (iin)
+      xf = .125 * ((dt_(i + 1, j) + dt_(i, j)) * u_(i + 1, j, k) + (dt_(i, j) + dt_(i - 1, j)) * u_(i, j, k)) *
+           (u_(i + 1, j, k) + u_(i, j, k));
+    if (i >= 2 && j >= 2)
+      yf = .125 * ((dt_(i, j) + dt_(i, j - 1)) * v_(i, j, k) + (dt_(i - 1, j) + dt_(i - 1, j - 1)) * v_(i - 1, j, k)) *
+           (u_(i, j, k) + u_(i, j - 1, k));
+    if (iin && j >= 2) {
+      xf = xf - dt_(i, j) * aam_(i, j, k) * 2. * (ub_(i + 1, j, k) - ub_(i, j, k)) / dx_(i, j);
+      const double dtaam = .25 * (dt_(i, j) + dt_(i - 1, j) + dt_(i, j - 1) + dt_(i - 1, j - 1)) *
+                           (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
+      yf = yf - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) +
+                         (vb_(i, j, k) - vb_(i - 1, j, k)) / (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)));
+      xf = dy_(i, j) * xf;
+      yf = .25 * (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)) * yf;
+    }
+  }
+  G3(P.s3[0], i, j, k) = cv;
+  G3(P.s3[1], i, j, k) = xf;
+  G3(P.s3[2], i, j, k) = yf;
+}
+
+// advct phase b: advx, and the fluxes of the y-momentum equation -- solver.f:282-367
+// scratch in: s3[0..2]; out: s3[3]=xflux' s3[4]=yflux'
+__global__ void k_advct_b(KP P) {
+  CELL3
+  const double *cv = P.s3[0], *xf = P.s3[1], *yf = P.s3[2];
+  double ax = 0., xg = 0., yg = 0.;
+  if (k <= P.kbm1 && i <= P.im && j <= P.jm) {
+    if (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
+      ax = G3(xf, i, j, k) - G3(xf, i - 1, j, k) + G3(yf, i, j + 1, k) - G3(yf, i, j, k);
+      if (i >= (P.W ? 3 : 2))
+        ax = ax - F2(aru, i, j) * .25 *
+                      (G3(cv, i, j, k) * dt_(i, j) * (v_(i, j + 1, k) + v_(i, j, k)) +
+                       G3(cv, i - 1, j, k) * dt_(i - 1, j) * (v_(i - 1, j + 1, k) + v_(i - 1, j, k)));
+    }
+    if (i >= 2 && j >= 2)
+      xg = .125 * ((dt_(i, j) + dt_(i - 1, j)) * u_(i, j, k) + (dt_(i, j - 1) + dt_(i - 1, j - 1)) * u_(i, j - 1, k)) *
+           (v_(i, j, k) + v_(i - 1, j, k));
+    if (j >= 2 && j <= P.jmm1) {
+      yg = .125 * ((dt_(i, j + 1) + dt_(i, j)) * v_(i, j + 1, k) + (dt_(i, j) + dt_(i, j - 1)) * v_(i, j, k)) *
+           (v_(i, j + 1, k) + v_(i, j, k));
+      if (i >= 2) {
+        const double dtaam = .25 * (dt_(i, j) + dt_(i - 1, j) + dt_(i, j - 1) + dt_(i - 1, j - 1)) *
+                             (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
+        xg = xg - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) +
+                           (vb_(i, j, k) - vb_(i - 1, j, k)) / (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)));
+        yg = yg - dt_(i, j) * aam_(i, j, k) * 2. * (vb_(i, j + 1, k) - vb_(i, j, k)) / dy_(i, j);
+        xg = .25 * (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) * xg;
+        yg = dx_(i, j) * yg;
+      }
+    }
+  }
+  F3(advx, i, j, k) = ax;
+  if (i <= P.im && j <= P.jm) {
+    G3(P.s3[3], i, j, k) = xg;
+    G3(P.s3[4], i, j, k) = yg;
+  }
+}
+
+// advct phase c: advy -- solver.f:372-403
+__global__ void k_advct_c(KP P) {
+  CELL3
+  const double *cv = P.s3[0], *xg = P.s3[3], *yg = P.s3[4];
+  double ay = 0.;
+  if (k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
+    ay = G3(xg, i + 1, j, k) - G3(xg, i, j, k) + G3(yg, i, j, k) - G3(yg, i, j - 1, k);
+    if (j >= (P.S ? 3 : 2))
+      ay = ay + F2(arv, i, j) * .25 *
+                    (G3(cv, i, j, k) * dt_(i, j) * (u_(i + 1, j, k) + u_(i, j, k)) +
+                     G3(cv, i, j - 1, k) * dt_(i, j - 1) * (u_(i + 1, j - 1, k) + u_(i, j - 1, k)));
+  }
+  F3(advy, i, j, k) = ay;
+}
+
+// Smagorinsky lateral viscosity -- advance.f:122-136
+__global__ void k_aam(KP P) {
+  CELL3
+  if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  F3(aam, i, j, k) =
+      P.horcon * dx_(i, j) * dy_(i, j) *
+      sqrt(sq((u_(i + 1, j, k) - u_(i, j, k)) / dx_(i, j)) + sq((v_(i, j + 1, k) - v_(i, j, k)) / dy_(i, j)) +
+           .5 * sq(.25 * (u_(i, j + 1, k) + u_(i + 1, j + 1, k) - u_(i, j - 1, k) - u_(i + 1, j - 1, k)) / dy_(i, j) +
+                   .25 * (v_(i + 1, j, k) + v_(i + 1, j + 1, k) - v_(i - 1, j, k) - v_(i - 1, j + 1, k)) / dx_(i, j)));
+}
+
+// rho = (rho-rmean)+rmean: the in-place round trip of baropg (solver.f:854,937) leaves rho changed
+// by a rounding, which later reads of rho (profq) see
+__global__ void k_roundtrip(KP P, double *a, const double *b, int fix_kb) {
+  CELL3
+  double x = G3(a, i, j, (fix_kb && k == P.kb) ? P.kbm1 : k);
+  const double y = G3(b, i, j, k);
+  x = x - y;
+  G3(a, i, j, k) = x + y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// advq -- solver.f:411-477.  Phase 1: fluxes (exchanged), phase 2: step.
+__global__ void k_advq_flux(KP P, const double *q, const double *qb, double *xf, double *yf) {
+  CELL3
+  if (i > P.im || j > P.jm) return;
+  double x = 0., y = 0.;
+  if (k >= 2 && k <= P.kbm1 && i >= 2 && j >= 2) {
+    x = .125 * (G3(q, i, j, k) + G3(q, i - 1, j, k)) * (dt_(i, j) + dt_(i - 1, j)) * (u_(i, j, k) + u_(i, j, k - 1));
+    y = .125 * (G3(q, i, j, k) + G3(q, i, j - 1, k)) * (dt_(i, j) + dt_(i, j - 1)) * (v_(i, j, k) + v_(i, j, k - 1));
+    x = x - .25 * (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j, k - 1) + aam_(i - 1, j, k - 1)) * (h_(i, j) + h_(i - 1, j)) *
+                (G3(qb, i, j, k) - G3(qb, i - 1, j, k)) * F2(dum, i, j) / (dx_(i, j) + dx_(i - 1, j));
+    y = y - .25 * (aam_(i, j, k) + aam_(i, j - 1, k) + aam_(i, j, k - 1) + aam_(i, j - 1, k - 1)) * (h_(i, j) + h_(i, j - 1)) *
+                (G3(qb, i, j, k) - G3(qb, i, j - 1, k)) * F2(dvm, i, j) / (dy_(i, j) + dy_(i, j - 1));
+    x = .5 * (dy_(i, j) + dy_(i - 1, j)) * x;
+    y = .5 * (dx_(i, j) + dx_(i, j - 1)) * y;
+  }
+  G3(xf, i, j, k) = x;
+  G3(yf, i, j, k) = y;
+}
+// zero_else: the caller zero-filled qf beforehand in the reference (advance.f:403-404)
+__global__ void k_advq_step(KP P, const double *q, const double *qb, double *qf, const double *xf, const double *yf,
+                            int zero_else) {
+  CELL3
+  if (k >= 2 && k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
+    double r = (w_(i, j, k - 1) * G3(q, i, j, k - 1) - w_(i, j, k + 1) * G3(q, i, j, k + 1)) * F2(art, i, j) /
+                   (F1(dz, k) + F1(dz, k - 1)) +
+               G3(xf, i + 1, j, k) - G3(xf, i, j, k) + G3(yf, i, j + 1, k) - G3(yf, i, j, k);
+    r = ((h_(i, j) + F2(etb, i, j)) * F2(art, i, j) * G3(qb, i, j, k) - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * F2(art, i, j));
+    G3(qf, i, j, k) = r;
+  } else if (zero_else) {
+    G3(qf, i, j, k) = 0.;
+  }
+}
+
+// bcond(6) mask + Asselin filter + rotation of q2/q2l -- bounds_forcing.f:315-322, advance.f:416-421
+__global__ void k_q_filter(KP P, int mask) {
+  CELL3
+  double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
+  if (mask && i <= P.im && j <= P.jm) {
+    const double m = F2(fsm, i, j);
+    uf = uf * m + 1.e-10;
+    vf = vf * m + 1.e-10;
+    F3(uf, i, j, k) = uf;
+    F3(vf, i, j, k) = vf;
+  }
+  const double q = F3(q2, i, j, k), ql = F3(q2l, i, j, k);
+  F3(q2b, i, j, k) = q + .5 * P.smoth * (uf + F3(q2b, i, j, k) - 2. * q);
+  F3(q2, i, j, k) = uf;
+  F3(q2lb, i, j, k) = ql + .5 * P.smoth * (vf + F3(q2lb, i, j, k) - 2. * ql);
+  F3(q2l, i, j, k) = vf;
+}
+__global__ void k_mask_q(KP P) {   // the mask of bcond(6) alone
+  CELL3
+  if (i > P.im || j > P.jm) return;
+  const double m = F2(fsm, i, j);
+  F3(uf, i, j, k) = F3(uf, i, j, k) * m + 1.e-10;
+  F3(vf, i, j, k) = F3(vf, i, j, k) * m + 1.e-10;
+}
+
+// ---------------------------------------------------------------------------------------------
+// advt1 -- solver.f:480-574.  Fluxes are recomputed per cell face (no intermediate arrays).
+__device__ __forceinline__ double advt1_xflux(const KP &P, const double *f, const double *fb, const double *fc, int i, int j, int k) {
+  double x = .25 * ((dt_(i, j) + dt_(i - 1, j)) * (G3(f, i, j, k) + G3(f, i - 1, j, k)) * u_(i, j, k));
+  x = x - .5 * (aam_(i, j, k) + aam_(i - 1, j, k)) * (h_(i, j) + h_(i - 1, j)) * P.tprni *
+              ((G3(fb, i, j, k) - G3(fc, i, j, k)) - (G3(fb, i - 1, j, k) - G3(fc, i - 1, j, k))) * F2(dum, i, j) /
+              (dx_(i, j) + dx_(i - 1, j));
+  return .5 * (dy_(i, j) + dy_(i - 1, j)) * x;
+}
+__device__ __forceinline__ double advt1_yflux(const KP &P, const double *f, const double *fb, const double *fc, int i, int j, int k) {
+  double y = .25 * ((dt_(i, j) + dt_(i, j - 1)) * (G3(f, i, j, k) + G3(f, i, j - 1, k)) * v_(i, j, k));
+  y = y - .5 * (aam_(i, j, k) + aam_(i, j - 1, k)) * (h_(i, j) + h_(i, j - 1)) * P.tprni *
+              ((G3(fb, i, j, k) - G3(fc, i, j, k)) - (G3(fb, i, j - 1, k) - G3(fc, i, j - 1, k))) * F2(dvm, i, j) /
+              (dy_(i, j) + dy_(i, j - 1));
+  return .5 * (dx_(i, j) + dx_(i, j - 1)) * y;
+}
+__global__ void k_advt1(KP P, const double *fb, const double *f, const double *fc, double *ff) {
+  CELL3
+  if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  const double art = F2(art, i, j);
+  const double zu = (k == 1) ? G3(f, i, j, 1) * w_(i, j, 1) * art
+                             : .5 * (G3(f, i, j, k - 1) + G3(f, i, j, k)) * w_(i, j, k) * art;
+  const double zl = (k == P.kbm1) ? 0. : .5 * (G3(f, i, j, k) + G3(f, i, j, k + 1)) * w_(i, j, k + 1) * art;
+  double r = advt1_xflux(P, f, fb, fc, i + 1, j, k) - advt1_xflux(P, f, fb, fc, i, j, k) +
+             advt1_yflux(P, f, fb, fc, i, j + 1, k) - advt1_yflux(P, f, fb, fc, i, j, k) + (zu - zl) / F1(dz, k);
+  const double fbr = (G3(fb, i, j, k) - G3(fc, i, j, k)) + G3(fc, i, j, k);   // fb after :511,:532
+  G3(ff, i, j, k) = (fbr * (h_(i, j) + F2(etb, i, j)) * art - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
+}
+// f(:,:,kb) = f(:,:,kbm1)  (solver.f:495)
+__global__ void k_copy_kb(KP P, double *f) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.iml || j > P.jml) return;
+  G3(f, i, j, P.kb) = G3(f, i, j, P.kbm1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// advt2 + smol_adif -- solver.f:577-731, :1880-1967  (general nitera path)
+// scratch: s3[0]=xmassflux s3[1]=ymassflux s3[2]=zwflux s3[3]=fbmem(itera>=2)
+__global__ void k_advt2_mass(KP P) {
+  CELL3
+  if (i > P.im || j > P.jm) return;
+  double xm = 0., ym = 0.;
+  if (k <= P.kbm1) {
+    if (j >= 2 && j <= P.jmm1 && i >= 2) xm = 0.25 * (dy_(i - 1, j) + dy_(i, j)) * (dt_(i - 1, j) + dt_(i, j)) * u_(i, j, k);
+    if (j >= 2 && i >= 2 && i <= P.imm1) ym = 0.25 * (dx_(i, j - 1) + dx_(i, j)) * (dt_(i, j - 1) + dt_(i, j)) * v_(i, j, k);
+  }
+  G3(P.s3[0], i, j, k) = xm;
+  G3(P.s3[1], i, j, k) = ym;
+  G3(P.s3[2], i, j, k) = w_(i, j, k);
+}
+__device__ __forceinline__ double upw(double m, double lo, double hi) {   // solver.f:631-635
+  return 0.5 * ((m + fabs(m)) * lo + (m - fabs(m)) * hi);
+}
+__global__ void k_advt2_step(KP P, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
+  CELL3
+  if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  const double *xm = P.s3[0], *ym = P.s3[1], *zw = P.s3[2];
+  const double art = F2(art, i, j);
+  const double fc = G3(fbmem, i, j, k);
+  const double xe = upw(G3(xm, i + 1, j, k), fc, G3(fbmem, i + 1, j, k));
+  const double xw = upw(G3(xm, i, j, k), G3(fbmem, i - 1, j, k), fc);
+  const double yn = upw(G3(ym, i, j + 1, k), fc, G3(fbmem, i, j + 1, k));
+  const double ys = upw(G3(ym, i, j, k), G3(fbmem, i, j - 1, k), fc);
+  double zu, zl;
+  if (k == 1) zu = (itera == 1) ? w_(i, j, 1) * G3(f, i, j, 1) * art : 0.;
+  else zu = upw(G3(zw, i, j, k), fc, G3(fbmem, i, j, k - 1)) * art;
+  if (k == P.kbm1) zl = 0.;
+  else zl = upw(G3(zw, i, j, k + 1), G3(fbmem, i, j, k + 1), fc) * art;
+  double r = xe - xw + yn - ys + (zu - zl) / F1(dz, k);
+  G3(ff, i, j, k) = (fc * ((h_(i, j) + G2(eta, i, j)) * art) - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
+}
+__global__ void k_mask3(KP P, double *a, const double *m2) {   // a(:,:,k) = a(:,:,k)*m2 for k=1..kb
+  CELL3
+  G3(a, i, j, k) = G3(a, i, j, k) * G2(m2, i, j);
+}
+__global__ void k_smol(KP P, const double *ff) {
+  CELL3
+  if (i > P.im || j > P.jm) return;
+  const double value_min = 1.e-9, epsilon = 1.0e-14;
+  double *xm = P.s3[0], *ym = P.s3[1], *zw = P.s3[2];
+  const double fc = G3(ff, i, j, k);
+  if (k <= P.kbm1 && j >= 2 && j <= P.jmm1 && i >= 2) {
+    const double fw = G3(ff, i - 1, j, k);
+    double r = 0.;
+    if (!(fc < value_min || fw < value_min)) {
+      const double m = G3(xm, i, j, k);
+      const double udx = fabs(m);
+      const double u2dt = P.dti2 * m * m * 2. / (F2(aru, i, j) * (dt_(i - 1, j) + dt_(i, j)));
+      const double mol = (fc - fw) / (fw + fc + epsilon);
+      r = (udx - u2dt) * mol * P.sw;
+      if (fabs(udx) < fabs(u2dt)) r = 0.;
+    }
+    G3(xm, i, j, k) = r;
+  }
+  if (k <= P.kbm1 && j >= 2 && i >= 2 && i <= P.imm1) {
+    const double fs = G3(ff, i, j - 1, k);
+    double r = 0.;
+    if (!(fc < value_min || fs < value_min)) {
+      const double m = G3(ym, i, j, k);
+      const double vdy = fabs(m);
+      const double v2dt = P.dti2 * m * m * 2. / (F2(arv, i, j) * (dt_(i, j - 1) + dt_(i, j)));
+      const double mol = (fc - fs) / (fs + fc + epsilon);
+      r = (vdy - v2dt) * mol * P.sw;
+      if (fabs(vdy) < fabs(v2dt)) r = 0.;
+    }
+    G3(ym, i, j, k) = r;
+  }
+  if (k >= 2 && k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
+    const double fu = G3(ff, i, j, k - 1);
+    double r = 0.;
+    if (!(fc < value_min || fu < value_min)) {
+      const double m = G3(zw, i, j, k);
+      const double wdz = fabs(m);
+      const double w2dt = P.dti2 * m * m / (F1(dzz, k - 1) * dt_(i, j));
+      const double mol = (fu - fc) / (fc + fu + epsilon);
+      r = (wdz - w2dt) * mol * P.sw;
+      if (fabs(wdz) < fabs(w2dt)) r = 0.;
+    }
+    G3(zw, i, j, k) = r;
+  }
+}
+__global__ void k_copy3(KP P, double *dst, const double *src) {
+  CELL3
+  G3(dst, i, j, k) = G3(src, i, j, k);
+}
+__device__ __forceinline__ double advt2_xdiff(const KP &P, const double *fb, const double *fc, int i, int j, int k) {
+  const double am = 0.5 * (aam_(i, j, k) + aam_(i - 1, j, k));
+  return -am * (h_(i, j) + h_(i - 1, j)) * P.tprni *
+         ((G3(fb, i, j, k) - G3(fc, i, j, k)) - (G3(fb, i - 1, j, k) - G3(fc, i - 1, j, k))) * F2(dum, i, j) *
+         (dy_(i, j) + dy_(i - 1, j)) * 0.5 / (dx_(i, j) + dx_(i - 1, j));
+}
+__device__ __forceinline__ double advt2_ydiff(const KP &P, const double *fb, const double *fc, int i, int j, int k) {
+  const double am = 0.5 * (aam_(i, j, k) + aam_(i, j - 1, k));
+  return -am * (h_(i, j) + h_(i, j - 1)) * P.tprni *
+         ((G3(fb, i, j, k) - G3(fc, i, j, k)) - (G3(fb, i, j - 1, k) - G3(fc, i, j - 1, k))) * F2(dvm, i, j) *
+         (dx_(i, j) + dx_(i, j - 1)) * 0.5 / (dy_(i, j) + dy_(i, j - 1));
+}
+__global__ void k_advt2_diff(KP P, const double *fb, const double *fc, double *ff) {
+  CELL3
+  if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  G3(ff, i, j, k) = G3(ff, i, j, k) -
+                    P.dti2 * (advt2_xdiff(P, fb, fc, i + 1, j, k) - advt2_xdiff(P, fb, fc, i, j, k) +
+                              advt2_ydiff(P, fb, fc, i, j + 1, k) - advt2_ydiff(P, fb, fc, i, j, k)) /
+                        ((h_(i, j) + F2(etf, i, j)) * F2(art, i, j));
+}
+// nitera == 1: the whole of advt2 in one pass.  Mass fluxes and upwind/diffusive face fluxes are
+// formed in registers from u, v, w, fb; the first (intermediate) halo exchange of ff and the
+// trailing smol_adif flux update are dead for nitera = 1 and only smol_adif's mask survives.
+__global__ void k_advt2_fused(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
+  CELL3
+  if (!(k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1)) {
+    G3(ff, i, j, k) = G3(ff, i, j, k) * F2(fsm, i, j);                                   // solver.f:1898-1900
+    return;
+  }
+  const double art = F2(art, i, j);
+  const double fc = G3(fb, i, j, k);
+  const double dtc = dt_(i, j), dyc = dy_(i, j), dxc = dx_(i, j);
+  const double xme = 0.25 * (dyc + dy_(i + 1, j)) * (dtc + dt_(i + 1, j)) * u_(i + 1, j, k);
+  const double xmw = 0.25 * (dy_(i - 1, j) + dyc) * (dt_(i - 1, j) + dtc) * u_(i, j, k);
+  const double ymn = 0.25 * (dxc + dx_(i, j + 1)) * (dtc + dt_(i, j + 1)) * v_(i, j + 1, k);
+  const double yms = 0.25 * (dx_(i, j - 1) + dxc) * (dt_(i, j - 1) + dtc) * v_(i, j, k);
+  // solver.f:605-606 defines xmassflux for j<=jmm1 only and :612-613 ymassflux for i<=imm1 only:
+  // both hold for every face of an interior cell
+  const double xe = upw(xme, fc, G3(fb, i + 1, j, k));
+  const double xw = upw(xmw, G3(fb, i - 1, j, k), fc);
+  const double yn = upw(ymn, fc, G3(fb, i, j + 1, k));
+  const double ys = upw(yms, G3(fb, i, j - 1, k), fc);
+  double zu, zl;
+  if (k == 1) zu = w_(i, j, 1) * G3(f, i, j, 1) * art;
+  else zu = upw(w_(i, j, k), fc, G3(fb, i, j, k - 1)) * art;
+  if (k == P.kbm1) zl = 0.;
+  else zl = upw(w_(i, j, k + 1), G3(fb, i, j, k + 1), fc) * art;
+  double r = xe - xw + yn - ys + (zu - zl) / F1(dz, k);
+  r = (fc * ((h_(i, j) + F2(etb, i, j)) * art) - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
+  r = r * F2(fsm, i, j);
+  r = r - P.dti2 * (advt2_xdiff(P, fb, fcl, i + 1, j, k) - advt2_xdiff(P, fb, fcl, i, j, k) +
+                    advt2_ydiff(P, fb, fcl, i, j + 1, k) - advt2_ydiff(P, fb, fcl, i, j, k)) /
+              ((h_(i, j) + F2(etf, i, j)) * art);
+  G3(ff, i, j, k) = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bcond(4) mask + Asselin filter + rotation of t/s -- bounds_forcing.f:233-240, advance.f:444-449
+__global__ void k_ts_filter(KP P, int mask) {
+  CELL3
+  double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
+  if (mask && k <= P.kbm1 && i <= P.im && j <= P.jm) {
+    const double m = F2(fsm, i, j);
+    uf = uf * m;
+    vf = vf * m;
+    F3(uf, i, j, k) = uf;
+    F3(vf, i, j, k) = vf;
+  }
+  const double t = F3(t, i, j, k), s = F3(s, i, j, k);
+  F3(tb, i, j, k) = t + .5 * P.smoth * (uf + F3(tb, i, j, k) - 2. * t);
+  F3(t, i, j, k) = uf;
+  F3(sb, i, j, k) = s + .5 * P.smoth * (vf + F3(sb, i, j, k) - 2. * s);
+  F3(s, i, j, k) = vf;
+}
+__global__ void k_mask_ts(KP P) {   // the mask of bcond(4) alone
+  CELL3
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  const double m = F2(fsm, i, j);
+  F3(uf, i, j, k) = F3(uf, i, j, k) * m;
+  F3(vf, i, j, k) = F3(vf, i, j, k) * m;
+}
+__global__ void k_mask_uv(KP P) {   // the mask of bcondorl(3) alone
+  CELL3
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  F3(uf, i, j, k) = F3(uf, i, j, k) * F2(dum, i, j);
+  F3(vf, i, j, k) = F3(vf, i, j, k) * F2(dvm, i, j);
+}
+__global__ void k_mask_w(KP P) {    // bcond(5) / bcondorl(5)
+  CELL3
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  F3(w, i, j, k) = F3(w, i, j, k) * F2(fsm, i, j);
+}
+
+// restore_interior, device part -- bounds_forcing.f:1086-1120 (interpolate, relax, mask)
+__global__ void k_restore(KP P, double fold, double fnew) {
+  CELL3
+  if (k > P.kbm1) return;
+  double t = F3(t, i, j, k), tb = F3(tb, i, j, k), s = F3(s, i, j, k), sb = F3(sb, i, j, k);
+  if (i <= P.im && j <= P.jm) {
+    const double tr = fold * F3(trstrb, i, j, k) + fnew * F3(trstrf, i, j, k);
+    const double sr = fold * F3(srstrb, i, j, k) + fnew * F3(srstrf, i, j, k);
+    const double ta = fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
+    F3(trstr, i, j, k) = tr;
+    F3(srstr, i, j, k) = sr;
+    F3(taurstr, i, j, k) = ta;
+    const double c = 2. * P.dti / 86400.;
+    t = t + c * ta * (tr - t);
+    tb = tb + c * ta * (tr - tb);
+    s = s + c * ta * (sr - s);
+    sb = sb + c * ta * (sr - sb);
+  }
+  const double m = F2(fsm, i, j);
+  F3(t, i, j, k) = t * m;
+  F3(tb, i, j, k) = tb * m;
+  F3(s, i, j, k) = s * m;
+  F3(sb, i, j, k) = sb * m;
+}
+// trstrb = trstrf etc. for k <= kbm1 (bounds_forcing.f:1056-1064)
+__global__ void k_restore_shift(KP P) {
+  CELL3
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  F3(trstrb, i, j, k) = F3(trstrf, i, j, k);
+  F3(srstrb, i, j, k) = F3(srstrf, i, j, k);
+  F3(taurstrb, i, j, k) = F3(taurstrf, i, j, k);
+}
+// trstrf(1:im,1:jm,:) = tr ; srstrf = sr ; taurstrf = 1./trst (whole array)
+__global__ void k_restore_load(KP P, const double *tr, const double *sr, double tau) {
+  CELL3
+  F3(taurstrf, i, j, k) = tau;
+  if (i > P.im || j > P.jm) return;
+  const size_t n = ((size_t)(k - 1) * P.jm + (size_t)(j - 1)) * P.im + (size_t)(i - 1);   // (im,jm,kb) record
+  F3(trstrf, i, j, k) = tr[n];
+  F3(srstrf, i, j, k) = sr[n];
+}
+
+// ---------------------------------------------------------------------------------------------
+// dens -- solver.f:1162-1209.  abs(sr)**1.5 is formed as sr*sqrt(sr) in double-double so that it
+// is correctly rounded (glibc's pow, which the reference calls, is within 2^-12 ulp of that).
+__device__ __forceinline__ double pow15(double x) {
+  if (x == 0.) return 0.;
+  const double s = sqrt(x);
+  const double e = __builtin_fma(-s, s, x) / (2. * s);   // sqrt(x) = s + e
+  const double p = x * s;
+  const double pe = __builtin_fma(x, s, -p);             // x*s = p + pe
+  return p + (pe + x * e);
+}
+__global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
+  CELL3
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  const double tr = G3(ti, i, j, k) + P.tbias;
+  const double sr = G3(si, i, j, k) + P.sbias;
+  const double tr2 = tr * tr, tr3 = tr2 * tr, tr4 = tr3 * tr;
+  const double p = P.grav * P.rhoref * (-F1(zz, k) * h_(i, j)) * 1.e-5;
+  double rhor = -0.157406 + 6.793952e-2 * tr - 9.095290e-3 * tr2 + 1.001685e-4 * tr3 - 1.120083e-6 * tr4 + 6.536332e-9 * tr4 * tr;
+  rhor = rhor + (0.824493 - 4.0899e-3 * tr + 7.6438e-5 * tr2 - 8.2467e-7 * tr3 + 5.3875e-9 * tr4) * sr +
+         (-5.72466e-3 + 1.0227e-4 * tr - 1.6546e-6 * tr2) * pow15(fabs(sr)) + 4.8314e-4 * sr * sr;
+  const double cr = 1449.1 + .0821 * p + 4.55 * tr - .045 * tr2 + 1.34 * (sr - 35.);
+  rhor = rhor + 1.e5 * p / (cr * cr) * (1. - 2. * p / (cr * cr));
+  G3(rhoo, i, j, k) = rhor / P.rhoref * F2(fsm, i, j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// realvertvl -- solver.f:2024-2067.  The zero-gradient edge copies (:2057-2060) become a clamped
+// source index; the mask (:2062-2064) is applied on store.
+__global__ void k_realvertvl(KP P) {
+  CELL3
+  double v = 0.;
+  if (k <= P.kbm1 && i <= P.im && j <= P.jm) {
+    const int a = (P.W && i == 1) ? 2 : ((P.E && i == P.im) ? P.imm1 : i);
+    const int b = (P.S && j == 1) ? 2 : ((P.N && j == P.jm) ? P.jmm1 : j);
+    if (a >= 2 && a <= P.imm1 && b >= 2 && b <= P.jmm1) {
+      const double zzk = F1(zz, k);
+#define TPS(ii, jj) (zzk * dt_(ii, jj) + F2(et, ii, jj))
+      const double tc = TPS(a, b);
+      const double dxr = 2.0 / (dx_(a + 1, b) + dx_(a, b));
+      const double dxl = 2.0 / (dx_(a, b) + dx_(a - 1, b));
+      const double dyt = 2.0 / (dy_(a, b + 1) + dy_(a, b));
+      const double dyb = 2.0 / (dy_(a, b) + dy_(a, b - 1));
+      v = 0.5 * (w_(a, b, k) + w_(a, b, k + 1)) +
+          0.5 * (u_(a + 1, b, k) * (TPS(a + 1, b) - tc) * dxr + u_(a, b, k) * (tc - TPS(a - 1, b)) * dxl +
+                 v_(a, b + 1, k) * (TPS(a, b + 1) - tc) * dyt + v_(a, b, k) * (tc - TPS(a, b - 1)) * dyb) +
+          (1.0 + zzk) * (F2(etf, a, b) - F2(etb, a, b)) / P.dti2;
+#undef TPS
+    }
+    v = F2(fsm, i, j) * v;
+  }
+  F3(wr, i, j, k) = v;
+}
+
+__global__ void k_fill(double *p, size_t n, double v) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; t < n; t += stride) p[t] = v;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+void launch_advct_a(pomgpu_ctx *c) { LAUNCH(c, k_advct_a, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_advct_b(pomgpu_ctx *c) { LAUNCH(c, k_advct_b, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_advct_c(pomgpu_ctx *c) { LAUNCH(c, k_advct_c, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_aam(pomgpu_ctx *c) { LAUNCH(c, k_aam, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb) { LAUNCH(c, k_roundtrip, grid3(c->P, c->P.kb), blk2(), c->P, a, b, fix_kb); }
+void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf) {
+  LAUNCH(c, k_advq_flux, grid3(c->P, c->P.kb), blk2(), c->P, q, qb, xf, yf);
+}
+void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *xf, const double *yf, int zero_else) {
+  LAUNCH(c, k_advq_step, grid3(c->P, c->P.kb), blk2(), c->P, q, qb, qf, xf, yf, zero_else);
+}
+void launch_q_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_q_filter, grid3(c->P, c->P.kb), blk2(), c->P, mask); }
+void launch_mask_q(pomgpu_ctx *c) { LAUNCH(c, k_mask_q, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {
+  LAUNCH(c, k_advt1, grid3(c->P, c->P.kb), blk2(), c->P, (const double *)fb, (const double *)f, fclim, ff);
+  LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f);
+}
+void launch_copy_kb(pomgpu_ctx *c, double *f) { LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f); }
+void launch_advt2_mass(pomgpu_ctx *c) { LAUNCH(c, k_advt2_mass, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_advt2_step(pomgpu_ctx *c, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
+  LAUNCH(c, k_advt2_step, grid3(c->P, c->P.kb), blk2(), c->P, fbmem, f, eta, ff, itera);
+}
+void launch_mask3(pomgpu_ctx *c, double *a, const double *m2) { LAUNCH(c, k_mask3, grid3(c->P, c->P.kb), blk2(), c->P, a, m2); }
+void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, grid3(c->P, c->P.kb), blk2(), c->P, ff); }
+void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, grid3(c->P, c->P.kb), blk2(), c->P, dst, src); }
+void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, grid3(c->P, c->P.kb), blk2(), c->P, fb, fc, ff); }
+void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
+  LAUNCH(c, k_advt2_fused, grid3(c->P, c->P.kb), blk2(), c->P, fb, f, fc, ff);
+}
+void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, grid3(c->P, c->P.kb), blk2(), c->P, mask); }
+void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_mask_w(pomgpu_ctx *c) { LAUNCH(c, k_mask_w, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_restore(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore, grid3(c->P, c->P.kb), blk2(), c->P, fold, fnew); }
+void launch_restore_shift(pomgpu_ctx *c) { LAUNCH(c, k_restore_shift, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau) { LAUNCH(c, k_restore_load, grid3(c->P, c->P.kb), blk2(), c->P, tr, sr, tau); }
+void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, grid3(c->P, c->P.kb), blk2(), c->P, si, ti, rhoo); }
+void launch_realvertvl(pomgpu_ctx *c) { LAUNCH(c, k_realvertvl, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  LAUNCH(c, k_fill, dim3(blocks), dim3(256), p, n, v);
+}

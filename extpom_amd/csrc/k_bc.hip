@@ -1,0 +1,191 @@
+// k_bc.hip -- open-boundary conditions that run inside the internal mode: bcond(4), bcond(6)
+// (bounds_forcing.f:151-324) and bcondorl(3) (:418-487).  Only the cells on a physical edge are
+// touched, so these kernels are launched over the four edge lines (blockIdx.y selects the line),
+// not over the field; the whole-field mask multiplies that end each branch are fused into the
+// Asselin-filter passes that follow (k_adv.hip).
+//
+// Corner precedence: the reference sweeps east/west inside its j-loop and then south/north inside
+// its i-loop, so at a corner cell the south/north value wins; the east/west lines therefore skip
+// the corner cells that a physical south/north edge also owns.
+#include "pomgpu_internal.hpp"
+
+#define EDGE_CELL(ncorner_skip)                                                              \
+  const int t = TID_I, line = (int)blockIdx.y, k = TID_K;                                    \
+  int i, j;                                                                                  \
+  if (line == 0) { if (!P.W || t > P.jm) return; i = 1; j = t; }                             \
+  else if (line == 1) { if (!P.E || t > P.jm) return; i = P.im; j = t; }                     \
+  else if (line == 2) { if (!P.S || t > P.im) return; i = t; j = 1; }                        \
+  else { if (!P.N || t > P.im) return; i = t; j = P.jm; }                                    \
+  if (ncorner_skip && line < 2 && ((P.S && j == 1) || (P.N && j == P.jm))) return;
+
+// bcond(4): upstream / inflow T,S on the open edges (uf = T, vf = S) -- bounds_forcing.f:155-231
+__global__ void k_bcond4_edges(KP P) {
+  EDGE_CELL(1)
+  if (k > P.kbm1) return;
+  const bool vert = (k != 1 && k != P.kbm1);
+  double u1, wm, tv, sv;
+  if (line == 1) {          // east
+    u1 = 2. * F3(u, P.im, j, k) * P.dti / (F2(dx, P.im, j) + F2(dx, P.imm1, j));
+    if (u1 <= 0.) {
+      tv = F3(t, P.im, j, k) - u1 * (BDJ(tbe, j, k) - F3(t, P.im, j, k));
+      sv = F3(s, P.im, j, k) - u1 * (BDJ(sbe, j, k) - F3(s, P.im, j, k));
+    } else {
+      tv = F3(t, P.im, j, k) - u1 * (F3(t, P.im, j, k) - F3(t, P.imm1, j, k));
+      sv = F3(s, P.im, j, k) - u1 * (F3(s, P.im, j, k) - F3(s, P.imm1, j, k));
+      if (vert) {
+        wm = .5 * (F3(w, P.imm1, j, k) + F3(w, P.imm1, j, k + 1)) * P.dti / ((F1(zz, k - 1) - F1(zz, k + 1)) * F2(dt, P.imm1, j));
+        tv = tv - wm * (F3(t, P.imm1, j, k - 1) - F3(t, P.imm1, j, k + 1));
+        sv = sv - wm * (F3(s, P.imm1, j, k - 1) - F3(s, P.imm1, j, k + 1));
+      }
+    }
+  } else if (line == 0) {   // west
+    u1 = 2. * F3(u, 2, j, k) * P.dti / (F2(dx, 1, j) + F2(dx, 2, j));
+    if (u1 >= 0.) {
+      tv = F3(t, 1, j, k) - u1 * (F3(t, 1, j, k) - BDJ(tbw, j, k));
+      sv = F3(s, 1, j, k) - u1 * (F3(s, 1, j, k) - BDJ(sbw, j, k));
+    } else {
+      tv = F3(t, 1, j, k) - u1 * (F3(t, 2, j, k) - F3(t, 1, j, k));
+      sv = F3(s, 1, j, k) - u1 * (F3(s, 2, j, k) - F3(s, 1, j, k));
+      if (vert) {
+        wm = .5 * (F3(w, 2, j, k) + F3(w, 2, j, k + 1)) * P.dti / ((F1(zz, k - 1) - F1(zz, k + 1)) * F2(dt, 2, j));
+        tv = tv - wm * (F3(t, 2, j, k - 1) - F3(t, 2, j, k + 1));
+        sv = sv - wm * (F3(s, 2, j, k - 1) - F3(s, 2, j, k + 1));
+      }
+    }
+  } else if (line == 2) {   // south
+    u1 = 2. * F3(v, i, 2, k) * P.dti / (F2(dy, i, 1) + F2(dy, i, 2));
+    if (u1 >= 0.) {
+      tv = F3(t, i, 1, k) - u1 * (F3(t, i, 1, k) - BDI(tbs, i, k));
+      sv = F3(s, i, 1, k) - u1 * (F3(s, i, 1, k) - BDI(sbs, i, k));
+    } else {
+      tv = F3(t, i, 1, k) - u1 * (F3(t, i, 2, k) - F3(t, i, 1, k));
+      sv = F3(s, i, 1, k) - u1 * (F3(s, i, 2, k) - F3(s, i, 1, k));
+      if (vert) {
+        wm = .5 * (F3(w, i, 2, k) + F3(w, i, 2, k + 1)) * P.dti / ((F1(zz, k - 1) - F1(zz, k + 1)) * F2(dt, i, 2));
+        tv = tv - wm * (F3(t, i, 2, k - 1) - F3(t, i, 2, k + 1));
+        sv = sv - wm * (F3(s, i, 2, k - 1) - F3(s, i, 2, k + 1));
+      }
+    }
+  } else {                  // north
+    u1 = 2. * F3(v, i, P.jm, k) * P.dti / (F2(dy, i, P.jm) + F2(dy, i, P.jmm1));
+    if (u1 <= 0.) {
+      tv = F3(t, i, P.jm, k) - u1 * (BDI(tbn, i, k) - F3(t, i, P.jm, k));
+      sv = F3(s, i, P.jm, k) - u1 * (BDI(sbn, i, k) - F3(s, i, P.jm, k));
+    } else {
+      tv = F3(t, i, P.jm, k) - u1 * (F3(t, i, P.jm, k) - F3(t, i, P.jmm1, k));
+      sv = F3(s, i, P.jm, k) - u1 * (F3(s, i, P.jm, k) - F3(s, i, P.jmm1, k));
+      if (vert) {
+        wm = .5 * (F3(w, i, P.jmm1, k) + F3(w, i, P.jmm1, k + 1)) * P.dti / ((F1(zz, k - 1) - F1(zz, k + 1)) * F2(dt, i, P.jmm1));
+        tv = tv - wm * (F3(t, i, P.jmm1, k - 1) - F3(t, i, P.jmm1, k + 1));
+        sv = sv - wm * (F3(s, i, P.jmm1, k - 1) - F3(s, i, P.jmm1, k + 1));
+      }
+    }
+  }
+  F3(uf, i, j, k) = tv;
+  F3(vf, i, j, k) = sv;
+}
+
+// bcond(6): upstream q2, q2l on the open edges (uf = q2, vf = q2l), k = 1..kb -- :261-313
+__global__ void k_bcond6_edges(KP P) {
+  EDGE_CELL(1)
+  if (k > P.kb) return;
+  double u1, qv, lv;
+  if (line == 0) {
+    u1 = 2. * F3(u, 2, j, k) * P.dti / (F2(dx, 1, j) + F2(dx, 2, j));
+    if (u1 >= 0.) {
+      qv = F3(q2, 1, j, k) - u1 * (F3(q2, 1, j, k) - P.small_);
+      lv = F3(q2l, 1, j, k) - u1 * (F3(q2l, 1, j, k) - P.small_);
+    } else {
+      qv = F3(q2, 1, j, k) - u1 * (F3(q2, 2, j, k) - F3(q2, 1, j, k));
+      lv = F3(q2l, 1, j, k) - u1 * (F3(q2l, 2, j, k) - F3(q2l, 1, j, k));
+    }
+  } else if (line == 1) {
+    u1 = 2. * F3(u, P.im, j, k) * P.dti / (F2(dx, P.im, j) + F2(dx, P.imm1, j));
+    if (u1 <= 0.) {
+      qv = F3(q2, P.im, j, k) - u1 * (P.small_ - F3(q2, P.im, j, k));
+      lv = F3(q2l, P.im, j, k) - u1 * (P.small_ - F3(q2l, P.im, j, k));
+    } else {
+      qv = F3(q2, P.im, j, k) - u1 * (F3(q2, P.im, j, k) - F3(q2, P.imm1, j, k));
+      lv = F3(q2l, P.im, j, k) - u1 * (F3(q2l, P.im, j, k) - F3(q2l, P.imm1, j, k));
+    }
+  } else if (line == 2) {
+    u1 = 2. * F3(v, i, 2, k) * P.dti / (F2(dy, i, 1) + F2(dy, i, 2));
+    if (u1 >= 0.) {
+      qv = F3(q2, i, 1, k) - u1 * (F3(q2, i, 1, k) - P.small_);
+      lv = F3(q2l, i, 1, k) - u1 * (F3(q2l, i, 1, k) - P.small_);
+    } else {
+      qv = F3(q2, i, 1, k) - u1 * (F3(q2, i, 2, k) - F3(q2, i, 1, k));
+      lv = F3(q2l, i, 1, k) - u1 * (F3(q2l, i, 2, k) - F3(q2l, i, 1, k));
+    }
+  } else {
+    u1 = 2. * F3(v, i, P.jm, k) * P.dti / (F2(dy, i, P.jm) + F2(dy, i, P.jmm1));
+    if (u1 <= 0.) {
+      qv = F3(q2, i, P.jm, k) - u1 * (P.small_ - F3(q2, i, P.jm, k));
+      lv = F3(q2l, i, P.jm, k) - u1 * (P.small_ - F3(q2l, i, P.jm, k));
+    } else {
+      qv = F3(q2, i, P.jm, k) - u1 * (F3(q2, i, P.jm, k) - F3(q2, i, P.jmm1, k));
+      lv = F3(q2l, i, P.jm, k) - u1 * (F3(q2l, i, P.jm, k) - F3(q2l, i, P.jmm1, k));
+    }
+  }
+  F3(uf, i, j, k) = qv;
+  F3(vf, i, j, k) = lv;
+}
+
+// bcondorl(3): Orlanski radiation for uf, vf -- bounds_forcing.f:422-476, then the dum/dvm mask
+// (:478-485) on the rim cells only: every interior cell of uf/vf already carries its mask factor
+// from profu/profv (masks are 0/1, so the second multiply of the reference changes nothing).
+// Lines 0..5: i=1, i=2, i=im, j=1, j=2, j=jm.
+__device__ __forceinline__ double orl(double fb_in, double ff_in, double f_in2, double fb_edge, double f_in) {
+  double denom = (ff_in + fb_in - 2. * f_in2);
+  if (denom == 0.) denom = 0.01;
+  double cl = (fb_in - ff_in) / denom;
+  if (cl > 1.) cl = 1.;
+  if (cl < 0.) cl = 0.;
+  return (fb_edge * (1. - cl) + 2. * cl * f_in) / (1. + cl);
+}
+__global__ void k_bcondorl3(KP P) {
+  const int t = TID_I, line = (int)blockIdx.y, k = TID_K;
+  if (k > P.kbm1) return;
+  int i, j;
+  if (line < 3) { if (t > P.jm) return; j = t; i = (line == 0) ? 1 : ((line == 1) ? 2 : P.im); }
+  else { if (t > P.im) return; i = t; j = (line == 3) ? 1 : ((line == 4) ? 2 : P.jm); }
+  const bool jin = (j >= 2 && j <= P.jmm1), iin = (i >= 2 && i <= P.imm1);
+  double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
+  if (P.E && jin && i == P.im) {                                                            // :425-434
+    uf = orl(F3(ub, P.im - 1, j, k), F3(uf, P.im - 1, j, k), F3(u, P.im - 2, j, k), F3(ub, P.im, j, k), F3(u, P.im - 1, j, k));
+    vf = 0.;
+  }
+  if (P.W && jin && (i == 1 || i == 2)) {                                                   // :437-447
+    uf = orl(F3(ub, 3, j, k), F3(uf, 3, j, k), F3(u, 4, j, k), F3(ub, 2, j, k), F3(u, 3, j, k));
+    if (i == 1) vf = 0.;
+  }
+  if (P.S && iin && (j == 1 || j == 2)) {                                                   // :452-462
+    vf = orl(F3(vb, i, 3, k), F3(vf, i, 3, k), F3(v, i, 4, k), F3(vb, i, 2, k), F3(v, i, 3, k));
+    if (j == 1) uf = 0.;
+  }
+  if (P.N && iin && j == P.jm) {                                                            // :465-474
+    vf = orl(F3(vb, i, P.jm - 1, k), F3(vf, i, P.jm - 1, k), F3(v, i, P.jm - 2, k), F3(vb, i, P.jm, k), F3(v, i, P.jm - 1, k));
+    uf = 0.;
+  }
+  F3(uf, i, j, k) = uf * F2(dum, i, j);
+  F3(vf, i, j, k) = vf * F2(dvm, i, j);
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+void launch_bcond4_edges(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  if (!(P.W || P.E || P.S || P.N)) return;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_bcond4_edges, dim3((len + 63) / 64, 4, P.kbm1), dim3(64, 1, 1), c->P);
+}
+void launch_bcond6_edges(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  if (!(P.W || P.E || P.S || P.N)) return;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_bcond6_edges, dim3((len + 63) / 64, 4, P.kb), dim3(64, 1, 1), c->P);
+}
+void launch_bcondorl3(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_bcondorl3, dim3((len + 63) / 64, 6, P.kbm1), dim3(64, 1, 1), c->P);
+}

@@ -1,0 +1,559 @@
+// k_vert.hip -- the vertically coupled kernels of the internal mode: one thread per water column,
+// threadIdx.x along i.  At a given k all 64 lanes of a wavefront read one contiguous 512-byte row
+// segment, so the k-loops stream whole planes coalesced.  The Thomas recurrences (profq, proft,
+// profu, profv) keep their ee/gg work vectors in per-thread private arrays instead of the five to
+// eleven full 3-D temporaries the reference streams through memory (solver.f:1224-1230,1552-1554).
+#include "pomgpu_internal.hpp"
+
+#define dt_(i, j) F2(dt, i, j)
+#define dx_(i, j) F2(dx, i, j)
+#define dy_(i, j) F2(dy, i, j)
+#define h_(i, j) F2(h, i, j)
+#define u_(i, j, k) F3(u, i, j, k)
+#define v_(i, j, k) F3(v, i, j, k)
+#define w_(i, j, k) F3(w, i, j, k)
+
+#define COL2                               \
+  const int i = TID_I, j = TID_J;          \
+  if (i > P.iml || j > P.jml) return;
+
+// ---------------------------------------------------------------------------------------------
+// baropg -- solver.f:848-940.  The running vertical sum lives in a register; density anomalies
+// rho-rmean are formed on the fly (the reference subtracts rmean in place first, :854).
+__global__ void k_baropg(KP P) {
+  COL2
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  const double dtc = dt_(i, j), dtw = dt_(i - 1, j), dts = dt_(i, j - 1);
+  const double sx = .25 * (dtc + dtw), sy = .25 * (dtc + dts);
+  const double mx = F2(dum, i, j), my = F2(dvm, i, j);
+  const double ex = dy_(i, j) + dy_(i - 1, j), ey = dx_(i, j) + dx_(i, j - 1);
+  double rc0 = F3(rho, i, j, 1) - F3(rmean, i, j, 1);
+  double rw0 = F3(rho, i - 1, j, 1) - F3(rmean, i - 1, j, 1);
+  double rs0 = F3(rho, i, j - 1, 1) - F3(rmean, i, j - 1, 1);
+  double ax = .5 * P.grav * (-F1(zz, 1)) * (dtc + dtw) * (rc0 - rw0);                       // :859-860
+  double ay = .5 * P.grav * (-F1(zz, 1)) * (dtc + dts) * (rc0 - rs0);                       // :895-896
+  F3(drhox, i, j, 1) = P.ramp * (sx * ax * mx * ex);                                        // :883-885,931
+  F3(drhoy, i, j, 1) = P.ramp * (sy * ay * my * ey);
+  for (int k = 2; k <= P.kbm1; k++) {
+    const double rc = F3(rho, i, j, k) - F3(rmean, i, j, k);
+    const double rw = F3(rho, i - 1, j, k) - F3(rmean, i - 1, j, k);
+    const double rs = F3(rho, i, j - 1, k) - F3(rmean, i, j - 1, k);
+    const double zm = F1(zz, k - 1) - F1(zz, k), zp = F1(zz, k - 1) + F1(zz, k);
+    ax = ax + P.grav * .25 * zm * (dtc + dtw) * (rc - rw + rc0 - rw0) +
+         P.grav * .25 * zp * (dtc - dtw) * (rc + rw - rc0 - rw0);                           // :867-875
+    ay = ay + P.grav * .25 * zm * (dtc + dts) * (rc - rs + rc0 - rs0) +
+         P.grav * .25 * zp * (dtc - dts) * (rc + rs - rc0 - rs0);                           // :903-911
+    F3(drhox, i, j, k) = P.ramp * (sx * ax * mx * ex);
+    F3(drhoy, i, j, k) = P.ramp * (sy * ay * my * ey);
+    rc0 = rc; rw0 = rw; rs0 = rs;
+  }
+  F3(drhox, i, j, P.kb) = P.ramp * F3(drhox, i, j, P.kb);                                   // :928-935, k=kb
+  F3(drhoy, i, j, P.kb) = P.ramp * F3(drhoy, i, j, P.kb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mode_internal: make the depth mean of (u,v) equal (ua,va) -- advance.f:365-393
+__global__ void k_int_uvmean(KP P) {
+  COL2
+  double su = 0., sv = 0.;
+  for (int k = 1; k <= P.kbm1; k++) {
+    const double dzk = F1(dz, k);
+    su = su + u_(i, j, k) * dzk;
+    sv = sv + v_(i, j, k) * dzk;
+  }
+  if (j <= P.jm && i >= 2 && i <= P.im) {
+    const double c = (F2(utb, i, j) + F2(utf, i, j)) / (dt_(i, j) + dt_(i - 1, j));
+    for (int k = 1; k <= P.kbm1; k++) F3(u, i, j, k) = (u_(i, j, k) - su) + c;
+  }
+  if (i <= P.im && j >= 2 && j <= P.jm) {
+    const double c = (F2(vtb, i, j) + F2(vtf, i, j)) / (dt_(i, j) + dt_(i, j - 1));
+    for (int k = 1; k <= P.kbm1; k++) F3(v, i, j, k) = (v_(i, j, k) - sv) + c;
+  }
+  F2(tps, i, j) = sv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vertvl (+ the fsm mask of bcondorl(5) when mask != 0) -- solver.f:1970-2021, bounds_forcing.f:550-561
+__global__ void k_vertvl(KP P, int mask) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  const double m = mask ? F2(fsm, i, j) : 1.;
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) {
+    if (mask) for (int k = 1; k <= P.kbm1; k++) F3(w, i, j, k) = w_(i, j, k) * m;
+    return;
+  }
+  const double cw = .25 * (dy_(i, j) + dy_(i - 1, j)) * (dt_(i, j) + dt_(i - 1, j));
+  const double ce = .25 * (dy_(i + 1, j) + dy_(i, j)) * (dt_(i + 1, j) + dt_(i, j));
+  const double cs = .25 * (dx_(i, j) + dx_(i, j - 1)) * (dt_(i, j) + dt_(i, j - 1));
+  const double cn = .25 * (dx_(i, j + 1) + dx_(i, j)) * (dt_(i, j + 1) + dt_(i, j));
+  const double area = dx_(i, j) * dy_(i, j);
+  const double det = (F2(etf, i, j) - F2(etb, i, j)) / P.dti2;
+  double wk = 0.5 * (F2(vfluxb, i, j) + F2(vfluxf, i, j));                                  // :2004
+  F3(w, i, j, 1) = mask ? wk * m : wk;
+  for (int k = 1; k <= P.kbm1; k++) {
+    wk = wk + F1(dz, k) * ((ce * u_(i + 1, j, k) - cw * u_(i, j, k) + cn * v_(i, j + 1, k) - cs * v_(i, j, k)) / area + det);
+    F3(w, i, j, k + 1) = (mask && k + 1 <= P.kbm1) ? wk * m : wk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// profq -- solver.f:1212-1538
+// (1) surface/bottom boundary values (2-D) -- :1281-1288   scratch: s2[4]=utau2
+__global__ void k_profq_bc(KP P) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  double ut = 0.;
+  if (i <= P.imm1 && j <= P.jmm1) {
+    ut = sqrt(sq(.5 * (F2(wusurf, i, j) + F2(wusurf, i + 1, j))) + sq(.5 * (F2(wvsurf, i, j) + F2(wvsurf, i, j + 1))));
+    F3(uf, i, j, P.kb) =
+        sqrt(sq(.5 * (F2(wubot, i, j) + F2(wubot, i + 1, j))) + sq(.5 * (F2(wvbot, i, j) + F2(wvbot, i, j + 1)))) * P.const1_profq;
+  }
+  G2(P.s2[4], i, j) = ut;
+}
+// speed of sound (squared root form) at one level -- :1308-1316
+__device__ __forceinline__ double profq_cc(const KP &P, int i, int j, int k) {
+  const double tp = F3(t, i, j, k) + P.tbias;
+  const double sp = F3(s, i, j, k) + P.sbias;
+  const double p = P.grav * P.rhoref * (-F1(zz, k) * h_(i, j)) * 1.e-4;
+  double cc = 1449.1 + .00821 * p + 4.55 * tp - .045 * sq(tp) + 1.34 * (sp - 35.0);
+  cc = cc / sqrt((1. - .01642 * p / cc) * (1. - 0.40 * p / sq(cc)));
+  return cc;
+}
+__device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, double ccm, double cck) {   // :1327-1330
+  return P.grav * (F3(rho, i, j, k - 1) - F3(rho, i, j, k)) / (F1(dzz, k - 1) * h_(i, j)) +
+         sq(P.grav) * 2. / (sq(ccm) + sq(cck));
+}
+// (2) shear + buoyancy production (exchanged before the solves) -- :1359-1373   scratch: s3[0]=prod
+__global__ void k_profq_prod(KP P) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  double *prod = P.s3[0];
+  G3(prod, i, j, 1) = 0.;
+  G3(prod, i, j, P.kb) = 0.;
+  const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  if (!in) {
+    for (int k = 2; k <= P.kbm1; k++) G3(prod, i, j, k) = 0.;
+    return;
+  }
+  const double dh = h_(i, j) + F2(etf, i, j);
+  const double sef = 1., shiw = 0.;
+  double ccm = profq_cc(P, i, j, 1);
+  for (int k = 2; k <= P.kbm1; k++) {
+    const double cck = profq_cc(P, i, j, k);
+    const double bg = profq_boygr(P, i, j, k, ccm, cck);
+    const double km = F3(km, i, j, k);
+    double p = km * .25 * sef *
+                   (sq(u_(i, j, k) - u_(i, j, k - 1) + u_(i + 1, j, k) - u_(i + 1, j, k - 1)) +
+                    sq(v_(i, j, k) - v_(i, j, k - 1) + v_(i, j + 1, k) - v_(i, j + 1, k - 1))) /
+                   sq(F1(dzz, k - 1) * dh) -
+               shiw * km * bg;
+    p = p + F3(kh, i, j, k) * bg;
+    G3(prod, i, j, k) = p;
+    ccm = cck;
+  }
+}
+// (3) everything else: length scale, stability, two Thomas solves, new km/kh/kq
+__global__ void k_profq(KP P) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
+  const double *prod = P.s3[0];
+  double ee[POMGPU_KBMAX], gg[POMGPU_KBMAX], gh[POMGPU_KBMAX];
+  const int kb = P.kb, kbm1 = P.kbm1;
+  const double dh = h_(i, j) + F2(etf, i, j);
+  const double utau2 = G2(P.s2[4], i, j);
+  const double l0 = surfl * utau2 / P.grav;                                                 // :1299
+  const double umol2 = 2. * P.umol;
+  // buoyancy gradient, length scale, gh -- :1322-1356
+  double ccm = profq_cc(P, i, j, 1);
+  gh[0] = 0.;
+  gh[kb - 1] = 0.;
+  F3(l, i, j, 1) = P.kappa * l0;
+  F3(l, i, j, kb) = 0.;
+  for (int k = 2; k <= kbm1; k++) {
+    const double cck = profq_cc(P, i, j, k);
+    const double q2b = fabs(F3(q2b, i, j, k)), q2lb = fabs(F3(q2lb, i, j, k));
+    F3(q2b, i, j, k) = q2b;
+    F3(q2lb, i, j, k) = q2lb;
+    const double bg = profq_boygr(P, i, j, k, ccm, cck);
+    double l = fabs(q2lb / q2b);
+    if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
+    F3(l, i, j, k) = l;
+    gh[k - 1] = fmin(sq(l) * bg / q2b, .028);
+    ccm = cck;
+  }
+  // dtef (stf = 1) -- :1380-1392
+  for (int k = 1; k <= kb; k++)
+    F3(dtef, i, j, k) = sqrt(fabs(F3(q2b, i, j, k))) * 1. / (b1 * F3(l, i, j, k) + P.small_);
+  // q2 solve -- :1258-1267 (a, c), :1296-1297, :1394-1413
+  ee[0] = 0.;
+  gg[0] = P.cb_profq * utau2;
+  {
+    double kqm = F3(kq, i, j, 1), kqc = F3(kq, i, j, 2);
+    for (int k = 2; k <= kbm1; k++) {
+      const double kqp = F3(kq, i, j, k + 1);
+      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);
+      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
+      double g = 1. / (a + c * (1. - ee[k - 2]) - (2. * P.dti2 * F3(dtef, i, j, k) + 1.));
+      ee[k - 1] = a * g;
+      gg[k - 1] = (-2. * P.dti2 * G3(prod, i, j, k) + c * gg[k - 2] - F3(uf, i, j, k)) * g;
+      kqm = kqc; kqc = kqp;
+    }
+  }
+  {
+    double x = F3(uf, i, j, kb);
+    for (int ki = kbm1; ki >= 1; ki--) {
+      x = ee[ki - 1] * x + gg[ki - 1];
+      F3(uf, i, j, ki) = (ki >= 2) ? fabs(x) : x;                                           // :1467
+    }
+  }
+  // q2l solve -- :1417-1455
+  F3(vf, i, j, 1) = 0.;
+  F3(vf, i, j, kb) = 0.;
+  ee[1] = 0.;
+  gg[1] = -P.kappa * F1(z, 2) * dh * F3(q2, i, j, 2);
+  const double vbot = P.kappa * (1 + F1(z, kbm1)) * dh * F3(q2, i, j, kbm1);
+  for (int k = 2; k <= kbm1; k++) {
+    const double zk = F1(z, k);
+    F3(dtef, i, j, k) = F3(dtef, i, j, k) *
+                        (1. + e2 * sq((1. / fabs(zk - F1(z, 1)) + 1. / fabs(zk - F1(z, kb))) * F3(l, i, j, k) / (dh * P.kappa)));
+  }
+  {
+    double kqm = F3(kq, i, j, 2), kqc = F3(kq, i, j, 3 <= kb ? 3 : kb);
+    for (int k = 3; k <= kbm1; k++) {
+      const double kqp = F3(kq, i, j, k + 1);
+      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);
+      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
+      const double rhs = (k == kbm1) ? vbot : F3(vf, i, j, k);
+      double g = 1. / (a + c * (1. - ee[k - 2]) - (P.dti2 * F3(dtef, i, j, k) + 1.));
+      ee[k - 1] = a * g;
+      gg[k - 1] = (P.dti2 * (-G3(prod, i, j, k) * F3(l, i, j, k) * e1) + c * gg[k - 2] - rhs) * g;
+      kqm = kqc; kqc = kqp;
+    }
+  }
+  {
+    double x = 0.;   // vf(kb)
+    for (int ki = kbm1; ki >= 2; ki--) {
+      x = ee[ki - 1] * x + gg[ki - 1];
+      F3(vf, i, j, ki) = fabs(x);                                                           // :1468
+    }
+  }
+  // stability functions and new mixing coefficients -- :1474-1506, cosmetics+mask :1510-1535
+  const double coef4 = 18. * a1 * a1 + 9. * a1 * a2, coef5 = 9. * a1 * a2;
+  const double coef1 = a2 * (1. - 6. * a1 / b1 * 1.), coef2 = 3. * a2 * b2 / 1. + 18. * a1 * a2,
+               coef3 = a1 * (1. - 3. * c1 - 6. * a1 / b1 * 1.);
+  // which cells take this column's km/kh/kq: itself unless it is a physical-edge cell (those copy
+  // their inward neighbour, north/south first, then east/west)
+  const bool repl = (P.W && i == 1) || (P.E && i == P.im) || (P.S && j == 1) || (P.N && j == P.jm);
+  const int ti = (P.W && i == 2) ? 1 : ((P.E && i == P.imm1) ? P.im : 0);
+  const int tj = (P.S && j == 2) ? 1 : ((P.N && j == P.jmm1) ? P.jm : 0);
+  for (int k = 1; k <= kb; k++) {
+    const double g = gh[k - 1];
+    const double sh = coef1 / (1. - coef2 * g);
+    double sm = coef3 + sh * coef4 * g;
+    sm = sm / (1. - coef5 * g);
+    const double pl = F3(l, i, j, k) * sqrt(fabs(F3(q2, i, j, k)));
+    if (repl) continue;
+    const double kq = (pl * .41 * sh + F3(kq, i, j, k)) * .5;
+    const double km = (pl * sm + F3(km, i, j, k)) * .5;
+    const double kh = (pl * sh + F3(kh, i, j, k)) * .5;
+    // own cell: in place.  Physical-edge cells that copy this column are written to the staging
+    // arrays s3[1..3] (their own threads are still reading the old kq) and moved by k_profq_rim.
+    {
+      const double m = F2(fsm, i, j);
+      F3(kq, i, j, k) = kq * m;
+      F3(km, i, j, k) = km * m;
+      F3(kh, i, j, k) = kh * m;
+    }
+#define PUT(ii, jj)                                  \
+  {                                                  \
+    const double m = F2(fsm, ii, jj);                \
+    G3(P.s3[1], ii, jj, k) = km * m;                 \
+    G3(P.s3[2], ii, jj, k) = kh * m;                 \
+    G3(P.s3[3], ii, jj, k) = kq * m;                 \
+  }
+    if (ti) PUT(ti, j)
+    if (tj) PUT(i, tj)
+    if (ti && tj) PUT(ti, tj)
+#undef PUT
+  }
+}
+
+// (4) move the staged km/kh/kq of the physical-edge cells into place (solver.f:1510-1529)
+__global__ void k_profq_rim(KP P) {
+  const int t = TID_I, line = (int)blockIdx.y, k = TID_K;
+  if (k > P.kb) return;
+  int i, j;
+  if (line == 0) { if (!P.W || t > P.jm) return; i = 1; j = t; }
+  else if (line == 1) { if (!P.E || t > P.jm) return; i = P.im; j = t; }
+  else if (line == 2) { if (!P.S || t > P.im) return; i = t; j = 1; }
+  else { if (!P.N || t > P.im) return; i = t; j = P.jm; }
+  F3(km, i, j, k) = G3(P.s3[1], i, j, k);
+  F3(kh, i, j, k) = G3(P.s3[2], i, j, k);
+  F3(kq, i, j, k) = G3(P.s3[3], i, j, k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// proft -- solver.f:1541-1683
+__global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  const double r_[5] = {.58, .62, .67, .77, .78}, ad1_[5] = {.35, .60, 1.0, 1.5, 1.4}, ad2_[5] = {23., 20., 17., 14., 7.9};
+  double ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
+  const int kbm1 = P.kbm1, kbm2 = P.kbm2;
+  const double dh = h_(i, j) + F2(etf, i, j);
+  const bool sw_ = (nbc == 2 || nbc == 4);
+  const double r = r_[P.ntp - 1], ad1 = ad1_[P.ntp - 1], ad2 = ad2_[P.ntp - 1];
+  const double swr = sw_ ? F2(swrad, i, j) : 0.;
+  // penetrative radiation at level k (0 at kb); the reference evaluates the exponentials in
+  // REAL(16) and rounds once (:1608-1611) -- here plain fp64 exp, see DESIGN.md (tolerance)
+#define RAD(k) ((sw_ && (k) <= kbm1) ? swr * (r * exp(F1(z, k) * dh / ad1) + (1. - r) * exp(F1(z, k) * dh / ad2)) : 0.)
+#define ACOEF(k) (((k) <= kbm2) ? -P.dti2 * (F3(kh, i, j, (k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
+#define CCOEF(k) (-P.dti2 * (F3(kh, i, j, k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
+  const double a1 = ACOEF(1);
+  double radk = RAD(1);
+  if (nbc == 1) {
+    ee[0] = a1 / (a1 - 1.);
+    double g = P.dti2 * G2(wfsurf, i, j) / (F1(dz, 1) * dh) - G3(f, i, j, 1);
+    gg[0] = g / (a1 - 1.);
+  } else if (nbc == 2) {
+    ee[0] = a1 / (a1 - 1.);
+    double g = P.dti2 * (G2(wfsurf, i, j) + radk - RAD(2)) / (F1(dz, 1) * dh) - G3(f, i, j, 1);
+    gg[0] = g / (a1 - 1.);
+  } else {
+    ee[0] = 0.;
+    gg[0] = G2(fsurf, i, j);
+  }
+  radk = RAD(2);
+  for (int k = 2; k <= kbm2; k++) {
+    const double a = ACOEF(k), c = CCOEF(k);
+    const double radn = RAD(k + 1);
+    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
+    ee[k - 1] = a * g;
+    gg[k - 1] = (c * gg[k - 2] - G3(f, i, j, k) + P.dti2 * (radk - radn) / (dh * F1(dz, k))) * g;
+    radk = radn;
+  }
+  {
+    const double c = CCOEF(kbm1);
+    // radk == rad(kbm1) here (also when the loop above did not run: kbm2 < 2 is not supported)
+    double x = (c * gg[kbm2 - 1] - G3(f, i, j, kbm1) + P.dti2 * (radk - 0.) / (dh * F1(dz, kbm1))) /
+               (c * (1. - ee[kbm2 - 1]) - 1.);
+    G3(f, i, j, kbm1) = x;
+    for (int ki = kbm2; ki >= 1; ki--) {
+      x = (ee[ki - 1] * x + gg[ki - 1]);
+      G3(f, i, j, ki) = x;
+    }
+  }
+#undef RAD
+#undef ACOEF
+#undef CCOEF
+}
+
+// ---------------------------------------------------------------------------------------------
+// advu + profu -- solver.f:734-788, :1686-1780.   do_adv / do_prof select the halves so that the
+// stand-alone entry points exist; with both set the right-hand side never leaves the thread.
+__global__ void k_advu_profu(KP P, int do_adv, int do_prof) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  double rhs[POMGPU_KBMAX], ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
+  const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
+  const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  if (do_adv) {
+    if (i >= 2) {
+      // vertical advective flux at w-levels (:744-751); 0 at k=1 and k=kb
+      double fk = 0.;
+      double hc = 0., step_a = 0., step_d = 0., aru = 0.;
+      if (in) {
+        aru = F2(aru, i, j);
+        hc = P.grav * .125 * (dt_(i, j) + dt_(i - 1, j)) *
+             (F2(egf, i, j) - F2(egf, i - 1, j) + F2(egb, i, j) - F2(egb, i - 1, j) + (F2(e_atmos, i, j) - F2(e_atmos, i - 1, j)) * 2.) *
+             (dy_(i, j) + dy_(i - 1, j));
+        step_a = (h_(i, j) + F2(etb, i, j) + h_(i - 1, j) + F2(etb, i - 1, j)) * aru;
+        step_d = (h_(i, j) + F2(etf, i, j) + h_(i - 1, j) + F2(etf, i - 1, j)) * aru;
+      }
+      for (int k = 1; k <= kbm1; k++) {
+        const double fn = (k + 1 <= kbm1) ? .25 * (w_(i, j, k + 1) + w_(i - 1, j, k + 1)) * (u_(i, j, k + 1) + u_(i, j, k)) : 0.;
+        if (in) {
+          double r = F3(advx, i, j, k) + (fk - fn) * aru / F1(dz, k) -
+                     aru * .25 * (F2(cor, i, j) * dt_(i, j) * (v_(i, j + 1, k) + v_(i, j, k)) +
+                                  F2(cor, i - 1, j) * dt_(i - 1, j) * (v_(i - 1, j + 1, k) + v_(i - 1, j, k))) +
+                     hc + F3(drhox, i, j, k);                                              // :758-769
+          rhs[k - 1] = (step_a * F3(ub, i, j, k) - 2. * P.dti2 * r) / step_d;              // :778-782
+        } else {
+          rhs[k - 1] = fk;
+        }
+        fk = fn;
+      }
+      rhs[kb - 1] = 0.;
+    } else {
+      for (int k = 1; k <= kb; k++) rhs[k - 1] = 0.;
+    }
+    if (!do_prof || !in) {
+      for (int k = 1; k <= kb; k++) F3(uf, i, j, k) = rhs[k - 1];
+      return;
+    }
+    F3(uf, i, j, kb) = 0.;
+  } else {
+    if (!in) return;
+    for (int k = 1; k <= kbm1; k++) rhs[k - 1] = F3(uf, i, j, k);
+  }
+  // profu on an interior column
+  const double dh = (h_(i, j) + F2(etf, i, j) + h_(i - 1, j) + F2(etf, i - 1, j)) * .5;
+#define KMU(k) ((F3(km, i, j, k) + F3(km, i - 1, j, k)) * .5)
+#define ACO(k) (((k) <= kbm2) ? -P.dti2 * (KMU((k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
+#define CCO(k) (-P.dti2 * (KMU(k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
+  const double a1 = ACO(1);
+  ee[0] = a1 / (a1 - 1.);
+  gg[0] = (-P.dti2 * F2(wusurf, i, j) / (-F1(dz, 1) * dh) - rhs[0]) / (a1 - 1.);
+  for (int k = 2; k <= kbm2; k++) {
+    const double a = ACO(k), c = CCO(k);
+    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
+    ee[k - 1] = a * g;
+    gg[k - 1] = (c * gg[k - 2] - rhs[k - 1]) * g;
+  }
+  const double tps = 0.5 * (F2(cbc, i, j) + F2(cbc, i - 1, j)) *
+                     sqrt(sq(F3(ub, i, j, kbm1)) +
+                          sq(.25 * (F3(vb, i, j, kbm1) + F3(vb, i, j + 1, kbm1) + F3(vb, i - 1, j, kbm1) + F3(vb, i - 1, j + 1, kbm1))));
+  const double c = CCO(kbm1);
+  const double m = F2(dum, i, j);
+  double x = (c * gg[kbm2 - 1] - rhs[kbm1 - 1]) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
+  x = x * m;
+  F3(uf, i, j, kbm1) = x;
+  F2(wubot, i, j) = -tps * x;
+  for (int ki = kbm2; ki >= 1; ki--) {
+    x = (ee[ki - 1] * x + gg[ki - 1]) * m;
+    F3(uf, i, j, ki) = x;
+  }
+  F2(tps, i, j) = tps;
+#undef KMU
+#undef ACO
+#undef CCO
+}
+
+// advv + profv -- solver.f:791-845, :1783-1877
+__global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  double rhs[POMGPU_KBMAX], ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
+  const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
+  const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  if (do_adv) {
+    if (j >= 2) {
+      double fk = 0.;
+      double hc = 0., step_a = 0., step_d = 0., arv = 0.;
+      if (in) {
+        arv = F2(arv, i, j);
+        hc = P.grav * .125 * (dt_(i, j) + dt_(i, j - 1)) *
+             (F2(egf, i, j) - F2(egf, i, j - 1) + F2(egb, i, j) - F2(egb, i, j - 1) + (F2(e_atmos, i, j) - F2(e_atmos, i, j - 1)) * 2.) *
+             (dx_(i, j) + dx_(i, j - 1));
+        step_a = (h_(i, j) + F2(etb, i, j) + h_(i, j - 1) + F2(etb, i, j - 1)) * arv;
+        step_d = (h_(i, j) + F2(etf, i, j) + h_(i, j - 1) + F2(etf, i, j - 1)) * arv;
+      }
+      for (int k = 1; k <= kbm1; k++) {
+        const double fn = (k + 1 <= kbm1) ? .25 * (w_(i, j, k + 1) + w_(i, j - 1, k + 1)) * (v_(i, j, k + 1) + v_(i, j, k)) : 0.;
+        if (in) {
+          double r = F3(advy, i, j, k) + (fk - fn) * arv / F1(dz, k) +
+                     arv * .25 * (F2(cor, i, j) * dt_(i, j) * (u_(i + 1, j, k) + u_(i, j, k)) +
+                                  F2(cor, i, j - 1) * dt_(i, j - 1) * (u_(i + 1, j - 1, k) + u_(i, j - 1, k))) +
+                     hc + F3(drhoy, i, j, k);                                              // :815-826
+          rhs[k - 1] = (step_a * F3(vb, i, j, k) - 2. * P.dti2 * r) / step_d;              // :835-839
+        } else {
+          rhs[k - 1] = fk;
+        }
+        fk = fn;
+      }
+      rhs[kb - 1] = 0.;
+    } else {
+      for (int k = 1; k <= kb; k++) rhs[k - 1] = 0.;
+    }
+    if (!do_prof || !in) {
+      for (int k = 1; k <= kb; k++) F3(vf, i, j, k) = rhs[k - 1];
+      return;
+    }
+    F3(vf, i, j, kb) = 0.;
+  } else {
+    if (!in) return;
+    for (int k = 1; k <= kbm1; k++) rhs[k - 1] = F3(vf, i, j, k);
+  }
+  const double dh = .5 * (h_(i, j) + F2(etf, i, j) + h_(i, j - 1) + F2(etf, i, j - 1));
+#define KMV(k) ((F3(km, i, j, k) + F3(km, i, j - 1, k)) * .5)
+#define ACO(k) (((k) <= kbm2) ? -P.dti2 * (KMV((k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
+#define CCO(k) (-P.dti2 * (KMV(k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
+  const double a1 = ACO(1);
+  ee[0] = a1 / (a1 - 1.);
+  gg[0] = (-P.dti2 * F2(wvsurf, i, j) / (-F1(dz, 1) * dh) - rhs[0]) / (a1 - 1.);
+  for (int k = 2; k <= kbm2; k++) {
+    const double a = ACO(k), c = CCO(k);
+    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
+    ee[k - 1] = a * g;
+    gg[k - 1] = (c * gg[k - 2] - rhs[k - 1]) * g;
+  }
+  const double tps = 0.5 * (F2(cbc, i, j) + F2(cbc, i, j - 1)) *
+                     sqrt(sq(.25 * (F3(ub, i, j, kbm1) + F3(ub, i + 1, j, kbm1) + F3(ub, i, j - 1, kbm1) + F3(ub, i + 1, j - 1, kbm1))) +
+                          sq(F3(vb, i, j, kbm1)));
+  const double c = CCO(kbm1);
+  const double m = F2(dvm, i, j);
+  double x = (c * gg[kbm2 - 1] - rhs[kbm1 - 1]) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
+  x = x * m;
+  F3(vf, i, j, kbm1) = x;
+  F2(wvbot, i, j) = -tps * x;
+  for (int ki = kbm2; ki >= 1; ki--) {
+    x = (ee[ki - 1] * x + gg[ki - 1]) * m;
+    F3(vf, i, j, ki) = x;
+  }
+  F2(tps, i, j) = tps;
+#undef KMV
+#undef ACO
+#undef CCO
+}
+
+// ---------------------------------------------------------------------------------------------
+// column-mean-free Asselin filter of u,v and time rotation -- advance.f:469-514
+__global__ void k_uv_filter(KP P) {
+  COL2
+  const bool act = (i <= P.im && j <= P.jm);
+  double su = 0., sv = 0.;
+  if (act) {
+    for (int k = 1; k <= P.kbm1; k++) {
+      const double dzk = F1(dz, k);
+      su = su + (F3(uf, i, j, k) + F3(ub, i, j, k) - 2. * F3(u, i, j, k)) * dzk;
+      sv = sv + (F3(vf, i, j, k) + F3(vb, i, j, k) - 2. * F3(v, i, j, k)) * dzk;
+    }
+  }
+  for (int k = 1; k <= P.kb; k++) {
+    const double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
+    double u = F3(u, i, j, k), v = F3(v, i, j, k);
+    if (act && k <= P.kbm1) {
+      u = u + .5 * P.smoth * (uf + F3(ub, i, j, k) - 2. * u - su);
+      v = v + .5 * P.smoth * (vf + F3(vb, i, j, k) - 2. * v - sv);
+    }
+    F3(ub, i, j, k) = u;
+    F3(u, i, j, k) = uf;
+    F3(vb, i, j, k) = v;
+    F3(v, i, j, k) = vf;
+  }
+  F2(tps, i, j) = sv;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+static inline dim3 colblk() { return dim3(64, 2, 1); }
+static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
+void launch_baropg(pomgpu_ctx *c) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P); }
+void launch_int_uvmean(pomgpu_ctx *c) { LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P); }
+void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
+void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
+void launch_profq_prod(pomgpu_ctx *c) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); }
+void launch_profq(pomgpu_ctx *c) {
+  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P);
+  const KP &P = c->P;
+  if (P.W || P.E || P.S || P.N) {
+    const int len = P.im > P.jm ? P.im : P.jm;
+    LAUNCH(c, k_profq_rim, dim3((len + 63) / 64, 4, P.kb), dim3(64, 1, 1), c->P);
+  }
+}
+void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+}
+void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advu_profu, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
+void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advv_profv, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
+void launch_uv_filter(pomgpu_ctx *c) { LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P); }

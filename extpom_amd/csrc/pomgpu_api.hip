@@ -1,0 +1,696 @@
+// pomgpu_api.hip -- the C ABI of include/pomgpu.h: context, COMMON-block mirrors in HBM, and the
+// orchestration of the reference's advance.f as sequences of fused kernel launches on ONE HIP
+// stream.  Host code here only enqueues work; nothing synchronises except the calls documented
+// to do so (upload/download, check_velocity, sync).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "pomgpu.h"
+#include "pomgpu_internal.hpp"
+
+struct ProfPair { int slot; hipEvent_t a, b; };
+struct ProfState { std::vector<ProfPair> pending; std::vector<ProfPair> free_; char filter[64]; };
+static ProfState *PS(pomgpu_ctx *c) { return (ProfState *)c->prof_state; }
+
+#define SLOT2(c, n) ((c)->P.b2 + (size_t)(n) * (c)->P.n2)
+#define SLOT3(c, n) ((c)->P.b3 + (size_t)(n) * (c)->P.n3)
+#define D2(c, name) SLOT2(c, P2_##name)
+#define D3(c, name) SLOT3(c, P3_##name)
+
+static int fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    c->con.error_status = 1;   // the reference's error convention (advance.f:118,637)
+    fprintf(stderr, "pomgpu: %s\n", c->err);
+  }
+  return code;
+}
+#define HIPCHK(c, call)                                                                  \
+  do {                                                                                   \
+    hipError_t _e = (call);                                                              \
+    if (_e != hipSuccess) return fail((c), POMGPU_EHIP, "%s: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- profiling ---------------------------------------------------------------------------------
+int pomgpu_prof_slot(pomgpu_ctx *c, const char *name) {
+  ProfState *ps = PS(c);
+  if (ps->filter[0] && strcmp(ps->filter, name) != 0) return -1;
+  for (int k = 0; k < c->nprof; k++)
+    if (c->prof[k].name == name || strcmp(c->prof[k].name, name) == 0) return k;
+  if (c->nprof >= (int)(sizeof c->prof / sizeof c->prof[0])) return -1;
+  c->prof[c->nprof].name = name;
+  c->prof[c->nprof].launches = 0;
+  c->prof[c->nprof].ms = 0.;
+  return c->nprof++;
+}
+void pomgpu_prof_pre(pomgpu_ctx *c) {
+  ProfState *ps = PS(c);
+  ProfPair p;
+  if (!ps->free_.empty()) { p = ps->free_.back(); ps->free_.pop_back(); }
+  else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+  p.slot = -1;
+  (void)hipEventRecord(p.a, c->stream);
+  ps->pending.push_back(p);
+}
+void pomgpu_prof_post(pomgpu_ctx *c, int slot) {
+  ProfState *ps = PS(c);
+  ProfPair &p = ps->pending.back();
+  p.slot = slot;
+  (void)hipEventRecord(p.b, c->stream);
+}
+static void prof_drain(pomgpu_ctx *c) {
+  ProfState *ps = PS(c);
+  (void)hipStreamSynchronize(c->stream);
+  for (size_t n = 0; n < ps->pending.size(); n++) {
+    ProfPair &p = ps->pending[n];
+    float ms = 0.f;
+    if (p.slot >= 0 && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      c->prof[p.slot].launches += 1;
+      c->prof[p.slot].ms += (double)ms;
+    }
+    ps->free_.push_back(p);
+  }
+  ps->pending.clear();
+}
+extern "C" int pomgpu_prof_begin(pomgpu_ctx *c) {
+  if (!c) return POMGPU_EINVAL;
+  c->nprof = 0;
+  c->prof_on = true;
+  return POMGPU_OK;
+}
+// restrict event bracketing to one kernel (by name, e.g. "k_profq"); NULL or "" = every kernel
+extern "C" int pomgpu_prof_filter(pomgpu_ctx *c, const char *kernel_name) {
+  if (!c) return POMGPU_EINVAL;
+  ProfState *ps = PS(c);
+  snprintf(ps->filter, sizeof ps->filter, "%s", kernel_name ? kernel_name : "");
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_prof_end(pomgpu_ctx *c) {
+  if (!c) return POMGPU_EINVAL;
+  prof_drain(c);
+  c->prof_on = false;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_prof_count(pomgpu_ctx *c) { return c ? c->nprof : 0; }
+extern "C" int pomgpu_prof_get(pomgpu_ctx *c, int k, const char **name, long *launches, double *total_ms) {
+  if (!c || k < 0 || k >= c->nprof) return POMGPU_EINVAL;
+  if (name) *name = c->prof[k].name;
+  if (launches) *launches = c->prof[k].launches;
+  if (total_ms) *total_ms = c->prof[k].ms;
+  return POMGPU_OK;
+}
+
+// ---- scalars -----------------------------------------------------------------------------------
+static void sync_scalars(pomgpu_ctx *c) {
+  KP &P = c->P;
+  const pom_blkcon &k = c->con;
+  P.alpha = k.alpha; P.dte = k.dte; P.dti = k.dti; P.dti2 = k.dti2; P.dte2 = k.dte2; P.grav = k.grav;
+  P.kappa = k.kappa; P.ramp = k.ramp; P.rfe = k.rfe; P.rfn = k.rfn; P.rfs = k.rfs; P.rfw = k.rfw;
+  P.rhoref = k.rhoref; P.sbias = k.sbias; P.small_ = k.small; P.tbias = k.tbias; P.tprni = k.tprni;
+  P.umol = k.umol; P.horcon = k.horcon; P.ispi = k.ispi; P.isp2i = k.isp2i; P.smoth = k.smoth; P.sw = k.sw;
+  P.time = k.time; P.vmaxl = k.vmaxl;
+  P.mode = k.mode; P.ntp = k.ntp; P.nadv = k.nadv; P.nbct = k.nbct; P.nbcs = k.nbcs; P.nitera = k.nitera;
+  P.npg = k.npg; P.isplit = k.isplit; P.iext = k.iext; P.iint = k.iint; P.iend = k.iend;
+  // loop invariants the reference evaluates with libm pow at run time (solver.f:1273, :1297);
+  // 15.8 and 2./3. are REAL(4) literals there
+  P.const1_profq = pow(16.6, 2. / 3.) * 1.;
+  P.cb_profq = pow((double)15.8f * 100., (double)(2.f / 3.f));
+}
+
+// ---- life cycle -------------------------------------------------------------------------------
+extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.1 (gfx950)"; }
+
+extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *stream) {
+  if (!out || !d) return POMGPU_EINVAL;
+  *out = NULL;
+  if (d->kb < 4 || d->kb > POMGPU_KBMAX || d->im < 5 || d->jm < 5 || d->im > d->im_local || d->jm > d->jm_local) {
+    fprintf(stderr, "pomgpu_create: unsupported extents im=%d jm=%d kb=%d (need im,jm>=5, 4<=kb<=%d)\n", d->im, d->jm,
+            d->kb, POMGPU_KBMAX);
+    return POMGPU_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    fprintf(stderr, "pomgpu_create: no usable HIP device (count=%d, asked %d); the hot path has no CPU fallback\n", ndev,
+            device);
+    return POMGPU_ENODEV;
+  }
+  pomgpu_ctx *c = (pomgpu_ctx *)calloc(1, sizeof(pomgpu_ctx));
+  if (!c) return POMGPU_ENOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { free(c); return POMGPU_EHIP; }
+  KP &P = c->P;
+  P.im = d->im; P.jm = d->jm; P.kb = d->kb; P.imm1 = d->im - 1; P.jmm1 = d->jm - 1; P.kbm1 = d->kb - 1; P.kbm2 = d->kb - 2;
+  P.iml = d->im_local; P.jml = d->jm_local;
+  P.W = d->n_west == -1; P.E = d->n_east == -1; P.S = d->n_south == -1; P.N = d->n_north == -1;
+  P.n2 = (size_t)P.iml * P.jml; P.n3 = P.n2 * P.kb;
+  size_t off = 0; int s = 0;
+#define BD_(name, shape) P.bdoff[s++] = off; off += BDN_##shape;
+#define BDN_J ((size_t)P.jml)
+#define BDN_I ((size_t)P.iml)
+#define BDN_JK ((size_t)P.jml * P.kb)
+#define BDN_IK ((size_t)P.iml * P.kb)
+  POM_BDRY(BD_)
+#undef BD_
+  const size_t nbd = off;
+  c->con.error_status = 0;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return POMGPU_EHIP; }
+    c->own_stream = true;
+  }
+  c->prof_state = new ProfState();
+  PS(c)->filter[0] = 0;
+  bool ok = true;
+  auto alloc = [&](double **p, size_t n) {
+    if (!ok) return;
+    if (hipMalloc((void **)p, n * sizeof(double)) != hipSuccess) { ok = false; *p = NULL; return; }
+    if (hipMemsetAsync(*p, 0, n * sizeof(double), c->stream) != hipSuccess) ok = false;
+  };
+  alloc(&P.b1, (size_t)POM_NBLK1D * P.kb);
+  alloc(&P.b2, (size_t)POM_NBLK2D * P.n2);
+  alloc(&P.b3, (size_t)POM_NBLK3D * P.n3);
+  alloc(&P.bd, nbd);
+  for (int n = 0; n < POMGPU_NSCR3; n++) alloc(&P.s3[n], P.n3);
+  for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
+  alloc(&c->d_vel, 4);
+  if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
+  if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
+  if (!ok) {
+    fprintf(stderr, "pomgpu_create: device allocation failed (%zu MB per 3-D array)\n", P.n3 * 8 >> 20);
+    pomgpu_destroy(c);
+    return POMGPU_ENOMEM;
+  }
+  (void)hipStreamSynchronize(c->stream);
+  *out = c;
+  return POMGPU_OK;
+}
+
+extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  KP &P = c->P;
+  (void)hipFree(P.b1); (void)hipFree(P.b2); (void)hipFree(P.b3); (void)hipFree(P.bd);
+  for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
+  for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
+  for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
+  (void)hipFree(c->d_vel); (void)hipFree(c->d_err);
+  ProfState *ps = PS(c);
+  if (ps) {
+    for (auto &p : ps->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto &p : ps->free_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    delete ps;
+  }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  free(c);
+}
+
+extern "C" const char *pomgpu_last_error(const pomgpu_ctx *c) { return c ? c->err : "null context"; }
+extern "C" void *pomgpu_stream(pomgpu_ctx *c) { return c ? (void *)c->stream : NULL; }
+
+static int pull_err(pomgpu_ctx *c) {
+  int e = 0;
+  HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (e) c->con.error_status = 1;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_sync(pomgpu_ctx *c) {
+  if (!c) return POMGPU_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+
+// ---- state transfer ----------------------------------------------------------------------------
+extern "C" int pomgpu_set_con(pomgpu_ctx *c, const pom_blkcon *con, int lramp) {
+  if (!c || !con) return POMGPU_EINVAL;
+  c->con = *con;
+  c->lramp = lramp;
+  sync_scalars(c);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_get_con(pomgpu_ctx *c, pom_blkcon *con) {
+  if (!c || !con) return POMGPU_EINVAL;
+  int rc = pull_err(c);
+  if (rc) return rc;
+  *con = c->con;
+  return POMGPU_OK;
+}
+// masks must be exactly 0 or 1: the kernels fold repeated mask multiplies (k_bc.hip)
+static int check_masks(pomgpu_ctx *c, const double *blk2d) {
+  const int slots[3] = {P2_fsm, P2_dum, P2_dvm};
+  for (int s = 0; s < 3; s++) {
+    const double *m = blk2d + (size_t)slots[s] * c->P.n2;
+    for (size_t n = 0; n < c->P.n2; n++)
+      if (m[n] != 0. && m[n] != 1.) return fail(c, POMGPU_EINVAL, "mask array (blk2d slot %d) holds a value other than 0/1", slots[s]);
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, const double *b3, const double *bd,
+                             const pom_blkcon *con, int lramp) {
+  if (!c) return POMGPU_EINVAL;
+  KP &P = c->P;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
+  if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
+  if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
+  if (b3) HIPCHK(c, hipMemcpyAsync(P.b3, b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyHostToDevice, c->stream));
+  if (bd) {
+    const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
+    HIPCHK(c, hipMemcpyAsync(P.bd, bd, sizeof(double) * nbd, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (con) {
+    pomgpu_set_con(c, con, lramp);
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3, double *bd, pom_blkcon *con) {
+  if (!c) return POMGPU_EINVAL;
+  KP &P = c->P;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (b1) HIPCHK(c, hipMemcpyAsync(b1, P.b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyDeviceToHost, c->stream));
+  if (b2) HIPCHK(c, hipMemcpyAsync(b2, P.b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyDeviceToHost, c->stream));
+  if (b3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
+  if (bd) {
+    const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
+    HIPCHK(c, hipMemcpyAsync(bd, P.bd, sizeof(double) * nbd, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (con) return pomgpu_get_con(c, con);
+  return POMGPU_OK;
+}
+#define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL
+extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
+  SLOTCHK(c, s, POM_NBLK2D);
+  HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_upload_3d(pomgpu_ctx *c, int s, const double *h) {
+  SLOTCHK(c, s, POM_NBLK3D);
+  HIPCHK(c, hipMemcpyAsync(SLOT3(c, s), h, sizeof(double) * c->P.n3, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_download_2d(pomgpu_ctx *c, int s, double *h) {
+  SLOTCHK(c, s, POM_NBLK2D);
+  HIPCHK(c, hipMemcpyAsync(h, SLOT2(c, s), sizeof(double) * c->P.n2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_download_3d(pomgpu_ctx *c, int s, double *h) {
+  SLOTCHK(c, s, POM_NBLK3D);
+  HIPCHK(c, hipMemcpyAsync(h, SLOT3(c, s), sizeof(double) * c->P.n3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) { return (c && s >= 0 && s < POM_NBLK2D) ? SLOT2(c, s) : NULL; }
+extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) { return (c && s >= 0 && s < POM_NBLK3D) ? SLOT3(c, s) : NULL; }
+extern "C" int pomgpu_bind_host(pomgpu_ctx *c, const double *h2, const double *h3) {
+  if (!c) return POMGPU_EINVAL;
+  c->host2 = h2;
+  c->host3 = h3;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_set_restore_record(pomgpu_ctx *c, int n, const double *tr, const double *sr) {
+  if (!c || n < 1 || n > POMGPU_MAXREC || !tr || !sr) return POMGPU_EINVAL;
+  const size_t cnt = (size_t)c->P.im * c->P.jm * c->P.kb;
+  if (!c->rec_t[n]) {
+    HIPCHK(c, hipMalloc((void **)&c->rec_t[n], cnt * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->rec_s[n], cnt * sizeof(double)));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->rec_t[n], tr, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->rec_s[n], sr, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_set_exchange(pomgpu_ctx *c, pomgpu_exchange_fn fn, void *user) {
+  if (!c) return POMGPU_EINVAL;
+  c->exch = fn;
+  c->exch_user = user;
+  return POMGPU_OK;
+}
+
+// host address of a COMMON array -> device mirror (Fortran passes array actuals by reference)
+static double *dev3(pomgpu_ctx *c, const double *host) {
+  if (!c->host3 || !host) return NULL;
+  const ptrdiff_t off = host - c->host3;
+  if (off < 0 || (size_t)off >= (size_t)POM_NBLK3D * c->P.n3 || (size_t)off % c->P.n3) return NULL;
+  return c->P.b3 + off;
+}
+static double *dev2(pomgpu_ctx *c, const double *host) {
+  if (!c->host2 || !host) return NULL;
+  const ptrdiff_t off = host - c->host2;
+  if (off < 0 || (size_t)off >= (size_t)POM_NBLK2D * c->P.n2 || (size_t)off % c->P.n2) return NULL;
+  return c->P.b2 + off;
+}
+
+// ---- halo exchange points ---------------------------------------------------------------------
+static void xch(pomgpu_ctx *c, int count, ...) {
+  if (!c->exch) return;   // single tile: every neighbour is -1 (parallel_mpi.f:171)
+  double *ptr[8];
+  int nz[8];
+  va_list ap;
+  va_start(ap, count);
+  for (int n = 0; n < count; n++) { ptr[n] = va_arg(ap, double *); nz[n] = va_arg(ap, int); }
+  va_end(ap);
+  c->exch(c->exch_user, ptr, nz, count);
+}
+
+// ---- sequences (each mirrors one reference subroutine) ----------------------------------------
+static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
+  KP &P = c->P;
+  launch_advave_a(c);
+  xch(c, 2, P.s2[0], 1, P.s2[1], 1);                          // :60-61
+  launch_advave_b(c);
+  xch(c, 3, D2(c, advua), 1, D2(c, fluxua), 1, D2(c, fluxva), 1);   // :70, :111-112
+  launch_advave_c(c);
+  xch(c, 1, D2(c, advva), 1);                                 // :121
+  if (P.mode == 2) {
+    launch_advave_m2a(c);
+    xch(c, 1, P.s2[2], 1);                                    // :153
+    launch_advave_m2b(c);
+  }
+}
+static void seq_advct(pomgpu_ctx *c) {                        // solver.f:201-408
+  KP &P = c->P;
+  launch_advct_a(c);
+  xch(c, 2, P.s3[0], P.kbm1, P.s3[1], P.kbm1);                // :229, :279
+  launch_advct_b(c);
+  xch(c, 2, D3(c, advx), P.kb, P.s3[4], P.kbm1);              // :315, :369
+  launch_advct_c(c);
+  xch(c, 1, D3(c, advy), P.kb);                               // :405
+}
+static void seq_baropg(pomgpu_ctx *c) {                       // solver.f:848-940
+  launch_baropg(c);
+  launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :854 + :937
+}
+static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair, int zero_else) {   // solver.f:411-477
+  KP &P = c->P;
+  double *xf = P.s3[pair ? 2 : 0], *yf = P.s3[pair ? 3 : 1];
+  launch_advq_flux(c, q, qb, xf, yf);
+  xch(c, 2, xf, P.kbm1, yf, P.kbm1);                          // :458-459
+  launch_advq_step(c, q, qb, qf, xf, yf, zero_else);
+}
+static void seq_profq(pomgpu_ctx *c) {                        // solver.f:1212-1538
+  KP &P = c->P;
+  launch_profq_bc(c);
+  xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
+  launch_profq_prod(c);
+  xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
+  launch_profq(c);
+}
+static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
+  launch_copy_kb(c, fb);                                      // solver.f:496 / :618
+  launch_roundtrip(c, fb, fclim, 0);                          // :511+:532 / :691+:715
+}
+static void seq_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {   // solver.f:480-574
+  launch_advt1(c, fb, f, fclim, ff);
+  seq_fb_fix(c, fb, fclim);
+}
+static void seq_advt2(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {   // solver.f:577-731
+  KP &P = c->P;
+  if (P.nitera == 1) {
+    launch_advt2_fused(c, fb, f, fclim, ff);
+  } else {
+    launch_advt2_mass(c);
+    const double *fbmem = fb, *eta = D2(c, etb);
+    for (int itera = 1; itera <= P.nitera; itera++) {
+      launch_advt2_step(c, fbmem, f, eta, ff, itera);
+      xch(c, 1, ff, P.kbm1);                                  // :679
+      launch_mask3(c, ff, D2(c, fsm));                        // :1898-1900
+      launch_smol(c, ff);                                     // :1903-1964
+      eta = D2(c, etf);                                       // :684-685
+      launch_copy3(c, P.s3[3], ff);
+      fbmem = P.s3[3];
+    }
+    launch_advt2_diff(c, fb, fclim, ff);                      // :691-726
+  }
+  xch(c, 1, ff, P.kbm1);                                      // :728
+  seq_fb_fix(c, fb, fclim);
+}
+static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.f:1023-1121
+  KP &P = c->P;
+  const pom_blkcon &k = c->con;
+  const double trst = 30.;
+  const int irst = (int)(trst * 86400. / k.dti);
+  const int ntime = (int)(k.time / trst);
+  auto load = [&](int n) -> int {
+    if (n < 1 || n > POMGPU_MAXREC || !c->rec_t[n])
+      return fail(c, POMGPU_EINVAL, "restore_interior: record %d was not supplied (pomgpu_set_restore_record)", n);
+    launch_restore_load(c, c->rec_t[n], c->rec_s[n], 1. / trst);
+    return POMGPU_OK;
+  };
+  if (k.iint == 2) { int rc = load((k.iint / irst) + 1); if (rc) return rc; }
+  if (k.iint == 2 || (irst > 0 && k.iint % irst == 0)) {
+    launch_restore_shift(c);
+    if (k.iint != k.iend) { int rc = load((k.iint + irst) / irst + 1); if (rc) return rc; }
+  }
+  const double fnew = k.time / trst - ntime;
+  const double fold = 1. - fnew;
+  launch_restore(c, fold, fnew);
+  (void)P;
+  return POMGPU_OK;
+}
+
+#define NEED(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
+
+extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
+  NEED(c);
+  pom_blkcon &k = c->con;
+  k.time = k.dti * (double)(float)k.iint / 86400. + k.time0;
+  if (k.iint >= k.iswtch) k.iprint = (int)lround(k.prtd2 * 24. * 3600. / k.dti);
+  if (c->lramp) { k.ramp = k.time / k.period; if (k.ramp > 1.) k.ramp = 1.; }
+  else k.ramp = 1.;
+  sync_scalars(c);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {      // advance.f:96-141
+  NEED(c);
+  KP &P = c->P;
+  if (P.mode != 2) {
+    seq_advct(c);
+    if (P.npg == 1) seq_baropg(c);
+    else return fail(c, POMGPU_EINVAL, "Error: invalid value for npg (only npg=1 is built; baropg_mcc is a 'next' row)");
+    launch_aam(c);
+    xch(c, 1, D3(c, aam), P.kbm1);                            // :137
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) {       // advance.f:144-202
+  NEED(c);
+  if (c->P.mode != 2) {
+    launch_vint(c);
+    seq_advave(c);
+  }
+  launch_modeint_tail(c);
+  xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);                    // :198-199
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {          // advance.f:205-353
+  NEED(c);
+  KP &P = c->P;
+  P.iext = c->con.iext;
+  launch_ext_elf(c);                                          // :211-231
+  xch(c, 1, D2(c, elf), 1);                                   // :233
+  if (c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235
+  launch_ext_uvaf(c, 1);                                      // :237-290
+  xch(c, 2, D2(c, uaf), 1, D2(c, vaf), 1);                    // :292-293
+  launch_ext_update(c);                                       // :295-347
+  if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
+  NEED(c);
+  KP &P = c->P;
+  const pom_blkcon &k = c->con;
+  if ((k.iint != 1 || k.time0 != 0.) && k.mode != 2) {
+    launch_int_uvmean(c);                                     // :365-393
+    launch_vertvl(c, 1);                                      // :396-398
+    xch(c, 1, D3(c, w), P.kb);                                // :400
+    // :403-409 (uf = vf = 0 is folded into the advq step kernels)
+    {
+      double *x0 = P.s3[0], *y0 = P.s3[1], *x1 = P.s3[2], *y1 = P.s3[3];
+      launch_advq_flux(c, D3(c, q2), D3(c, q2b), x0, y0);
+      launch_advq_flux(c, D3(c, q2l), D3(c, q2lb), x1, y1);
+      xch(c, 4, x0, P.kbm1, y0, P.kbm1, x1, P.kbm1, y1, P.kbm1);
+      launch_advq_step(c, D3(c, q2), D3(c, q2b), D3(c, uf), x0, y0, 1);
+      launch_advq_step(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), x1, y1, 1);
+    }
+    seq_profq(c);
+    xch(c, 2, D3(c, uf) + P.n2, P.kbm2, D3(c, vf) + P.n2, P.kbm2);   // :411-412
+    launch_bcond6_edges(c);                                   // :414
+    launch_q_filter(c, 1);                                    // :416-421
+    if (k.mode != 4) {
+      if (k.nadv == 1) {
+        seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
+        seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
+      } else if (k.nadv == 2) {
+        seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
+        seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
+      } else {
+        return fail(c, POMGPU_EINVAL, "Error: invalid value for nadv");
+      }
+      xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);        // :436-437
+      launch_proft(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct);   // :439-440
+      launch_proft(c, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs);
+      launch_bcond4_edges(c);                                 // :442
+      launch_ts_filter(c, 1);                                 // :444-449
+      int rc = seq_restore_interior(c);                       // :452
+      if (rc) return rc;
+      launch_dens(c, D3(c, s), D3(c, t), D3(c, rho));         // :454
+    }
+    launch_advu_profu(c, 1, 1);                               // :459-462
+    launch_advv_profv(c, 1, 1);
+    xch(c, 2, D2(c, wubot), 1, D2(c, wvbot), 1);              // solver.f:1777, :1874
+    launch_bcondorl3(c);                                      // :464
+    xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);          // :466-467
+    launch_uv_filter(c);                                      // :469-514
+    xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
+  }
+  launch_int_tail(c);                                         // :525-531
+  launch_realvertvl(c);                                       // :534
+  xch(c, 1, D3(c, wr), P.kbm1);                               // solver.f:2055
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, int *jmax) {   // advance.f:611-641
+  NEED(c);
+  launch_check_velocity(c);
+  double out[3];
+  HIPCHK(c, hipMemcpyAsync(out, c->d_vel, sizeof out, hipMemcpyDeviceToHost, c->stream));
+  int rc = pull_err(c);
+  if (rc) return rc;
+  if (vamax) *vamax = out[0];
+  if (imax) *imax = (int)out[1];
+  if (jmax) *jmax = (int)out[2];
+  if (out[0] > c->con.vmaxl) {
+    fprintf(stderr, "Error: velocity condition violated\n iint =%8d vamax =%12.3e   imax,jmax =%5d%5d\n", c->con.iint, out[0],
+            (int)out[1], (int)out[2]);
+    c->con.error_status = 1;
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
+  NEED(c);
+  int rc;
+  if ((rc = pomgpu_get_time(c))) return rc;
+  if ((rc = pomgpu_lateral_viscosity(c))) return rc;
+  if ((rc = pomgpu_mode_interaction(c))) return rc;
+  for (int iext = 1; iext <= c->con.isplit; iext++) {
+    c->con.iext = iext;
+    if ((rc = pomgpu_mode_external(c))) return rc;
+  }
+  c->con.iext = c->con.isplit + 1;
+  if ((rc = pomgpu_mode_internal(c))) return rc;
+  launch_check_velocity(c);   // result stays on the device; error flag is merged at the next get_con
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
+  NEED(c);
+  for (int n = 0; n < nsteps; n++) {
+    c->con.iint += 1;
+    int rc = pomgpu_advance(c);
+    if (rc) return rc;
+  }
+  return POMGPU_OK;
+}
+
+// ---- stand-alone kernels (device-resident), reference names ------------------------------------
+extern "C" int pomgpu_advave(pomgpu_ctx *c) { NEED(c); seq_advave(c); return POMGPU_OK; }
+extern "C" int pomgpu_advct(pomgpu_ctx *c) { NEED(c); seq_advct(c); return POMGPU_OK; }
+extern "C" int pomgpu_baropg(pomgpu_ctx *c) { NEED(c); seq_baropg(c); return POMGPU_OK; }
+extern "C" int pomgpu_advq(pomgpu_ctx *c, const double *qb, const double *q, const double *qf) {
+  NEED(c);
+  double *a = dev3(c, qb), *b = dev3(c, q), *d = dev3(c, qf);
+  if (!a || !b || !d) return fail(c, POMGPU_EINVAL, "advq: arguments must be blk3d arrays of the bound host block");
+  seq_advq(c, a, b, d, 0, 0);
+  return POMGPU_OK;
+}
+static int advt_args(pomgpu_ctx *c, const double *fb, const double *f, const double *fclim, const double *ff, double **o) {
+  o[0] = dev3(c, fb); o[1] = dev3(c, f); o[2] = dev3(c, fclim); o[3] = dev3(c, ff);
+  if (!o[0] || !o[1] || !o[2] || !o[3]) return fail(c, POMGPU_EINVAL, "advt: arguments must be blk3d arrays of the bound host block");
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_advt1(pomgpu_ctx *c, const double *fb, const double *f, const double *fclim, const double *ff) {
+  NEED(c);
+  double *o[4];
+  int rc = advt_args(c, fb, f, fclim, ff, o);
+  if (rc) return rc;
+  seq_advt1(c, o[0], o[1], o[2], o[3]);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_advt2(pomgpu_ctx *c, const double *fb, const double *f, const double *fclim, const double *ff) {
+  NEED(c);
+  double *o[4];
+  int rc = advt_args(c, fb, f, fclim, ff, o);
+  if (rc) return rc;
+  seq_advt2(c, o[0], o[1], o[2], o[3]);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_advu(pomgpu_ctx *c) { NEED(c); launch_advu_profu(c, 1, 0); return POMGPU_OK; }
+extern "C" int pomgpu_advv(pomgpu_ctx *c) { NEED(c); launch_advv_profv(c, 1, 0); return POMGPU_OK; }
+extern "C" int pomgpu_profu(pomgpu_ctx *c) {
+  NEED(c);
+  launch_advu_profu(c, 0, 1);
+  xch(c, 1, D2(c, wubot), 1);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_profv(pomgpu_ctx *c) {
+  NEED(c);
+  launch_advv_profv(c, 0, 1);
+  xch(c, 1, D2(c, wvbot), 1);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_dens(pomgpu_ctx *c, const double *si, const double *ti, const double *rhoo) {
+  NEED(c);
+  double *a = dev3(c, si), *b = dev3(c, ti), *d = dev3(c, rhoo);
+  if (!a || !b || !d) return fail(c, POMGPU_EINVAL, "dens: arguments must be blk3d arrays of the bound host block");
+  launch_dens(c, a, b, d);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_profq(pomgpu_ctx *c) { NEED(c); seq_profq(c); return POMGPU_OK; }
+extern "C" int pomgpu_proft(pomgpu_ctx *c, const double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  NEED(c);
+  double *a = dev3(c, f), *b = dev2(c, wfsurf), *d = dev2(c, fsurf);
+  if (!a || !b || !d) return fail(c, POMGPU_EINVAL, "proft: arguments must be arrays of the bound host blocks");
+  if (nbc < 1 || nbc > 4) return fail(c, POMGPU_EINVAL, "proft: nbc must be 1..4");
+  launch_proft(c, a, b, d, nbc);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_vertvl(pomgpu_ctx *c) { NEED(c); launch_vertvl(c, 0); return POMGPU_OK; }
+extern "C" int pomgpu_realvertvl(pomgpu_ctx *c) {
+  NEED(c);
+  launch_realvertvl(c);
+  xch(c, 1, D3(c, wr), c->P.kbm1);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_bcond(pomgpu_ctx *c, int idx) {
+  NEED(c);
+  switch (idx) {
+    case 1: launch_bcond1(c); break;
+    case 2: launch_ext_uvaf(c, 0); break;
+    case 4: launch_bcond4_edges(c); launch_mask_ts(c); break;
+    case 5: launch_mask_w(c); break;
+    case 6: launch_bcond6_edges(c); launch_mask_q(c); break;
+    default: return fail(c, POMGPU_EINVAL, "bcond(%d) is not on the hot path", idx);
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_bcondorl(pomgpu_ctx *c, int idx) {
+  NEED(c);
+  switch (idx) {
+    case 3: launch_bcondorl3(c); launch_mask_uv(c); break;
+    case 5: launch_mask_w(c); break;
+    default: return fail(c, POMGPU_EINVAL, "bcondorl(%d) is not on the hot path", idx);
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_restore_interior(pomgpu_ctx *c) { NEED(c); return seq_restore_interior(c); }

@@ -1,0 +1,162 @@
+// pomgpu_internal.hpp -- shared by the HIP kernel files and the C-ABI implementation.
+//
+// Data layout in HBM: the device mirrors ARE the reference's COMMON blocks (pom.h_dist:46-640):
+// one allocation per block, arrays at slot*n2 / slot*n3, column-major with i contiguous and the
+// reference's leading dimensions (im_local, jm_local).  Kernels map threadIdx.x -> i, so every
+// global access of a wavefront is a contiguous 512-byte row segment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "pom_layout.h"
+
+#define POMGPU_NSCR3 8     // 3-D scratch arrays (the reference's automatic arrays that survive fusion)
+#define POMGPU_NSCR2 8     // 2-D scratch arrays
+#define POMGPU_MAXREC 8
+#define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
+
+// Kernel parameters, passed by value with every launch.
+struct KP {
+  int im, jm, kb, imm1, jmm1, kbm1, kbm2, iml, jml;
+  int W, E, S, N;            // 1 where the tile edge is a physical boundary (n_west == -1 ...)
+  size_t n2, n3;
+  double *b1, *b2, *b3, *bd; // device mirrors of blk1d, blk2d, blk3d, bdry
+  double *s3[POMGPU_NSCR3];
+  double *s2[POMGPU_NSCR2];
+  size_t bdoff[80];          // offset of every bdry member inside bd
+  // blkcon scalars used on the hot path
+  double alpha, dte, dti, dti2, dte2, grav, kappa, ramp, rfe, rfn, rfs, rfw, rhoref, sbias, small_,
+         tbias, tprni, umol, horcon, ispi, isp2i, smoth, sw, time, vmaxl;
+  int mode, ntp, nadv, nbct, nbcs, nitera, npg, isplit, iext, iint, iend;
+  // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
+  double const1_profq, cb_profq;
+};
+
+// ---- Fortran-style accessors (1-based), `P` is the KP in scope ------------------------------
+#define IX2(i, j) ((size_t)((j)-1) * (size_t)P.iml + (size_t)((i)-1))
+#define IX3(i, j, k) ((size_t)((k)-1) * P.n2 + IX2(i, j))
+#define F1(name, k) P.b1[(size_t)P1_##name * P.kb + ((k)-1)]
+#define F2(name, i, j) P.b2[(size_t)P2_##name * P.n2 + IX2(i, j)]
+#define F3(name, i, j, k) P.b3[(size_t)P3_##name * P.n3 + IX3(i, j, k)]
+#define A2(name) (P.b2 + (size_t)P2_##name * P.n2)
+#define A3(name) (P.b3 + (size_t)P3_##name * P.n3)
+#define G3(p, i, j, k) (p)[IX3(i, j, k)]
+#define G2(p, i, j) (p)[IX2(i, j)]
+
+enum pom_bdry_slot_dev {
+#define POMGPU_BD_(name, shape) PB_##name,
+  POM_BDRY(POMGPU_BD_)
+#undef POMGPU_BD_
+  PB__count
+};
+#define BD1(name, a) P.bd[P.bdoff[PB_##name] + (size_t)((a)-1)]
+#define BDJ(name, a, k) P.bd[P.bdoff[PB_##name] + (size_t)((k)-1) * P.jml + (size_t)((a)-1)]
+#define BDI(name, a, k) P.bd[P.bdoff[PB_##name] + (size_t)((k)-1) * P.iml + (size_t)((a)-1)]
+
+__device__ __forceinline__ double sq(double x) { return x * x; }
+
+// thread -> (i,j[,k]) maps (1-based); blockDim.x runs along i
+#define TID_I (int)(blockIdx.x * blockDim.x + threadIdx.x + 1)
+#define TID_J (int)(blockIdx.y * blockDim.y + threadIdx.y + 1)
+#define TID_K (int)(blockIdx.z * blockDim.z + threadIdx.z + 1)
+
+// ---- host side ---------------------------------------------------------------------------------
+struct ProfEntry { const char *name; long launches; double ms; };
+
+struct pomgpu_ctx {
+  KP P;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  pom_blkcon con;            // host copy of blkcon (iint, iext, error_status live here)
+  int lramp;
+  double *rec_t[POMGPU_MAXREC + 1], *rec_s[POMGPU_MAXREC + 1];
+  const double *host2, *host3;   // host bases registered by pomgpu_bind_host
+  void (*exch)(void *, double *const *, const int *, int);
+  void *exch_user;
+  double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
+  int *d_err;                // device error flag
+  // profiling
+  bool prof_on;
+  ProfEntry prof[96];
+  int nprof;
+  void *prof_state;
+  char err[512];
+};
+
+// launch helpers -----------------------------------------------------------------------------
+int pomgpu_prof_slot(pomgpu_ctx *c, const char *name);
+void pomgpu_prof_pre(pomgpu_ctx *c);
+void pomgpu_prof_post(pomgpu_ctx *c, int slot);
+
+#define LAUNCH(c, kern, grid, block, ...)                                        \
+  do {                                                                           \
+    int _s = (c)->prof_on ? pomgpu_prof_slot((c), #kern) : -1;                   \
+    if (_s >= 0) pomgpu_prof_pre(c);                                             \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
+  } while (0)
+
+static inline dim3 blk2() { return dim3(64, 4, 1); }
+static inline dim3 grid2(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 3) / 4, 1); }
+static inline dim3 grid3(const KP &P, int nz) { return dim3((P.iml + 63) / 64, (P.jml + 3) / 4, nz); }
+
+// kernel launchers implemented in the k_*.hip files (one per fused phase of the step)
+// k_ext.hip
+void launch_advave_a(pomgpu_ctx *c);
+void launch_advave_b(pomgpu_ctx *c);
+void launch_advave_c(pomgpu_ctx *c);
+void launch_advave_m2a(pomgpu_ctx *c);
+void launch_advave_m2b(pomgpu_ctx *c);
+void launch_vint(pomgpu_ctx *c);
+void launch_modeint_tail(pomgpu_ctx *c);
+void launch_ext_elf(pomgpu_ctx *c);
+void launch_ext_uvaf(pomgpu_ctx *c, int interior);
+void launch_ext_update(pomgpu_ctx *c);
+void launch_int_tail(pomgpu_ctx *c);
+void launch_bcond1(pomgpu_ctx *c);
+// k_adv.hip
+void launch_advct_a(pomgpu_ctx *c);
+void launch_advct_b(pomgpu_ctx *c);
+void launch_advct_c(pomgpu_ctx *c);
+void launch_aam(pomgpu_ctx *c);
+void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb);
+void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf);
+void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *xf, const double *yf, int zero_else);
+void launch_q_filter(pomgpu_ctx *c, int mask);
+void launch_mask_q(pomgpu_ctx *c);
+void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff);
+void launch_copy_kb(pomgpu_ctx *c, double *f);
+void launch_advt2_mass(pomgpu_ctx *c);
+void launch_advt2_step(pomgpu_ctx *c, const double *fbmem, const double *f, const double *eta, double *ff, int itera);
+void launch_mask3(pomgpu_ctx *c, double *a, const double *m2);
+void launch_smol(pomgpu_ctx *c, const double *ff);
+void launch_copy3(pomgpu_ctx *c, double *dst, const double *src);
+void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff);
+void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
+void launch_ts_filter(pomgpu_ctx *c, int mask);
+void launch_mask_ts(pomgpu_ctx *c);
+void launch_mask_uv(pomgpu_ctx *c);
+void launch_mask_w(pomgpu_ctx *c);
+void launch_restore(pomgpu_ctx *c, double fold, double fnew);
+void launch_restore_shift(pomgpu_ctx *c);
+void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau);
+void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo);
+void launch_realvertvl(pomgpu_ctx *c);
+void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v);
+// k_vert.hip
+void launch_baropg(pomgpu_ctx *c);
+void launch_int_uvmean(pomgpu_ctx *c);
+void launch_vertvl(pomgpu_ctx *c, int mask);
+void launch_profq_bc(pomgpu_ctx *c);
+void launch_profq_prod(pomgpu_ctx *c);
+void launch_profq(pomgpu_ctx *c);
+void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
+void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
+void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
+void launch_uv_filter(pomgpu_ctx *c);
+// k_bc.hip
+void launch_bcond4_edges(pomgpu_ctx *c);
+void launch_bcond6_edges(pomgpu_ctx *c);
+void launch_bcondorl3(pomgpu_ctx *c);
+// k_reduce.hip
+void launch_check_velocity(pomgpu_ctx *c);

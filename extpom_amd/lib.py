@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI (include/pomgpu.h) -- loads extpom_amd/csrc/libpomgpu.so.
+
+There is NO CPU fallback: if the shared library is missing or no HIP device can be opened the
+import / context creation fails loudly (PomGpuError).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "csrc", "libpomgpu.so")
+
+
+class PomGpuError(RuntimeError):
+    pass
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("im", "jm", "kb", "im_local", "jm_local", "n_west", "n_east", "n_south", "n_north")]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                               ctypes.c_int)
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_SIGS = {
+    "pomgpu_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(Dims), _I, _P]),
+    "pomgpu_destroy": (None, [_P]),
+    "pomgpu_last_error": (ctypes.c_char_p, [_P]),
+    "pomgpu_sync": (_I, [_P]),
+    "pomgpu_stream": (_P, [_P]),
+    "pomgpu_upload": (_I, [_P, _P, _P, _P, _P, _P, _I]),
+    "pomgpu_download": (_I, [_P, _P, _P, _P, _P, _P]),
+    "pomgpu_upload_2d": (_I, [_P, _I, _P]),
+    "pomgpu_upload_3d": (_I, [_P, _I, _P]),
+    "pomgpu_download_2d": (_I, [_P, _I, _P]),
+    "pomgpu_download_3d": (_I, [_P, _I, _P]),
+    "pomgpu_set_con": (_I, [_P, _P, _I]),
+    "pomgpu_get_con": (_I, [_P, _P]),
+    "pomgpu_bind_host": (_I, [_P, _P, _P]),
+    "pomgpu_set_restore_record": (_I, [_P, _I, _P, _P]),
+    "pomgpu_device_2d": (_P, [_P, _I]),
+    "pomgpu_device_3d": (_P, [_P, _I]),
+    "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
+    "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pomgpu_run": (_I, [_P, _I]),
+    "pomgpu_advq": (_I, [_P, _P, _P, _P]),
+    "pomgpu_advt1": (_I, [_P, _P, _P, _P, _P]),
+    "pomgpu_advt2": (_I, [_P, _P, _P, _P, _P]),
+    "pomgpu_dens": (_I, [_P, _P, _P, _P]),
+    "pomgpu_proft": (_I, [_P, _P, _P, _P, _I]),
+    "pomgpu_bcond": (_I, [_P, _I]),
+    "pomgpu_bcondorl": (_I, [_P, _I]),
+    "pomgpu_prof_begin": (_I, [_P]),
+    "pomgpu_prof_filter": (_I, [_P, ctypes.c_char_p]),
+    "pomgpu_prof_end": (_I, [_P]),
+    "pomgpu_prof_count": (_I, [_P]),
+    "pomgpu_prof_get": (_I, [_P, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_long),
+                             ctypes.POINTER(ctypes.c_double)]),
+    "pomgpu_version": (ctypes.c_char_p, []),
+}
+# argument-less hot-path entry points, same names as the reference subroutines
+NOARG = ["get_time", "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "advance", "advave",
+         "advct", "advu", "advv", "baropg", "profq", "profu", "profv", "vertvl", "realvertvl", "restore_interior"]
+for _n in NOARG:
+    _SIGS["pomgpu_" + _n] = (_I, [_P])
+
+EXPORTS = sorted(_SIGS)
+
+_cache = {}
+
+
+def load(path: str | None = None):
+    path = path or LIBPATH
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise PomGpuError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the hot path)")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)       # AttributeError = the library does not export the C ABI
+        fn.restype = res
+        fn.argtypes = args
+    _cache[path] = lib
+    return lib

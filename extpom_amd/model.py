@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's program flow for the hot path, over the C ABI.
+
+``PomGpu`` owns one tile's device context.  Method names are the reference's subroutine names
+(advance, lateral_viscosity, mode_interaction, mode_external, mode_internal, check_velocity, advct,
+advq, ... : reference pom/advance.f, pom/solver.f); array arguments are given by field NAME and
+resolved to the host address of that COMMON array -- what a Fortran caller passes by reference.
+State crosses the boundary only through ``upload`` / ``download`` (whole COMMON blocks).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+from .layout import P2, P3, PomState
+from .lib import Dims, PomGpuError
+
+
+class PomGpu:
+    def __init__(self, st: PomState, device: int = 0, stream: int | None = None, libpath: str | None = None):
+        self.L = _lib.load(libpath)
+        self.st = st
+        d = Dims(st.im, st.jm, st.kb, st.im_local, st.jm_local, st.n_west, st.n_east, st.n_south, st.n_north)
+        h = ctypes.c_void_p()
+        rc = self.L.pomgpu_create(ctypes.byref(h), ctypes.byref(d), device, ctypes.c_void_p(stream or 0))
+        if rc != 0:
+            raise PomGpuError(f"pomgpu_create failed with status {rc} (no CPU fallback exists for the hot path)")
+        self.h = h
+        self._exch_cb = None
+        self.upload()
+
+    # ---- plumbing ------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PomGpuError(f"{what}: status {rc}: {self.L.pomgpu_last_error(self.h).decode()}")
+
+    @staticmethod
+    def _p(a):
+        return ctypes.c_void_p(a.ctypes.data)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pomgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, st: PomState | None = None):
+        st = st or self.st
+        self.st = st
+        self._chk(self.L.pomgpu_upload(self.h, self._p(st.blk1d), self._p(st.blk2d), self._p(st.blk3d), self._p(st.bdry),
+                                       self._p(st.con), 1 if getattr(st, "lramp", False) else 0), "upload")
+        self._chk(self.L.pomgpu_bind_host(self.h, self._p(st.blk2d), self._p(st.blk3d)), "bind_host")
+        for n, (tr, sr) in enumerate(getattr(st, "restore_records", []), start=1):
+            tr = np.ascontiguousarray(tr, dtype=np.float64)
+            sr = np.ascontiguousarray(sr, dtype=np.float64)
+            self._chk(self.L.pomgpu_set_restore_record(self.h, n, self._p(tr), self._p(sr)), "set_restore_record")
+
+    def download(self, st: PomState | None = None) -> PomState:
+        st = st or self.st
+        self._chk(self.L.pomgpu_download(self.h, self._p(st.blk1d), self._p(st.blk2d), self._p(st.blk3d), self._p(st.bdry),
+                                         self._p(st.con)), "download")
+        return st
+
+    def set_con(self, **kw):
+        """update blkcon scalars (iint, iext, ...) on the library side"""
+        for k, v in kw.items():
+            self.st.con[k][0] = v
+        self._chk(self.L.pomgpu_set_con(self.h, self._p(self.st.con), 1 if getattr(self.st, "lramp", False) else 0),
+                  "set_con")
+
+    def get_con(self):
+        self._chk(self.L.pomgpu_get_con(self.h, self._p(self.st.con)), "get_con")
+        return self.st.con
+
+    def sync(self):
+        self._chk(self.L.pomgpu_sync(self.h), "sync")
+
+    def device_ptr(self, name: str) -> int:
+        if name in P3:
+            return self.L.pomgpu_device_3d(self.h, P3[name])
+        return self.L.pomgpu_device_2d(self.h, P2[name])
+
+    def set_exchange(self, fn):
+        """fn(list_of_device_addresses, list_of_levels) -- see extpom_amd.halo"""
+        def cb(user, ptrs, nz, count):
+            fn([ptrs[n] for n in range(count)], [nz[n] for n in range(count)])
+        self._exch_cb = _lib.EXCHANGE_FN(cb)
+        self._chk(self.L.pomgpu_set_exchange(self.h, self._exch_cb, None), "set_exchange")
+
+    # ---- hot path, reference names -------------------------------------------------------
+    def _a(self, name):
+        return self._p(self.st.field(name))
+
+    def call(self, name, *fields_or_ints):
+        fn = getattr(self.L, "pomgpu_" + name)
+        args = [self._a(a) if isinstance(a, str) else a for a in fields_or_ints]
+        self._chk(fn(self.h, *args), name)
+
+    def advance(self):
+        self.call("advance")
+
+    def run(self, nsteps: int):
+        self._chk(self.L.pomgpu_run(self.h, int(nsteps)), "run")
+
+    def check_velocity(self):
+        v = ctypes.c_double()
+        i = ctypes.c_int()
+        j = ctypes.c_int()
+        self._chk(self.L.pomgpu_check_velocity(self.h, ctypes.byref(v), ctypes.byref(i), ctypes.byref(j)), "check_velocity")
+        return v.value, i.value, j.value
+
+    # ---- measurement ---------------------------------------------------------------------
+    def prof_begin(self, only: str | None = None):
+        self._chk(self.L.pomgpu_prof_filter(self.h, (only or "").encode()), "prof_filter")
+        self._chk(self.L.pomgpu_prof_begin(self.h), "prof_begin")
+
+    def prof_end(self) -> dict:
+        self._chk(self.L.pomgpu_prof_end(self.h), "prof_end")
+        out = {}
+        for k in range(self.L.pomgpu_prof_count(self.h)):
+            name = ctypes.c_char_p()
+            n = ctypes.c_long()
+            ms = ctypes.c_double()
+            self.L.pomgpu_prof_get(self.h, k, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+
+def gpu_finish_initial(st: PomState, **kw) -> PomState:
+    """finish_initial() with the HIP dens / baropg (what the reference's initialize does with its own)."""
+    from .cases import finish_initial
+    g = PomGpu(st, **kw)
+
+    def dens(s, si, ti, rho):
+        g.upload(s)
+        g.call("dens", si, ti, rho)
+        g.download(s)
+
+    def baropg(s):
+        g.upload(s)
+        g.call("baropg")
+        g.download(s)
+
+    finish_initial(st, dens, baropg)
+    g.close()
+    return st

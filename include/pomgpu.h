@@ -1,0 +1,143 @@
+/* include/pomgpu.h -- C ABI of the MI355X hot path of extPOM's mode-split time step.
+ *
+ * The reference has no plugin registry: its boundary is the Fortran external-procedure ABI plus
+ * COMMON blocks (reference pom/pom.f:17-19 calls `advance`; every hot routine is an argument-less
+ * subroutine working on the blocks of pom.h_dist:46-640).  This library keeps that shape:
+ *
+ *   - state crosses the boundary as whole COMMON blocks in the reference's own layout
+ *     (include/pom_layout.h), handed over by address and mirrored in HBM;
+ *   - every hot-path routine of the reference has an entry point of the same name
+ *     (pomgpu_<name>) and the same argument meaning; routines whose Fortran actual arguments are
+ *     COMMON arrays (advq, advt1, advt2, dens, proft: advance.f:407-408,426-430,439-440,454) take
+ *     the HOST address of that array -- exactly what the Fortran caller passes by reference -- and
+ *     the library translates it to the device mirror;
+ *   - errors follow the reference's convention: a routine sets error_status=1 in blkcon and
+ *     reports on stderr (advance.f:118-119,631-637); in addition every entry point returns 0 on
+ *     success and a negative pomgpu_status otherwise (HIP failures map to POMGPU_EHIP and also
+ *     set error_status=1).
+ *
+ * All entry points are plain C: pointers, ints and doubles only.  One context = one tile = one GPU.
+ * The library never frees or reallocates host arrays; it owns only its device mirrors and stream.
+ */
+#ifndef POMGPU_H
+#define POMGPU_H
+#include <stddef.h>
+#include "pom_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pomgpu_ctx pomgpu_ctx;
+
+enum pomgpu_status {
+  POMGPU_OK = 0,
+  POMGPU_EINVAL = -1,   /* bad argument / unsupported option (message in pomgpu_last_error) */
+  POMGPU_EHIP = -2,     /* a HIP runtime call failed */
+  POMGPU_ENOMEM = -3,
+  POMGPU_ENODEV = -4    /* no usable GPU: the hot path has no CPU fallback */
+};
+
+/* Tile description: blksiz + blkpar of the reference (pom.h_dist:46-54,58-78). */
+typedef struct pomgpu_dims {
+  int im, jm, kb;                         /* active extents */
+  int im_local, jm_local;                 /* leading dimensions of every array */
+  int n_west, n_east, n_south, n_north;   /* neighbour ranks, -1 = physical edge (parallel_mpi.f:111-119) */
+} pomgpu_dims;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (or NULL for the library's own stream) passed as void* so that this
+ * header needs no HIP include. */
+int  pomgpu_create(pomgpu_ctx **ctx, const pomgpu_dims *dims, int device, void *stream);
+void pomgpu_destroy(pomgpu_ctx *ctx);
+const char *pomgpu_last_error(const pomgpu_ctx *ctx);
+int  pomgpu_sync(pomgpu_ctx *ctx);
+void *pomgpu_stream(pomgpu_ctx *ctx);
+
+/* ---- state transfer (pomgpu_upload_state / pomgpu_download_state of SURVEY 8b) ---------- */
+/* Whole blocks; any pointer may be NULL to skip that block.  `bdry` is the bdry block
+ * (pom.h_dist:532-608).  `lramp` is blklog. */
+int pomgpu_upload(pomgpu_ctx *ctx, const double *blk1d, const double *blk2d, const double *blk3d,
+                  const double *bdry, const pom_blkcon *con, int lramp);
+int pomgpu_download(pomgpu_ctx *ctx, double *blk1d, double *blk2d, double *blk3d, double *bdry,
+                    pom_blkcon *con);
+/* Single arrays, addressed by their slot in the block (enum pom_slot2d / pom_slot3d). */
+int pomgpu_upload_2d(pomgpu_ctx *ctx, int slot2d, const double *host);
+int pomgpu_upload_3d(pomgpu_ctx *ctx, int slot3d, const double *host);
+int pomgpu_download_2d(pomgpu_ctx *ctx, int slot2d, double *host);
+int pomgpu_download_3d(pomgpu_ctx *ctx, int slot3d, double *host);
+/* blkcon only (iint, time, ramp ... change every step on the host side of the reference). */
+int pomgpu_set_con(pomgpu_ctx *ctx, const pom_blkcon *con, int lramp);
+int pomgpu_get_con(pomgpu_ctx *ctx, pom_blkcon *con);
+/* Register the host base addresses of blk2d/blk3d so that array arguments given as host
+ * addresses (Fortran by-reference actuals) can be translated to device mirrors. */
+int pomgpu_bind_host(pomgpu_ctx *ctx, const double *host_blk2d, const double *host_blk3d);
+/* Relaxation targets that the reference's restore_interior reads through
+ * read_restore_ts_interior_pnetcdf(n,kb,tr,sr) (bounds_forcing.f:1040,1060): record n (1-based),
+ * arrays dimensioned (im,jm,kb).  Copied to the device. */
+int pomgpu_set_restore_record(pomgpu_ctx *ctx, int n, const double *tr, const double *sr);
+/* Device address of a mirror (for halo exchange by the caller, e.g. RCCL send/recv). */
+double *pomgpu_device_2d(pomgpu_ctx *ctx, int slot2d);
+double *pomgpu_device_3d(pomgpu_ctx *ctx, int slot3d);
+
+/* ---- halo exchange hook (replaces exchange2d_mpi / exchange3d_mpi, parallel_mpi.f:154-351) */
+/* Called on the library's stream order: `dev` is the DEVICE address of the first level to
+ * exchange, leading dimensions (im_local, jm_local), `nz` levels (1 for 2-D).  `count` arrays are
+ * exchanged at one program point (the caller may batch them into one message per neighbour).
+ * NULL hook = single tile (all neighbours -1: every exchange is a no-op, parallel_mpi.f:171). */
+typedef void (*pomgpu_exchange_fn)(void *user, double *const *dev, const int *nz, int count);
+int pomgpu_set_exchange(pomgpu_ctx *ctx, pomgpu_exchange_fn fn, void *user);
+
+/* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
+int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
+int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */
+int pomgpu_mode_interaction(pomgpu_ctx *ctx);    /* advance.f:144-202 */
+int pomgpu_mode_external(pomgpu_ctx *ctx);       /* advance.f:205-353; uses blkcon.iext */
+int pomgpu_mode_internal(pomgpu_ctx *ctx);       /* advance.f:356-537 */
+/* advance.f:611-641; any of the out pointers may be NULL.  Synchronises the stream. */
+int pomgpu_check_velocity(pomgpu_ctx *ctx, double *vamax, int *imax, int *jmax);
+/* One internal step for the current blkcon.iint: get_time, lateral_viscosity, mode_interaction,
+ * isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus file forcing,
+ * print and output, which stay on the host).  Does not synchronise. */
+int pomgpu_advance(pomgpu_ctx *ctx);
+/* nsteps x { iint = iint+1; advance }  (pom.f:17-19).  Does not synchronise. */
+int pomgpu_run(pomgpu_ctx *ctx, int nsteps);
+
+/* ---- the hot path: kernels (solver.f, bounds_forcing.f), device-resident ---------------- */
+int pomgpu_advave(pomgpu_ctx *ctx);              /* solver.f:6-198   */
+int pomgpu_advct(pomgpu_ctx *ctx);               /* solver.f:201-408 */
+int pomgpu_advq(pomgpu_ctx *ctx, const double *qb, const double *q, const double *qf);   /* :411-477 */
+int pomgpu_advt1(pomgpu_ctx *ctx, const double *fb, const double *f, const double *fclim, const double *ff); /* :480-574 */
+int pomgpu_advt2(pomgpu_ctx *ctx, const double *fb, const double *f, const double *fclim, const double *ff); /* :577-731 */
+int pomgpu_advu(pomgpu_ctx *ctx);                /* solver.f:734-788 */
+int pomgpu_advv(pomgpu_ctx *ctx);                /* solver.f:791-845 */
+int pomgpu_baropg(pomgpu_ctx *ctx);              /* solver.f:848-940 */
+int pomgpu_dens(pomgpu_ctx *ctx, const double *si, const double *ti, const double *rhoo); /* :1162-1209 */
+int pomgpu_profq(pomgpu_ctx *ctx);               /* solver.f:1212-1538 */
+int pomgpu_proft(pomgpu_ctx *ctx, const double *f, const double *wfsurf, const double *fsurf, int nbc); /* :1541-1683 */
+int pomgpu_profu(pomgpu_ctx *ctx);               /* solver.f:1686-1780 */
+int pomgpu_profv(pomgpu_ctx *ctx);               /* solver.f:1783-1877 */
+int pomgpu_vertvl(pomgpu_ctx *ctx);              /* solver.f:1970-2021 */
+int pomgpu_realvertvl(pomgpu_ctx *ctx);          /* solver.f:2024-2067 */
+int pomgpu_bcond(pomgpu_ctx *ctx, int idx);      /* bounds_forcing.f:6-328   (idx 1,2,4,5,6) */
+int pomgpu_bcondorl(pomgpu_ctx *ctx, int idx);   /* bounds_forcing.f:331-590 (idx 3,5) */
+int pomgpu_restore_interior(pomgpu_ctx *ctx);    /* bounds_forcing.f:1023-1121 */
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* Per-kernel device time measured with HIP events on the library's stream.  Between
+ * pomgpu_prof_begin and pomgpu_prof_end every launch is bracketed by events; pomgpu_prof_get
+ * returns, for kernel number `k` (0 <= k < pomgpu_prof_count()), its name, launch count and
+ * total milliseconds. */
+int pomgpu_prof_begin(pomgpu_ctx *ctx);
+/* restrict the bracketing to one kernel (its name, e.g. "k_profq"); NULL or "" = every kernel */
+int pomgpu_prof_filter(pomgpu_ctx *ctx, const char *kernel_name);
+int pomgpu_prof_end(pomgpu_ctx *ctx);
+int pomgpu_prof_count(pomgpu_ctx *ctx);
+int pomgpu_prof_get(pomgpu_ctx *ctx, int k, const char **name, long *launches, double *total_ms);
+
+const char *pomgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POMGPU_H */

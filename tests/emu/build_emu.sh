@@ -1,0 +1,14 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: host build of the unmodified kernel sources (see tests/emu/hip/hip_runtime.h)
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
+OUT=$ROOT/tests/_emu; mkdir -p "$OUT"
+SRC=$ROOT/extpom_amd/csrc
+FLAGS="-x c++ -std=c++17 -O2 -ffp-contract=off -fno-fast-math -fPIC -w -I$HERE -I$ROOT/include -I$SRC"
+for f in k_ext k_adv k_vert k_bc pomgpu_api; do
+  g++ $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &
+done
+g++ $FLAGS -c "$HERE/emu_support.cpp" -o "$OUT/emu_support.o" &
+wait
+g++ -shared -o "$OUT/libpomgpu_emu.so" "$OUT"/*.o -lm
+echo "built $OUT/libpomgpu_emu.so"
