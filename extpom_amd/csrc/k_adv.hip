@@ -451,15 +451,81 @@ __global__ void k_restore_load(KP P, const double *tr, const double *sr, double 
 }
 
 // ---------------------------------------------------------------------------------------------
-// dens -- solver.f:1162-1209.  abs(sr)**1.5 is formed as sr*sqrt(sr) in double-double so that it
-// is correctly rounded (glibc's pow, which the reference calls, is within 2^-12 ulp of that).
-__device__ __forceinline__ double pow15(double x) {
+// dens -- solver.f:1162-1209.
+// abs(sr)**1.5 is the one libm call on the hot path (the reference calls glibc's pow).  glibc's
+// pow is accurate to ~0.52 ulp but NOT correctly rounded, and this flow amplifies a 1-ulp seed
+// by 1e11 in 1000 steps, so gpow15() restates glibc 2.35's algorithm (FMA variant, the one x86-64
+// hosts with FMA run) instruction for instruction: log via a 128-entry table + degree-7 tail
+// polynomial in double-double, multiply by y, exp via a 128-entry 2^(k/128) table.  Verified
+// bit-identical to pow() on 2e7 arguments by tools/check_glibc_pow_clone.c.
+#include "glibc_pow_tables.h"
+static __device__ const double GP_A[7] = GPOW_A;
+static __device__ const double GP_LT[128][3] = GPOW_LOGTAB;
+static __device__ const double GP_C[4] = GEXP_C;
+static __device__ const unsigned long long GP_ET[256] = GEXP_TAB;
+__device__ __forceinline__ double pow15_dd(double x) {   // correctly rounded x*sqrt(x); only for non-normal x
   if (x == 0.) return 0.;
   const double s = sqrt(x);
-  const double e = __builtin_fma(-s, s, x) / (2. * s);   // sqrt(x) = s + e
+  const double e = __builtin_fma(-s, s, x) / (2. * s);
   const double p = x * s;
-  const double pe = __builtin_fma(x, s, -p);             // x*s = p + pe
+  const double pe = __builtin_fma(x, s, -p);
   return p + (pe + x * e);
+}
+__device__ __forceinline__ double gpow15(double x) {
+  const double y = 1.5;
+  const unsigned long long ix = __builtin_bit_cast(unsigned long long, x);
+  const unsigned top = (unsigned)(ix >> 52);
+  if (top - 1u >= 0x7feu) return pow15_dd(x);   // zero, subnormal, inf, nan: glibc's slow paths
+  const unsigned long long tmp = ix - 0x3fe6955500000000ULL;
+  const int i = (int)((tmp >> 45) & 127);
+  const long long k = (long long)tmp >> 52;
+  const double z = __builtin_bit_cast(double, ix - (tmp & 0xfff0000000000000ULL));
+  const double kd = (double)k;
+  const double invc = GP_LT[i][0], logc = GP_LT[i][1], logctail = GP_LT[i][2];
+  const double t1 = __builtin_fma(kd, GPOW_LN2HI, logc);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double ar = r * GP_A[0];
+  const double lo1 = __builtin_fma(kd, GPOW_LN2LO, logctail);
+  const double q1 = __builtin_fma(r, GP_A[2], GP_A[1]);
+  const double q2 = __builtin_fma(r, GP_A[4], GP_A[3]);
+  const double t2 = r + t1;
+  const double ar2 = r * ar;
+  const double d1 = t1 - t2;
+  const double ar3 = r * ar2;
+  const double lo3 = __builtin_fma(ar, r, -ar2);
+  const double lo2 = d1 + r;
+  const double q3 = __builtin_fma(r, GP_A[6], GP_A[5]);
+  const double hi = t2 + ar2;
+  const double d2 = t2 - hi;
+  const double q4 = __builtin_fma(q3, ar2, q2);
+  const double lo4 = d2 + ar2;
+  const double q5 = __builtin_fma(ar2, q4, q1);
+  double sm = lo1 + lo2;
+  sm = sm + lo3;
+  sm = sm + lo4;
+  const double lo = __builtin_fma(ar3, q5, sm);
+  const double yl = hi + lo;
+  const double tl = (hi - yl) + lo;
+  const double ehi = y * yl;
+  const double e2 = __builtin_fma(yl, y, -ehi);
+  const double elo = __builtin_fma(y, tl, e2);
+  double kd2 = __builtin_fma(ehi, GEXP_INVLN2N, GEXP_SHIFT);
+  const unsigned long long ki = __builtin_bit_cast(unsigned long long, kd2);
+  kd2 = kd2 - GEXP_SHIFT;
+  double rr = __builtin_fma(kd2, GEXP_NEGLN2HIN, ehi);
+  rr = __builtin_fma(kd2, GEXP_NEGLN2LON, rr);
+  const unsigned idx = 2u * (unsigned)(ki & 127);
+  const unsigned long long sbits = GP_ET[idx + 1] + (ki << 45);
+  rr = elo + rr;
+  const double p1 = __builtin_fma(rr, GP_C[1], GP_C[0]);
+  const double s1 = rr + __builtin_bit_cast(double, GP_ET[idx]);
+  const double r2 = rr * rr;
+  const double p2 = __builtin_fma(rr, GP_C[3], GP_C[2]);
+  const double s2 = __builtin_fma(p1, r2, s1);
+  const double r4 = r2 * r2;
+  const double tm = __builtin_fma(p2, r4, s2);
+  const double sc = __builtin_bit_cast(double, sbits);
+  return __builtin_fma(tm, sc, sc);
 }
 __global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
   CELL3
@@ -470,7 +536,7 @@ __global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
   const double p = P.grav * P.rhoref * (-F1(zz, k) * h_(i, j)) * 1.e-5;
   double rhor = -0.157406 + 6.793952e-2 * tr - 9.095290e-3 * tr2 + 1.001685e-4 * tr3 - 1.120083e-6 * tr4 + 6.536332e-9 * tr4 * tr;
   rhor = rhor + (0.824493 - 4.0899e-3 * tr + 7.6438e-5 * tr2 - 8.2467e-7 * tr3 + 5.3875e-9 * tr4) * sr +
-         (-5.72466e-3 + 1.0227e-4 * tr - 1.6546e-6 * tr2) * pow15(fabs(sr)) + 4.8314e-4 * sr * sr;
+         (-5.72466e-3 + 1.0227e-4 * tr - 1.6546e-6 * tr2) * gpow15(fabs(sr)) + 4.8314e-4 * sr * sr;
   const double cr = 1449.1 + .0821 * p + 4.55 * tr - .045 * tr2 + 1.34 * (sr - 35.);
   rhor = rhor + 1.e5 * p / (cr * cr) * (1. - 2. * p / (cr * cr));
   G3(rhoo, i, j, k) = rhor / P.rhoref * F2(fsm, i, j);
