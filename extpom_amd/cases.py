@@ -44,155 +44,182 @@ def sigma_levels(kb: int) -> tuple[np.ndarray, np.ndarray]:
     return z, zz
 
 
-def _grid_metrics(st: PomState, delx: float, stretch: float) -> None:
-    im, jm = st.im, st.jm
-    i = np.arange(1, im + 1)[None, :]
-    j = np.arange(1, jm + 1)[:, None]
-    st.dx[...] = delx - stretch * delx * np.sin(math.pi * i / im) / 2.0 + 0.0 * j
-    st.dy[...] = delx - stretch * delx * np.sin(math.pi * j / jm) / 2.0 + 0.0 * i
-    # corner / centre coordinates by accumulating spacings
-    ec = np.zeros((jm, im))
-    nc = np.zeros((jm, im))
-    ec[:, 1:] = np.cumsum(st.dx[:, :-1], axis=1)
-    nc[1:, :] = np.cumsum(st.dy[:-1, :], axis=0)
-    st.east_c[...] = ec
-    st.north_c[...] = nc
-    st.east_e[...] = ec + 0.5 * st.dx
-    st.north_e[...] = nc + 0.5 * st.dy
-    st.east_u[...] = ec
-    st.north_u[...] = nc + 0.5 * st.dy
-    st.east_v[...] = ec + 0.5 * st.dx
-    st.north_v[...] = nc
-    st.rot[...] = 0.0
+def _hash_noise(gi, gj, k, seed=12345):
+    """Deterministic, decomposition-independent pseudo-noise in [-1,1) from GLOBAL indices."""
+    x = np.sin(gi * 12.9898 + gj * 78.233 + k * 37.719 + seed * 0.0001) * 43758.5453
+    return 2.0 * (x - np.floor(x)) - 1.0
 
 
-def _derive_grid(st: PomState, lat0: float, lat_span: float) -> None:
-    """What read_grid derives after the file read (initialize.f:329-386) + the u/v masks."""
-    kb = st.kb
-    st.dz[:kb - 1] = st.z[:kb - 1] - st.z[1:]
-    st.dzz[:kb - 1] = st.zz[:kb - 1] - st.zz[1:]
-    st.dz[kb - 1] = 0.0
-    st.dzz[kb - 1] = 0.0
-    ymax = float(st.north_e.max())
-    lat = lat0 + lat_span * st.north_e / ymax
-    st.cor[...] = 2.0 * 7.29e-5 * np.sin(lat * (st.pi / 180.0))
-    st.period = (2.0 * st.pi) / abs(st.cor[st.jm // 2 - 1, st.im // 2 - 1]) / 86400.0
-    st.art[...] = st.dx * st.dy
-    st.aru[1:, 1:] = 0.25 * (st.dx[1:, 1:] + st.dx[1:, :-1]) * (st.dy[1:, 1:] + st.dy[1:, :-1])
-    st.arv[1:, 1:] = 0.25 * (st.dx[1:, 1:] + st.dx[:-1, 1:]) * (st.dy[1:, 1:] + st.dy[:-1, 1:])
-    st.aru[:, 0] = st.aru[:, 1]
-    st.arv[:, 0] = st.arv[:, 1]
-    st.aru[0, :] = st.aru[1, :]
-    st.arv[0, :] = st.arv[1, :]
-    # masks (io_pnetcdf.F:2243-2256)
-    fsm = st.fsm
-    st.dvm[...] = fsm
-    st.dum[...] = fsm
-    st.dvm[1:, :][(fsm[:-1, :] == 0.0) & (fsm[1:, :] != 0.0)] = 0.0
-    st.dum[:, 1:][(fsm[:, :-1] == 0.0) & (fsm[:, 1:] != 0.0)] = 0.0
-    st.d[...] = st.h + st.el
-    st.dt[...] = st.h + st.et
-
-
-def make_case(name: str, im: int, jm: int, kb: int, **nml) -> PomState:
-    """Global (single-tile) state holding everything the reference's readers + read_grid provide."""
-    st = PomState(im, jm, kb)
+def make_case(name: str, im: int, jm: int, kb: int, tile=None, **nml) -> PomState:
+    """State of one tile (default: the whole im x jm grid as a single tile) holding everything the
+    reference's readers + read_grid provide.  Every value is a function of GLOBAL indices and 1-D
+    global coordinate vectors, so a tile generated here equals the same window cut out of the
+    single-tile state bit for bit (tests/test_host_logic.py) without any rank ever building the
+    global 3-D arrays."""
+    if tile is None:
+        from .decomp import make_tile
+        tile = make_tile(0, im, jm, im, jm)
+    st = PomState(tile.im_local, tile.jm_local, kb, tile.im, tile.jm)
+    st.n_west, st.n_east, st.n_south, st.n_north = tile.n_west, tile.n_east, tile.n_south, tile.n_north
+    st.i_off, st.j_off = tile.i_off, tile.j_off
     c = run_constants(None, **nml)
     apply_constants(st, c)
     z, zz = sigma_levels(kb)
     st.z[...] = z
     st.zz[...] = zz
+    st.dz[:kb - 1] = z[:kb - 1] - z[1:]
+    st.dzz[:kb - 1] = zz[:kb - 1] - zz[1:]
+
+    # ---- global 1-D coordinate vectors (index 0 = global point 1) -------------------------
     delx = 8000.0
-    _grid_metrics(st, delx, 1.0 if name != "basin" else 0.5)
-    xc = st.east_e - st.east_e[:, (im + 1) // 2 - 1][:, None]
-    yc = st.north_e - st.north_e[(jm + 1) // 2 - 1, :][None, :]
-    lx = float(st.east_e.max())
-    ly = float(st.north_e.max())
+    stretch = 0.5 if name == "basin" else 1.0
+    gi1 = np.arange(1, im + 1, dtype=np.float64)
+    gj1 = np.arange(1, jm + 1, dtype=np.float64)
+    dx1 = delx - stretch * delx * np.sin(math.pi * gi1 / im) / 2.0
+    dy1 = delx - stretch * delx * np.sin(math.pi * gj1 / jm) / 2.0
+    ec1 = np.concatenate(([0.0], np.cumsum(dx1[:-1])))
+    nc1 = np.concatenate(([0.0], np.cumsum(dy1[:-1])))
+    ee1 = ec1 + 0.5 * dx1
+    ne1 = nc1 + 0.5 * dy1
+    lx, ly = float(ee1[-1]), float(ne1[-1])
+    x0, y0 = float(ee1[(im + 1) // 2 - 1]), float(ne1[(jm + 1) // 2 - 1])
+
+    # ---- window = tile plus one extra column/row on the low side (for the u/v masks) ------
+    ti, tj, io, jo = tile.im, tile.jm, tile.i_off, tile.j_off
+    wi = np.arange(io, io + ti + 1)          # global i (1-based) of window columns; wi[0] may be 0
+    wj = np.arange(jo, jo + tj + 1)
+    ci = np.clip(wi, 1, im) - 1              # index into the 1-D vectors
+    cj = np.clip(wj, 1, jm) - 1
+    X = ee1[ci][None, :]
+    Y = ne1[cj][:, None]
+    xc, yc = X - x0, Y - y0
     vel = 0.0
     if name == "seamount":
         ra = 0.12 * min(lx, ly) + 12500.0
-        st.h[...] = 4500.0 * (1.0 - 0.9 * np.exp(-(xc * xc + yc * yc) / (ra * ra)))
-        st.h[st.h < 1.0] = 1.0
-        st.h[0, :] = 1.0
-        st.h[jm - 1, :] = 1.0
+        hw = 4500.0 * (1.0 - 0.9 * np.exp(-(xc * xc + yc * yc) / (ra * ra)))
         vel = 0.2
     elif name == "island":
         ra = 0.10 * min(lx, ly) + 10000.0
-        st.h[...] = 3000.0 * (1.0 - 0.85 * np.exp(-(xc * xc + 1.7 * yc * yc) / (ra * ra)))
-        st.h[st.h < 1.0] = 1.0
+        hw = 3000.0 * (1.0 - 0.85 * np.exp(-(xc * xc + 1.7 * yc * yc) / (ra * ra)))
         vel = 0.1
     elif name == "basin":
-        sx = st.east_e / lx
-        sy = st.north_e / ly
-        st.h[...] = (1500.0 + 1500.0 * sx + 400.0 * np.sin(3.0 * math.pi * sx) * np.sin(2.0 * math.pi * sy)
-                     + 250.0 * np.cos(7.0 * math.pi * sy))
-        st.h[0, :] = 1.0
-        st.h[jm - 1, :] = 1.0
-        st.h[:, 0] = 1.0
-        st.h[:, im - 1] = 1.0
+        sx, sy = X / lx, Y / ly
+        hw = (1500.0 + 1500.0 * sx + 400.0 * np.sin(3.0 * math.pi * sx) * np.sin(2.0 * math.pi * sy)
+              + 250.0 * np.cos(7.0 * math.pi * sy))
     else:
         raise ValueError(f"unknown case {name!r}")
-    st.fsm[...] = np.where(st.h > 1.0, 1.0, 0.0)
-    _derive_grid(st, 30.0, 15.0)
-
-    # initial T/S and climatology (level kb defined explicitly -- the reference's reader leaves it
-    # uninitialised, io_pnetcdf.F:2825-2839)
-    depth = zz[:, None, None] * st.h[None, :, :]
+    hw = np.where(hw < 1.0, 1.0, hw) + 0.0 * X
+    gI = wi[None, :] + 0 * wj[:, None]
+    gJ = wj[:, None] + 0 * wi[None, :]
+    if name in ("seamount", "basin"):
+        hw = np.where((gJ <= 1) | (gJ >= jm), 1.0, hw)          # closed north/south walls
     if name == "basin":
-        rng = np.random.default_rng(12345)
-        st.tb[...] = 18.0 + 14.0 * depth / 3500.0 + 1.0e-3 * rng.standard_normal(st.tb.shape)
-        st.sb[...] = 35.0 - 0.6 * depth / 3500.0
-        st.tclim[...] = 18.0 + 14.0 * depth / 3500.0
-        st.sclim[...] = st.sb
-    else:
-        st.tb[...] = 5.0 + 15.0 * np.exp(depth / 1000.0) - st.tbias
-        st.sb[...] = 35.0 - st.sbias
-        st.tclim[...] = st.tb
-        st.sclim[...] = st.sb
-    st.tb[kb - 1] = st.tb[kb - 2]
-    st.sb[kb - 1] = st.sb[kb - 2]
-    st.tclim[kb - 1] = st.tclim[kb - 2]
-    st.sclim[kb - 1] = st.sclim[kb - 2]
-    st.tb[...] *= st.fsm[None]
-    st.sb[...] *= st.fsm[None]
-    st.tclim[...] *= st.fsm[None]
-    st.sclim[...] *= st.fsm[None]
+        hw = np.where((gI <= 1) | (gI >= im), 1.0, hw)          # land rim all round
+    fw = np.where(hw > 1.0, 1.0, 0.0)
+    # masks (io_pnetcdf.F:2243-2256): a u/v point is closed when the cell behind it is land
+    dumw = fw.copy()
+    dvmw = fw.copy()
+    dumw[:, 1:][(fw[:, :-1] == 0.0) & (fw[:, 1:] != 0.0)] = 0.0
+    dvmw[1:, :][(fw[:-1, :] == 0.0) & (fw[1:, :] != 0.0)] = 0.0
+    if io == 0:      # global column 1 has nothing behind it
+        dumw[:, 1] = fw[:, 1]
+    if jo == 0:
+        dvmw[1, :] = fw[1, :]
 
-    # initial flow and open-boundary data
+    A = (slice(0, tj), slice(0, ti))         # active part of the (padded) tile arrays
+    W = (slice(1, None), slice(1, None))     # the tile inside the window
+    st.h[A] = hw[W]
+    st.fsm[A] = fw[W]
+    st.dum[A] = dumw[W]
+    st.dvm[A] = dvmw[W]
+    li, lj = ci[1:], cj[1:]
+    st.dx[A] = dx1[li][None, :] + 0.0 * dy1[lj][:, None]
+    st.dy[A] = dy1[lj][:, None] + 0.0 * dx1[li][None, :]
+    st.east_c[A] = ec1[li][None, :] + 0.0 * nc1[lj][:, None]
+    st.north_c[A] = nc1[lj][:, None] + 0.0 * ec1[li][None, :]
+    st.east_e[A] = st.east_c[A] + 0.5 * st.dx[A]
+    st.north_e[A] = st.north_c[A] + 0.5 * st.dy[A]
+    st.east_u[A] = st.east_c[A]
+    st.north_u[A] = st.north_c[A] + 0.5 * st.dy[A]
+    st.east_v[A] = st.east_c[A] + 0.5 * st.dx[A]
+    st.north_v[A] = st.north_c[A]
+    # read_grid's derived quantities (initialize.f:329-386)
+    lat = 30.0 + 15.0 * st.north_e[A] / ly
+    st.cor[A] = 2.0 * 7.29e-5 * np.sin(lat * (st.pi / 180.0))
+    lat_mid = 30.0 + 15.0 * ne1[jm // 2 - 1] / ly
+    st.period = (2.0 * st.pi) / abs(2.0 * 7.29e-5 * math.sin(lat_mid * (st.pi / 180.0))) / 86400.0
+    st.art[A] = st.dx[A] * st.dy[A]
+    dxw, dyw = dx1[ci], dy1[cj]              # window-indexed spacings
+    # aru/arv for global i,j >= 2; row/column 1 copy their neighbour (initialize.f:362-378)
+    aruw = 0.25 * (dxw[None, 1:] + dxw[None, :-1]) * (dyw[1:, None] + dyw[1:, None]) + 0.0
+    arvw = 0.25 * (dxw[None, 1:] + dxw[None, 1:]) * (dyw[1:, None] + dyw[:-1, None]) + 0.0
+    st.aru[A] = aruw
+    st.arv[A] = arvw
+    if io == 0:
+        st.aru[:tj, 0] = st.aru[:tj, 1]
+        st.arv[:tj, 0] = st.arv[:tj, 1]
+    if jo == 0:
+        st.aru[0, :ti] = st.aru[1, :ti]
+        st.arv[0, :ti] = st.arv[1, :ti]
+    st.d[...] = st.h + st.el
+    st.dt[...] = st.h + st.et
+
+    # ---- initial T/S and climatology (level kb defined explicitly -- the reference's reader
+    # leaves it uninitialised, io_pnetcdf.F:2825-2839) ------------------------------------
+    hA = st.h[A]
+    depth = zz[:, None, None] * hA[None]
+    A3 = (slice(None),) + A
+    if name == "basin":
+        kk = np.arange(1, kb + 1, dtype=np.float64)[:, None, None]
+        noise = _hash_noise(gI[W][None].astype(np.float64), gJ[W][None].astype(np.float64), kk)
+        st.tclim[A3] = 18.0 + 14.0 * depth / 3500.0
+        st.tb[A3] = st.tclim[A3] + 1.0e-3 * noise
+        st.sb[A3] = 35.0 - 0.6 * depth / 3500.0
+        st.sclim[A3] = st.sb[A3]
+    else:
+        st.tb[A3] = 5.0 + 15.0 * np.exp(depth / 1000.0) - st.tbias
+        st.sb[A3] = 35.0 - st.sbias
+        st.tclim[A3] = st.tb[A3]
+        st.sclim[A3] = st.sb[A3]
+    for f in (st.tb, st.sb, st.tclim, st.sclim):
+        f[kb - 1] = f[kb - 2]
+        f[...] *= st.fsm[None]
+
+    # ---- initial flow and open-boundary data ------------------------------------------------
     st.ub[:kb - 1] = vel * st.dum[None]
     st.uab[...] = vel * st.dum
-    st.uabe[...] = st.uab[:, im - 2]
+    st.uabe[...] = st.uab[:, ti - 2]
     st.uabw[...] = st.uab[:, 1]
     if name == "island":
         st.vb[:kb - 1] = 0.25 * vel * st.dvm[None]
         st.vab[...] = 0.25 * vel * st.dvm
-        st.vabn[...] = st.vab[jm - 2, :]
+        st.vabn[...] = st.vab[tj - 2, :]
         st.vabs[...] = st.vab[1, :]
-        st.vabe[...] = st.vab[:, im - 1]
+        st.vabe[...] = st.vab[:, ti - 1]
         st.vabw[...] = st.vab[:, 0]
-        st.uabn[...] = st.uab[jm - 1, :]
+        st.uabn[...] = st.uab[tj - 1, :]
         st.uabs[...] = st.uab[0, :]
-        st.vbn[...] = st.vb[:, jm - 2, :]
+        st.vbn[...] = st.vb[:, tj - 2, :]
         st.vbs[...] = st.vb[:, 1, :]
-        st.ubn[...] = st.ub[:, jm - 1, :]
+        st.ubn[...] = st.ub[:, tj - 1, :]
         st.ubs[...] = st.ub[:, 0, :]
-    st.ube[...] = st.ub[:, :, im - 2]
+    st.ube[...] = st.ub[:, :, ti - 2]
     st.ubw[...] = st.ub[:, :, 1]
 
-    # surface forcing, constant in time (the reference's wind/heat readers are out of scope)
+    # ---- surface forcing, constant in time (the reference's wind/heat readers are out of scope)
     if name == "basin":
-        st.wusurf[...] = -1.0e-4 * np.cos(math.pi * st.north_e / ly) * st.fsm
-        st.wtsurf[...] = 2.0e-6 * np.sin(2.0 * math.pi * st.east_e / lx) * st.fsm
+        st.wusurf[A] = -1.0e-4 * np.cos(math.pi * st.north_e[A] / ly) * st.fsm[A]
+        st.wtsurf[A] = 2.0e-6 * np.sin(2.0 * math.pi * st.east_e[A] / lx) * st.fsm[A]
     else:
-        st.wusurf[...] = -2.0e-5 * st.fsm
-        st.wvsurf[...] = 1.0e-5 * np.sin(math.pi * st.east_e / lx) * st.fsm
+        st.wusurf[A] = -2.0e-5 * st.fsm[A]
+        st.wvsurf[A] = 1.0e-5 * np.sin(math.pi * st.east_e[A] / lx) * st.fsm[A]
 
     # relaxation targets served to restore_interior (bounds_forcing.f:1039-1065 reads record
     # iint/irst+1 at iint=2 and the following one): climatology, the second record 0.01 degC /
     # 0.002 psu warmer/saltier so that the time interpolation is exercised.
     st.restore_records = [
-        (st.tclim[:, :jm, :im].copy(), st.sclim[:, :jm, :im].copy()),
-        ((st.tclim[:, :jm, :im] + 0.01) * st.fsm[None, :jm, :im], (st.sclim[:, :jm, :im] + 0.002) * st.fsm[None, :jm, :im]),
+        (st.tclim[A3].copy(), st.sclim[A3].copy()),
+        ((st.tclim[A3] + 0.01) * st.fsm[A][None], (st.sclim[A3] + 0.002) * st.fsm[A][None]),
     ]
     return st
 
@@ -244,7 +271,8 @@ def finish_initial(st: PomState, dens, baropg) -> PomState:
         st.drx2d[...] += st.drhox[k] * st.dz[k]
         st.dry2d[...] += st.drhoy[k] * st.dz[k]
     # bottom_friction (initialize.f:524-544)
-    cbc = (st.kappa / np.log((1.0 + st.zz[kb - 2]) * st.h / st.z0b)) ** 2
+    with np.errstate(divide="ignore"):      # h = 0 only in the padding of a trimmed tile
+        cbc = (st.kappa / np.log((1.0 + st.zz[kb - 2]) * st.h / st.z0b)) ** 2
     st.cbc[...] = np.minimum(st.cbcmax, np.maximum(st.cbcmin, cbc))
     return st
 

@@ -1,0 +1,121 @@
+"""Kernel LOGIC on the CPU: the unmodified kernel sources of extpom_amd/csrc are compiled for the
+host by tests/emu (each launch runs as a serial loop over its grid) and must reproduce the CPU
+oracle bit for bit -- per routine and per step.  This is test infrastructure: the emulated
+library lives in tests/_emu and is loaded only here (the product path needs a real HIP device).
+The arrays tps, fluxua, fluxva, zflux are pure scratch in the reference;
+the fused kernels do not materialise them, so they are not compared."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from extpom_amd.cases import make_case
+from extpom_amd.layout import BLK2D, BLK3D
+from extpom_amd.model import PomGpu
+from oracle.pyoracle import OracleTile, oracle_finish_initial
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "_emu", "libpomgpu_emu.so")
+SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_lib():
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+
+
+def diff(a, b, skip=SCRATCH):
+    return [n for n in BLK2D + BLK3D if n not in skip and not np.array_equal(a.field(n), b.field(n))]
+
+
+@pytest.mark.parametrize("case,nml,steps", [
+    ("seamount", dict(), 8), ("island", dict(), 6), ("basin", dict(), 6),
+    ("seamount", dict(nadv=1), 4), ("island", dict(nitera=2), 4), ("seamount", dict(nitera=3, sw=1.0), 3),
+    ("seamount", dict(mode=4), 4), ("seamount", dict(mode=2), 4), ("seamount", dict(nbct=3, nbcs=3), 4),
+    ("basin", dict(isplit=10, alpha=0.225), 4)])
+def test_steps_bit_identical(case, nml, steps):
+    kw = dict(dte=6.0, isplit=30)
+    kw.update(nml)
+    a = make_case(case, 65, 49, 21, **kw)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, steps + 1):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+        assert a.iint == b.iint == n
+    assert g.check_velocity() == ot.vamax
+
+
+def warm_state(case="island"):
+    a = make_case(case, 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    OracleTile(a).run(3)
+    a.iint = 4
+    a.iext = 7
+    return a
+
+
+ROUTINES = [
+    ("advave", (), ()), ("advct", (), ()), ("advu", (), ()), ("advv", (), ()), ("baropg", (), ()), ("profq", (), ()),
+    ("profu", (), ()), ("profv", (), ()), ("vertvl", (), ()), ("realvertvl", (), ()), ("lateral_viscosity", (), ()),
+    ("mode_interaction", (), ()), ("mode_external", (), ()), ("mode_internal", (), ()),
+    ("advq", ("q2b", "q2", "uf"), ()), ("advt1", ("tb", "t", "tclim", "uf"), ()), ("advt2", ("sb", "s", "sclim", "vf"), ()),
+    ("dens", ("s", "t", "rho"), ()), ("proft", ("uf", "wtsurf", "tsurf"), (1,)), ("proft", ("vf", "wssurf", "ssurf"), (3,)),
+    ("bcond", (), (1,)), ("bcond", (), (2,)), ("bcond", (), (4,)), ("bcond", (), (5,)), ("bcond", (), (6,)),
+    ("bcondorl", (), (3,)), ("bcondorl", (), (5,)), ("restore_interior", (), ()),
+]
+
+
+@pytest.mark.parametrize("name,fields,ints", ROUTINES, ids=[f"{r[0]}{''.join(map(str, r[2]))}" for r in ROUTINES])
+def test_routine_bit_identical(name, fields, ints):
+    a = warm_state()
+    b = a.copy()
+    ot = OracleTile(a)
+    ot.call(name, *[ot.a3(f) for f in fields], *[ctypes.c_int(i) for i in ints])
+    g = PomGpu(b, libpath=EMU)
+    g.call(name, *fields, *ints)
+    g.download()
+    # stand-alone profu/profv leave the reference's non-interior junk of advu/advv untouched: same input, same output
+    assert not diff(a, b), f"{name}: {diff(a, b)}"
+
+
+def test_trimmed_tile_padding_is_inert():
+    """a tile whose active extent is smaller than its leading dimensions (east/north-most tiles,
+    parallel_mpi.f:83-87) gives the same active-region result as the tight layout"""
+    from extpom_amd.layout import PomState
+    a = make_case("basin", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = PomState(72, 53, 21, im=65, jm=49)
+    b.blk1d[...] = a.blk1d
+    b.blk2d[:, :49, :65] = a.blk2d
+    b.blk3d[:, :, :49, :65] = a.blk3d
+    from extpom_amd.layout import BDRY
+    for n, kind in BDRY:
+        src, dst = a.field(n), b.field(n)
+        if kind == "J":
+            dst[:49] = src
+        elif kind == "I":
+            dst[:65] = src
+        elif kind == "JK":
+            dst[:, :49] = src
+        else:
+            dst[:, :65] = src
+    b.con[...] = a.con
+    b.restore_records = a.restore_records
+    ga, gb = PomGpu(a, libpath=EMU), PomGpu(b, libpath=EMU)
+    ga.run(3)
+    gb.run(3)
+    ga.download()
+    gb.download()
+    for n in BLK2D:
+        if n not in SCRATCH:
+            assert np.array_equal(a.field(n), b.field(n)[:49, :65]), n
+    for n in BLK3D:
+        if n not in SCRATCH:
+            assert np.array_equal(a.field(n), b.field(n)[:, :49, :65]), n
