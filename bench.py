@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: whole internal steps of the mode-split time step (one `advance`:
+lateral_viscosity, mode_interaction, isplit external substeps, mode_internal, check_velocity).
+
+    python bench.py --gpus N --steps K --warmup W [--workload basin2048|seamount256|basin1024|...]
+
+N=1 runs in this process; for N>1 the driver launches one rank per GPU with torch.distributed.run
+and the global grid is split into N tiles (strong scaling: the global grid is fixed).  Rank 0
+prints ONE JSON line.  `value` = im_global*jm_global*kb*K / max-over-ranks wall time of the K timed
+steps, state resident in HBM before the timed region starts.
+
+Extra objects on the same line:
+  roofline      dominant kernel (largest share of device time in a profiled step): ALGORITHMIC bytes
+                per launch / its mean launch duration measured with HIP events on the kernels' own
+                stream inside the timed region (only that kernel is bracketed there).
+  cpu_baseline  the CPU oracle (plain-C restatement, bit-identical to the reference build) timed on
+                this box's host, 1 core, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (case, im, jm, kb, description)
+    "basin2048": ("basin", 2048, 1536, 50, "closed basin 2048x1536x50 fp64 (BASELINE configs[3] grid)"),
+    "basin1024": ("basin", 1024, 1024, 40, "closed basin 1024x1024x40 fp64 (BASELINE configs[2] grid)"),
+    "seamount256": ("seamount", 256, 256, 30, "seamount 256x256x30 fp64 (BASELINE configs[1])"),
+    "seamount65": ("seamount", 65, 49, 21, "seamount 65x49x21 fp64 (BASELINE configs[0])"),
+}
+NML = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
+
+# ALGORITHMIC traffic per kernel launch in full 3-D array passes (distinct arrays a launch must read
+# + write once; 2-D arrays cost 1/kb and are not counted) -- DESIGN.md "Kernels" derives each row from
+# SURVEY 8(a)/(d).  bytes per launch = passes * 8 B * im*jm*kb of the tile.
+KERNEL_PASSES = {
+    "k_advt2_fused": 7,      # a13: R fb,fclim,u,v,w,aam  W ff
+    "k_profq": 21,           # a10 minus the separately launched production term: R kq,km,kh,t,s,rho,q2b,q2lb,q2,uf,vf,prod W q2b,q2lb,l,dtef,uf,vf,kq,km,kh
+    "k_profq_prod": 9,       # R km,kh,t,s,rho,u,v (+1 k-shifted reuse counted once) W prod  -> 7R+1W (+1)
+    "k_advq_flux": 7,        # a9 first half: R q,qb,u,v,aam W xflux,yflux
+    "k_advq_step": 6,        # a9 second half: R q,qb,w,xflux,yflux W qf
+    "k_advct_a": 8,          # a2: R u,v,ub,vb,aam W curv,xflux,yflux
+    "k_advct_b": 11,         # R curv,xflux,yflux,u,v,ub,vb,aam W advx,xflux',yflux'
+    "k_advct_c": 6,          # R curv,xflux',yflux',u (+v) W advy
+    "k_advu_profu": 9,       # a17+a18: R w,u,v,advx,drhox,ub,vb(kbm1),km W uf
+    "k_advv_profv": 9,
+    "k_uv_filter": 10,       # a19: R uf,ub,u,vf,vb,v W ub,u,vb,v
+    "k_proft": 3,            # a14: R f,kh W f
+    "k_ts_filter": 10,       # a15: R uf,vf,t,tb,s,sb W tb,t,sb,s (+uf,vf masks)
+    "k_q_filter": 10,
+    "k_restore": 13,         # R trstrb/f,srstrb/f,taurstrb/f,t,tb,s,sb W trstr,srstr,taurstr,t,tb,s,sb (not in SURVEY's 133)
+    "k_dens": 3,             # a16
+    "k_baropg": 4,           # a3
+    "k_roundtrip": 3,
+    "k_aam": 3,              # a1
+    "k_vint": 5,             # a4
+    "k_int_uvmean": 4,       # a7
+    "k_vertvl": 3,           # a8
+    "k_realvertvl": 4,       # a20
+}
+P_STEP = 133                 # algorithmic 3-D passes per internal step (mode=3 nadv=2 nitera=1)
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+
+
+def build_state(workload, tile):
+    from extpom_amd.cases import make_case
+    case, im, jm, kb, _ = WORKLOADS[workload]
+    return make_case(case, im, jm, kb, tile=tile, **NML)
+
+
+def gpu_initialise(st, device, stream):
+    """the reference's initialisation tail (dens, baropg, bottom friction ...) with the HIP kernels"""
+    from extpom_amd.cases import finish_initial
+    from extpom_amd.layout import P3
+    from extpom_amd.model import PomGpu
+    g = PomGpu(st, device=device, stream=stream)
+    P = lambda a: __import__("ctypes").c_void_p(a.ctypes.data)
+
+    def dens(s, si, ti, rho):
+        g.call("dens", si, ti, rho)
+        g._chk(g.L.pomgpu_download_3d(g.h, P3[rho], P(s.field(rho))), "download")
+
+    def baropg(s):
+        g.call("baropg")
+        for f in ("drhox", "drhoy", "rho"):
+            g._chk(g.L.pomgpu_download_3d(g.h, P3[f], P(s.field(f))), "download")
+
+    finish_initial(st, dens, baropg)
+    g.upload(st)
+    return g
+
+
+def cpu_baseline(workload):
+    """oracle on one host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid"""
+    from extpom_amd.cases import make_case
+    from oracle.pyoracle import OracleTile, oracle_finish_initial
+    case, im, jm, kb, _ = WORKLOADS[workload]
+    sim, sjm = max(65, im // 8), max(49, jm // 8)
+    st = make_case(case, sim, sjm, kb, **NML)
+    oracle_finish_initial(st)
+    ot = OracleTile(st)
+    ot.run(2)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 4 or (time.perf_counter() - t0 < 12.0 and n < 400):
+        ot.run(1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": sim * sjm * kb * n / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{case} {sim}x{sjm}x{kb}, {n} internal steps of the plain-C oracle (gcc -O2, bit-identical to the flang-built reference), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("POM_BENCH_WORKLOAD", "basin2048"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    from extpom_amd import decomp, dist as pdist
+    rank, world, local = pdist.init()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench: no GPU visible -- the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    case, im, jm, kb, desc = WORKLOADS[args.workload]
+    tile = pdist.tile_for_rank(rank, world, im, jm)
+    st = build_state(args.workload, tile)
+    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    g = gpu_initialise(st, local, stream)
+    if world > 1:
+        from extpom_amd.halo import Halo
+        halo = Halo(tile)
+        g.set_exchange(halo.gpu_hook(torch.device("cuda", local)))
+
+    def barrier():
+        g.sync()
+        if world > 1:
+            torch.distributed.barrier()
+
+    # warm-up, then a profiled step to find the dominant kernel
+    g.run(max(args.warmup, 1))
+    barrier()
+    g.prof_begin()
+    g.run(1)
+    prof = g.prof_end()
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+    barrier()
+
+    # the timed region: exactly K steps, only the dominant kernel bracketed by events
+    g.prof_begin(only=None if args.profile_all else dom)
+    barrier()
+    t0 = time.perf_counter()
+    g.run(args.steps)
+    g.sync()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    timed = g.prof_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    g.get_con()
+    err = int(st.error_status)
+
+    if rank == 0:
+        cells = im * jm * kb
+        tile_cells = tile.im_local * tile.jm_local * kb
+        ms = dt / args.steps * 1e3
+        value = cells * args.steps / dt
+        nl, tms = timed.get(dom, (0, 0.0))
+        passes = KERNEL_PASSES.get(dom)
+        roof = None
+        if nl and passes:
+            ach = passes * 8.0 * tile_cells / (tms / nl * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                rec = json.load(open(tf)).get(f"{args.workload}/{world}/{dom}")
+                traffic = rec["bytes_per_launch"] if rec else None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": passes * 8 * tile_cells, "launches": nl,
+                    "avg_launch_ms": round(tms / nl, 4)}
+        # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
+        ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
+        int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
+        ext_ms = sum(v[1] for k, v in prof.items() if k.startswith(ext))
+        step_gbs = P_STEP * 8.0 * cells / (dt / args.steps) / 1e9
+        share = sorted(((k, v[1]) for k, v in prof.items()), key=lambda kv: -kv[1])
+        tot = sum(v for _, v in share) or 1.0
+        out = {
+            "metric": "3D cell-updates/sec (whole internal step incl. the isplit external substeps)",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
+                       "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells},
+            "roofline": roof,
+            "step_algorithmic_GBps": round(step_gbs, 1), "step_frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4),
+            "internal_mode": {"device_ms_per_step": round(int_ms, 3), "cell_updates_per_s": (tile_cells / (int_ms * 1e-3)) if int_ms else None,
+                              "algorithmic_GBps": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
+                              "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
+            "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
+            "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
+            "error_status": err,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    g.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
