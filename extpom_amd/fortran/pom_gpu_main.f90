@@ -1,0 +1,85 @@
+! pom_gpu_main.f90 -- a minimal Fortran driver in the shape of the reference's `program pom`
+! (reference pom/pom.f:5-39): take the initial COMMON blocks from a raw dump written by extpom_amd
+! (the reference would read them through PnetCDF, which this image lacks), read pom.nml like
+! read_input (initialize.f:71-74,173-198), then
+!     do iint=1,nsteps: advance
+! where `advance_hot` is the reference's sequence (advance.f:6-59) minus file forcing / print /
+! output, and every routine it calls is a pom_gpu_host.f90 wrapper -> C ABI -> HIP kernels.
+! Writes the final blocks back for checking against the oracle (tests/test_fortran_host.py).
+!
+! usage: pom_gpu_main <state.in> <state.out>     (pom.nml in the working directory)
+program pom_gpu_main
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  namelist/pom_nml/ title,wrk_pth,netcdf_file,mode,nadv,nitera,sw,npg,dte,isplit,time_start,nread_rst, &
+                    read_rst_file,cont_bry,write_rst,write_rst_file,days,prtd1,prtd2,swtch,ntp,nbct,nbcs
+  integer :: nsteps, nrec, n, rc, n2, n3, nbd
+  double precision, allocatable, target :: tr(:,:,:,:), sr(:,:,:,:)
+  character(len=256) :: fin, fout
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  n2 = im_local*jm_local
+  n3 = n2*kb
+  nbd = 8*jm_local + 8*im_local + (12+12+6+6)*0   ! filled below
+  nbd = 20*jm_local + 20*im_local + 18*jm_local*kb + 18*im_local*kb   ! bdry: 20 J, 20 I... see pom_layout.h
+  open(71, file=trim(fin), form='unformatted', access='stream', status='old')
+  read(71) im, jm, n_west, n_east, n_south, n_north, nsteps, nrec, nbd
+  imm1=im-1; imm2=im-2; jmm1=jm-1; jmm2=jm-2; kbm1=kb-1; kbm2=kb-2
+  call blk_read(71, dz, 4*kb)                ! COMMON members are contiguous: read each block whole
+  call blk_read(71, aam2d, 73*n2)
+  call blk_read(71, aam, 40*n3)
+  call blk_read(71, ele, nbd)
+  call blk_read(71, alpha, 47)               ! blkcon: 376 bytes
+  allocate(tr(im,jm,kb,max(nrec,1)), sr(im,jm,kb,max(nrec,1)))
+  do n = 1, nrec
+    read(71) tr(:,:,:,n), sr(:,:,:,n)
+  end do
+  close(71)
+  lramp = .false.
+  open(73, file='pom.nml', status='old')
+  read(73, nml=pom_nml)
+  close(73)
+  dti=dte*float(isplit); dte2=dte*2; dti2=dti*2
+  ispi=1.d0/float(isplit); isp2i=1.d0/(2.d0*float(isplit))
+
+  call pomgpu_host_init(0)
+  call pomgpu_upload_state
+  do n = 1, nrec
+    rc = pomgpu_set_restore_record(pom_ctx, int(n, c_int), c_loc(tr(1,1,1,n)), c_loc(sr(1,1,1,n)))
+  end do
+  do n = 1, nsteps                           ! pom.f:17-19
+    iint = iint + 1
+    call advance_hot
+  end do
+  call pomgpu_download_state
+  open(72, file=trim(fout), form='unformatted', access='stream', status='replace')
+  call blk_write(72, aam2d, 73*n2)
+  call blk_write(72, aam, 40*n3)
+  call blk_write(72, alpha, 47)
+  close(72)
+  write(6,'(a,i6,a,i3)') 'pom_gpu_main: steps ', nsteps, '  error_status ', error_status
+  call pomgpu_destroy(pom_ctx)
+end program
+
+! advance.f:6-59 without surface_forcing / lateral_bc (file readers), print_section and output
+subroutine advance_hot
+  implicit none
+  include 'pom.h'
+  time=dti*float(iint)/86400.d0+time0        ! get_time, advance.f:62-75
+  if(iint.ge.iswtch) iprint=nint(prtd2*24.d0*3600.d0/dti)
+  if(lramp) then
+    ramp=time/period
+    if(ramp.gt.1.d0) ramp=1.d0
+  else
+    ramp=1.d0
+  endif
+  call lateral_viscosity
+  call mode_interaction
+  do iext=1,isplit
+    call mode_external
+  end do
+  call mode_internal
+  call check_velocity
+end subroutine

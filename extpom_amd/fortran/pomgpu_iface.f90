@@ -1,0 +1,85 @@
+! pomgpu_iface.f90 -- ISO_C_BINDING view of the C ABI (include/pomgpu.h).
+! One interface per entry point; array arguments are passed as the address of the COMMON array
+! (c_loc), exactly what the reference's by-reference calls hand to its own kernels.
+module pomgpu_iface
+  use iso_c_binding
+  implicit none
+  type, bind(C) :: pomgpu_dims
+    integer(c_int) :: im, jm, kb, im_local, jm_local, n_west, n_east, n_south, n_north
+  end type
+  type(c_ptr), save :: pom_ctx = c_null_ptr
+  interface
+    integer(c_int) function pomgpu_create(ctx, dims, device, stream) bind(C, name='pomgpu_create')
+      import; type(c_ptr) :: ctx; type(pomgpu_dims) :: dims; integer(c_int), value :: device; type(c_ptr), value :: stream
+    end function
+    subroutine pomgpu_destroy(ctx) bind(C, name='pomgpu_destroy')
+      import; type(c_ptr), value :: ctx
+    end subroutine
+    integer(c_int) function pomgpu_upload(ctx, b1, b2, b3, bd, con, lramp) bind(C, name='pomgpu_upload')
+      import; type(c_ptr), value :: ctx, b1, b2, b3, bd, con; integer(c_int), value :: lramp
+    end function
+    integer(c_int) function pomgpu_download(ctx, b1, b2, b3, bd, con) bind(C, name='pomgpu_download')
+      import; type(c_ptr), value :: ctx, b1, b2, b3, bd, con
+    end function
+    integer(c_int) function pomgpu_set_con(ctx, con, lramp) bind(C, name='pomgpu_set_con')
+      import; type(c_ptr), value :: ctx, con; integer(c_int), value :: lramp
+    end function
+    integer(c_int) function pomgpu_get_con(ctx, con) bind(C, name='pomgpu_get_con')
+      import; type(c_ptr), value :: ctx, con
+    end function
+    integer(c_int) function pomgpu_bind_host(ctx, h2, h3) bind(C, name='pomgpu_bind_host')
+      import; type(c_ptr), value :: ctx, h2, h3
+    end function
+    integer(c_int) function pomgpu_set_restore_record(ctx, n, tr, sr) bind(C, name='pomgpu_set_restore_record')
+      import; type(c_ptr), value :: ctx, tr, sr; integer(c_int), value :: n
+    end function
+    integer(c_int) function pomgpu_sync(ctx) bind(C, name='pomgpu_sync')
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function pomgpu_check_velocity(ctx, vamax, imax, jmax) bind(C, name='pomgpu_check_velocity')
+      import; type(c_ptr), value :: ctx; real(c_double) :: vamax; integer(c_int) :: imax, jmax
+    end function
+    integer(c_int) function pomgpu_advq(ctx, qb, q, qf) bind(C, name='pomgpu_advq')
+      import; type(c_ptr), value :: ctx, qb, q, qf
+    end function
+    integer(c_int) function pomgpu_advt1(ctx, fb, f, fclim, ff) bind(C, name='pomgpu_advt1')
+      import; type(c_ptr), value :: ctx, fb, f, fclim, ff
+    end function
+    integer(c_int) function pomgpu_advt2(ctx, fb, f, fclim, ff) bind(C, name='pomgpu_advt2')
+      import; type(c_ptr), value :: ctx, fb, f, fclim, ff
+    end function
+    integer(c_int) function pomgpu_dens(ctx, si, ti, rhoo) bind(C, name='pomgpu_dens')
+      import; type(c_ptr), value :: ctx, si, ti, rhoo
+    end function
+    integer(c_int) function pomgpu_proft(ctx, f, wfsurf, fsurf, nbc) bind(C, name='pomgpu_proft')
+      import; type(c_ptr), value :: ctx, f, wfsurf, fsurf; integer(c_int), value :: nbc
+    end function
+    integer(c_int) function pomgpu_bcond(ctx, idx) bind(C, name='pomgpu_bcond')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: idx
+    end function
+    integer(c_int) function pomgpu_bcondorl(ctx, idx) bind(C, name='pomgpu_bcondorl')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: idx
+    end function
+  end interface
+  ! the argument-less entry points share one abstract shape
+  abstract interface
+    integer(c_int) function pomgpu_noarg(ctx) bind(C)
+      import; type(c_ptr), value :: ctx
+    end function
+  end interface
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_lateral_viscosity') :: pomgpu_lateral_viscosity
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_mode_interaction') :: pomgpu_mode_interaction
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_mode_external') :: pomgpu_mode_external
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_mode_internal') :: pomgpu_mode_internal
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_advave') :: pomgpu_advave
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_advct') :: pomgpu_advct
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_advu') :: pomgpu_advu
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_advv') :: pomgpu_advv
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_baropg') :: pomgpu_baropg
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_profq') :: pomgpu_profq
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_profu') :: pomgpu_profu
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_profv') :: pomgpu_profv
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_vertvl') :: pomgpu_vertvl
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_realvertvl') :: pomgpu_realvertvl
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_restore_interior') :: pomgpu_restore_interior
+end module pomgpu_iface
