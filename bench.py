@@ -216,6 +216,7 @@ def main():
                               "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
             "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
+            "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -20,15 +20,35 @@
 #define w_(i, j, k) F3(w, i, j, k)
 #define aam_(i, j, k) F3(aam, i, j, k)
 
-#define CELL3                                  \
-  const int i = TID_I, j = TID_J, k = TID_K;   \
-  if (i > P.iml || j > P.jml || k > P.kb) return;
-
+// Launch geometry of the cell kernels (1-D grid, decoded here; see gridm() for the encoding).
+// The plane is cut into BANDS of a few rows; bands are dealt round-robin to the 8 XCDs and every XCD
+// walks ALL levels of one band before it takes its next band.  A band is sized so that its slice of
+// every 2-D coefficient array plus the current levels of the 3-D operands fit the XCD's 4 MiB L2:
+// the coefficients are then fetched from HBM once per band instead of once per level, and the j+-1
+// rows of a stencil are L2 hits.  (A plain k-on-blockIdx.z launch re-streams every 2-D array and the
+// k+-1 planes once per level -- measured 2-4x the algorithmic traffic at 2048x1536; marching k inside
+// the thread serialises the loads of a column -- measured slower.)  Workgroups are observed to be
+// dispatched round-robin over the XCDs in linear-id order (MI355X_MICROARCH.md); the mapping only
+// relies on that for speed, never for correctness.
+#define MARCH3(call)                                                                  \
+  const int g_ = (int)(blockIdx.x * blockDim.x + threadIdx.x);   /* x-thread index; 64 per workgroup */ \
+  const int L_ = g_ >> 6, xcd_ = L_ & 7, m_ = L_ >> 3;                                \
+  const int bpl_ = P.g_bpl, nbx_ = P.g_nbx;                                           \
+  const int p_ = m_ % bpl_, t_ = m_ / bpl_;                                           \
+  const int k = t_ % P.kb + 1;                                                        \
+  const int band_ = (t_ / P.kb) * 8 + xcd_;                                           \
+  const int i = (p_ % nbx_) * 64 + (g_ & 63) + 1;                                     \
+  const int j = band_ * P.g_rb + (p_ / nbx_) * 4 + (int)threadIdx.y + 1;              \
+  if (i > P.iml || j > P.jml) return;                                                 \
+  call;
 // ---------------------------------------------------------------------------------------------
 // advct phase a: curv, and the fluxes of the x-momentum equation -- solver.f:213-277
 // scratch: s3[0]=curv  s3[1]=xflux  s3[2]=yflux
+__device__ __forceinline__ void c_advct_a(const KP &P, const int i, const int j, const int k);
 __global__ void k_advct_a(KP P) {
-  CELL3
+  MARCH3(c_advct_a(P, i, j, k))
+}
+__device__ __forceinline__ void c_advct_a(const KP &P, const int i, const int j, const int k) {
   if (i > P.im || j > P.jm) return;
   double cv = 0., xf = 0., yf = 0.;
   if (k <= P.kbm1) {
@@ -59,8 +79,11 @@ __global__ void k_advct_a(KP P) {
 
 // advct phase b: advx, and the fluxes of the y-momentum equation -- solver.f:282-367
 // scratch in: s3[0..2]; out: s3[3]=xflux' s3[4]=yflux'
+__device__ __forceinline__ void c_advct_b(const KP &P, const int i, const int j, const int k);
 __global__ void k_advct_b(KP P) {
-  CELL3
+  MARCH3(c_advct_b(P, i, j, k))
+}
+__device__ __forceinline__ void c_advct_b(const KP &P, const int i, const int j, const int k) {
   const double *cv = P.s3[0], *xf = P.s3[1], *yf = P.s3[2];
   double ax = 0., xg = 0., yg = 0.;
   if (k <= P.kbm1 && i <= P.im && j <= P.jm) {
@@ -96,8 +119,11 @@ __global__ void k_advct_b(KP P) {
 }
 
 // advct phase c: advy -- solver.f:372-403
+__device__ __forceinline__ void c_advct_c(const KP &P, const int i, const int j, const int k);
 __global__ void k_advct_c(KP P) {
-  CELL3
+  MARCH3(c_advct_c(P, i, j, k))
+}
+__device__ __forceinline__ void c_advct_c(const KP &P, const int i, const int j, const int k) {
   const double *cv = P.s3[0], *xg = P.s3[3], *yg = P.s3[4];
   double ay = 0.;
   if (k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
@@ -111,8 +137,11 @@ __global__ void k_advct_c(KP P) {
 }
 
 // Smagorinsky lateral viscosity -- advance.f:122-136
+__device__ __forceinline__ void c_aam(const KP &P, const int i, const int j, const int k);
 __global__ void k_aam(KP P) {
-  CELL3
+  MARCH3(c_aam(P, i, j, k))
+}
+__device__ __forceinline__ void c_aam(const KP &P, const int i, const int j, const int k) {
   if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
   F3(aam, i, j, k) =
       P.horcon * dx_(i, j) * dy_(i, j) *
@@ -123,8 +152,11 @@ __global__ void k_aam(KP P) {
 
 // rho = (rho-rmean)+rmean: the in-place round trip of baropg (solver.f:854,937) leaves rho changed
 // by a rounding, which later reads of rho (profq) see
+__device__ __forceinline__ void c_roundtrip(const KP &P, const int i, const int j, const int k, double *a, const double *b, int fix_kb);
 __global__ void k_roundtrip(KP P, double *a, const double *b, int fix_kb) {
-  CELL3
+  MARCH3(c_roundtrip(P, i, j, k, a, b, fix_kb))
+}
+__device__ __forceinline__ void c_roundtrip(const KP &P, const int i, const int j, const int k, double *a, const double *b, int fix_kb) {
   double x = G3(a, i, j, (fix_kb && k == P.kb) ? P.kbm1 : k);
   const double y = G3(b, i, j, k);
   x = x - y;
@@ -133,8 +165,11 @@ __global__ void k_roundtrip(KP P, double *a, const double *b, int fix_kb) {
 
 // ---------------------------------------------------------------------------------------------
 // advq -- solver.f:411-477.  Phase 1: fluxes (exchanged), phase 2: step.
+__device__ __forceinline__ void c_advq_flux(const KP &P, const int i, const int j, const int k, const double *q, const double *qb, double *xf, double *yf);
 __global__ void k_advq_flux(KP P, const double *q, const double *qb, double *xf, double *yf) {
-  CELL3
+  MARCH3(c_advq_flux(P, i, j, k, q, qb, xf, yf))
+}
+__device__ __forceinline__ void c_advq_flux(const KP &P, const int i, const int j, const int k, const double *q, const double *qb, double *xf, double *yf) {
   if (i > P.im || j > P.jm) return;
   double x = 0., y = 0.;
   if (k >= 2 && k <= P.kbm1 && i >= 2 && j >= 2) {
@@ -151,9 +186,14 @@ __global__ void k_advq_flux(KP P, const double *q, const double *qb, double *xf,
   G3(yf, i, j, k) = y;
 }
 // zero_else: the caller zero-filled qf beforehand in the reference (advance.f:403-404)
+__device__ __forceinline__ void c_advq_step(const KP &P, const int i, const int j, const int k, const double *q, const double *qb, double *qf, const double *xf, const double *yf,
+                            int zero_else);
 __global__ void k_advq_step(KP P, const double *q, const double *qb, double *qf, const double *xf, const double *yf,
                             int zero_else) {
-  CELL3
+  MARCH3(c_advq_step(P, i, j, k, q, qb, qf, xf, yf, zero_else))
+}
+__device__ __forceinline__ void c_advq_step(const KP &P, const int i, const int j, const int k, const double *q, const double *qb, double *qf, const double *xf, const double *yf,
+                            int zero_else) {
   if (k >= 2 && k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
     double r = (w_(i, j, k - 1) * G3(q, i, j, k - 1) - w_(i, j, k + 1) * G3(q, i, j, k + 1)) * F2(art, i, j) /
                    (F1(dz, k) + F1(dz, k - 1)) +
@@ -166,8 +206,11 @@ __global__ void k_advq_step(KP P, const double *q, const double *qb, double *qf,
 }
 
 // bcond(6) mask + Asselin filter + rotation of q2/q2l -- bounds_forcing.f:315-322, advance.f:416-421
+__device__ __forceinline__ void c_q_filter(const KP &P, const int i, const int j, const int k, int mask);
 __global__ void k_q_filter(KP P, int mask) {
-  CELL3
+  MARCH3(c_q_filter(P, i, j, k, mask))
+}
+__device__ __forceinline__ void c_q_filter(const KP &P, const int i, const int j, const int k, int mask) {
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
   if (mask && i <= P.im && j <= P.jm) {
     const double m = F2(fsm, i, j);
@@ -182,8 +225,11 @@ __global__ void k_q_filter(KP P, int mask) {
   F3(q2lb, i, j, k) = ql + .5 * P.smoth * (vf + F3(q2lb, i, j, k) - 2. * ql);
   F3(q2l, i, j, k) = vf;
 }
+__device__ __forceinline__ void c_mask_q(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_q(KP P) {   // the mask of bcond(6) alone
-  CELL3
+  MARCH3(c_mask_q(P, i, j, k))
+}
+__device__ __forceinline__ void c_mask_q(const KP &P, const int i, const int j, const int k) {
   if (i > P.im || j > P.jm) return;
   const double m = F2(fsm, i, j);
   F3(uf, i, j, k) = F3(uf, i, j, k) * m + 1.e-10;
@@ -206,8 +252,11 @@ __device__ __forceinline__ double advt1_yflux(const KP &P, const double *f, cons
               (dy_(i, j) + dy_(i, j - 1));
   return .5 * (dx_(i, j) + dx_(i, j - 1)) * y;
 }
+__device__ __forceinline__ void c_advt1(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fc, double *ff);
 __global__ void k_advt1(KP P, const double *fb, const double *f, const double *fc, double *ff) {
-  CELL3
+  MARCH3(c_advt1(P, i, j, k, fb, f, fc, ff))
+}
+__device__ __forceinline__ void c_advt1(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fc, double *ff) {
   if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
   const double art = F2(art, i, j);
   const double zu = (k == 1) ? G3(f, i, j, 1) * w_(i, j, 1) * art
@@ -228,8 +277,11 @@ __global__ void k_copy_kb(KP P, double *f) {
 // ---------------------------------------------------------------------------------------------
 // advt2 + smol_adif -- solver.f:577-731, :1880-1967  (general nitera path)
 // scratch: s3[0]=xmassflux s3[1]=ymassflux s3[2]=zwflux s3[3]=fbmem(itera>=2)
+__device__ __forceinline__ void c_advt2_mass(const KP &P, const int i, const int j, const int k);
 __global__ void k_advt2_mass(KP P) {
-  CELL3
+  MARCH3(c_advt2_mass(P, i, j, k))
+}
+__device__ __forceinline__ void c_advt2_mass(const KP &P, const int i, const int j, const int k) {
   if (i > P.im || j > P.jm) return;
   double xm = 0., ym = 0.;
   if (k <= P.kbm1) {
@@ -243,8 +295,11 @@ __global__ void k_advt2_mass(KP P) {
 __device__ __forceinline__ double upw(double m, double lo, double hi) {   // solver.f:631-635
   return 0.5 * ((m + fabs(m)) * lo + (m - fabs(m)) * hi);
 }
+__device__ __forceinline__ void c_advt2_step(const KP &P, const int i, const int j, const int k, const double *fbmem, const double *f, const double *eta, double *ff, int itera);
 __global__ void k_advt2_step(KP P, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
-  CELL3
+  MARCH3(c_advt2_step(P, i, j, k, fbmem, f, eta, ff, itera))
+}
+__device__ __forceinline__ void c_advt2_step(const KP &P, const int i, const int j, const int k, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
   if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
   const double *xm = P.s3[0], *ym = P.s3[1], *zw = P.s3[2];
   const double art = F2(art, i, j);
@@ -261,12 +316,18 @@ __global__ void k_advt2_step(KP P, const double *fbmem, const double *f, const d
   double r = xe - xw + yn - ys + (zu - zl) / F1(dz, k);
   G3(ff, i, j, k) = (fc * ((h_(i, j) + G2(eta, i, j)) * art) - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
 }
+__device__ __forceinline__ void c_mask3(const KP &P, const int i, const int j, const int k, double *a, const double *m2);
 __global__ void k_mask3(KP P, double *a, const double *m2) {   // a(:,:,k) = a(:,:,k)*m2 for k=1..kb
-  CELL3
+  MARCH3(c_mask3(P, i, j, k, a, m2))
+}
+__device__ __forceinline__ void c_mask3(const KP &P, const int i, const int j, const int k, double *a, const double *m2) {
   G3(a, i, j, k) = G3(a, i, j, k) * G2(m2, i, j);
 }
+__device__ __forceinline__ void c_smol(const KP &P, const int i, const int j, const int k, const double *ff);
 __global__ void k_smol(KP P, const double *ff) {
-  CELL3
+  MARCH3(c_smol(P, i, j, k, ff))
+}
+__device__ __forceinline__ void c_smol(const KP &P, const int i, const int j, const int k, const double *ff) {
   if (i > P.im || j > P.jm) return;
   const double value_min = 1.e-9, epsilon = 1.0e-14;
   double *xm = P.s3[0], *ym = P.s3[1], *zw = P.s3[2];
@@ -311,8 +372,11 @@ __global__ void k_smol(KP P, const double *ff) {
     G3(zw, i, j, k) = r;
   }
 }
+__device__ __forceinline__ void c_copy3(const KP &P, const int i, const int j, const int k, double *dst, const double *src);
 __global__ void k_copy3(KP P, double *dst, const double *src) {
-  CELL3
+  MARCH3(c_copy3(P, i, j, k, dst, src))
+}
+__device__ __forceinline__ void c_copy3(const KP &P, const int i, const int j, const int k, double *dst, const double *src) {
   G3(dst, i, j, k) = G3(src, i, j, k);
 }
 __device__ __forceinline__ double advt2_xdiff(const KP &P, const double *fb, const double *fc, int i, int j, int k) {
@@ -327,8 +391,11 @@ __device__ __forceinline__ double advt2_ydiff(const KP &P, const double *fb, con
          ((G3(fb, i, j, k) - G3(fc, i, j, k)) - (G3(fb, i, j - 1, k) - G3(fc, i, j - 1, k))) * F2(dvm, i, j) *
          (dx_(i, j) + dx_(i, j - 1)) * 0.5 / (dy_(i, j) + dy_(i, j - 1));
 }
+__device__ __forceinline__ void c_advt2_diff(const KP &P, const int i, const int j, const int k, const double *fb, const double *fc, double *ff);
 __global__ void k_advt2_diff(KP P, const double *fb, const double *fc, double *ff) {
-  CELL3
+  MARCH3(c_advt2_diff(P, i, j, k, fb, fc, ff))
+}
+__device__ __forceinline__ void c_advt2_diff(const KP &P, const int i, const int j, const int k, const double *fb, const double *fc, double *ff) {
   if (k > P.kbm1 || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
   G3(ff, i, j, k) = G3(ff, i, j, k) -
                     P.dti2 * (advt2_xdiff(P, fb, fc, i + 1, j, k) - advt2_xdiff(P, fb, fc, i, j, k) +
@@ -338,8 +405,11 @@ __global__ void k_advt2_diff(KP P, const double *fb, const double *fc, double *f
 // nitera == 1: the whole of advt2 in one pass.  Mass fluxes and upwind/diffusive face fluxes are
 // formed in registers from u, v, w, fb; the first (intermediate) halo exchange of ff and the
 // trailing smol_adif flux update are dead for nitera = 1 and only smol_adif's mask survives.
+__device__ __forceinline__ void c_advt2_fused(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fcl, double *ff);
 __global__ void k_advt2_fused(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
-  CELL3
+  MARCH3(c_advt2_fused(P, i, j, k, fb, f, fcl, ff))
+}
+__device__ __forceinline__ void c_advt2_fused(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fcl, double *ff) {
   if (!(k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1)) {
     G3(ff, i, j, k) = G3(ff, i, j, k) * F2(fsm, i, j);                                   // solver.f:1898-1900
     return;
@@ -373,8 +443,11 @@ __global__ void k_advt2_fused(KP P, const double *fb, const double *f, const dou
 
 // ---------------------------------------------------------------------------------------------
 // bcond(4) mask + Asselin filter + rotation of t/s -- bounds_forcing.f:233-240, advance.f:444-449
+__device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int j, const int k, int mask);
 __global__ void k_ts_filter(KP P, int mask) {
-  CELL3
+  MARCH3(c_ts_filter(P, i, j, k, mask))
+}
+__device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int j, const int k, int mask) {
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
   if (mask && k <= P.kbm1 && i <= P.im && j <= P.jm) {
     const double m = F2(fsm, i, j);
@@ -389,28 +462,40 @@ __global__ void k_ts_filter(KP P, int mask) {
   F3(sb, i, j, k) = s + .5 * P.smoth * (vf + F3(sb, i, j, k) - 2. * s);
   F3(s, i, j, k) = vf;
 }
+__device__ __forceinline__ void c_mask_ts(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_ts(KP P) {   // the mask of bcond(4) alone
-  CELL3
+  MARCH3(c_mask_ts(P, i, j, k))
+}
+__device__ __forceinline__ void c_mask_ts(const KP &P, const int i, const int j, const int k) {
   if (k > P.kbm1 || i > P.im || j > P.jm) return;
   const double m = F2(fsm, i, j);
   F3(uf, i, j, k) = F3(uf, i, j, k) * m;
   F3(vf, i, j, k) = F3(vf, i, j, k) * m;
 }
+__device__ __forceinline__ void c_mask_uv(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_uv(KP P) {   // the mask of bcondorl(3) alone
-  CELL3
+  MARCH3(c_mask_uv(P, i, j, k))
+}
+__device__ __forceinline__ void c_mask_uv(const KP &P, const int i, const int j, const int k) {
   if (k > P.kbm1 || i > P.im || j > P.jm) return;
   F3(uf, i, j, k) = F3(uf, i, j, k) * F2(dum, i, j);
   F3(vf, i, j, k) = F3(vf, i, j, k) * F2(dvm, i, j);
 }
+__device__ __forceinline__ void c_mask_w(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_w(KP P) {    // bcond(5) / bcondorl(5)
-  CELL3
+  MARCH3(c_mask_w(P, i, j, k))
+}
+__device__ __forceinline__ void c_mask_w(const KP &P, const int i, const int j, const int k) {
   if (k > P.kbm1 || i > P.im || j > P.jm) return;
   F3(w, i, j, k) = F3(w, i, j, k) * F2(fsm, i, j);
 }
 
 // restore_interior, device part -- bounds_forcing.f:1086-1120 (interpolate, relax, mask)
+__device__ __forceinline__ void c_restore(const KP &P, const int i, const int j, const int k, double fold, double fnew);
 __global__ void k_restore(KP P, double fold, double fnew) {
-  CELL3
+  MARCH3(c_restore(P, i, j, k, fold, fnew))
+}
+__device__ __forceinline__ void c_restore(const KP &P, const int i, const int j, const int k, double fold, double fnew) {
   if (k > P.kbm1) return;
   double t = F3(t, i, j, k), tb = F3(tb, i, j, k), s = F3(s, i, j, k), sb = F3(sb, i, j, k);
   if (i <= P.im && j <= P.jm) {
@@ -433,16 +518,22 @@ __global__ void k_restore(KP P, double fold, double fnew) {
   F3(sb, i, j, k) = sb * m;
 }
 // trstrb = trstrf etc. for k <= kbm1 (bounds_forcing.f:1056-1064)
+__device__ __forceinline__ void c_restore_shift(const KP &P, const int i, const int j, const int k);
 __global__ void k_restore_shift(KP P) {
-  CELL3
+  MARCH3(c_restore_shift(P, i, j, k))
+}
+__device__ __forceinline__ void c_restore_shift(const KP &P, const int i, const int j, const int k) {
   if (k > P.kbm1 || i > P.im || j > P.jm) return;
   F3(trstrb, i, j, k) = F3(trstrf, i, j, k);
   F3(srstrb, i, j, k) = F3(srstrf, i, j, k);
   F3(taurstrb, i, j, k) = F3(taurstrf, i, j, k);
 }
 // trstrf(1:im,1:jm,:) = tr ; srstrf = sr ; taurstrf = 1./trst (whole array)
+__device__ __forceinline__ void c_restore_load(const KP &P, const int i, const int j, const int k, const double *tr, const double *sr, double tau);
 __global__ void k_restore_load(KP P, const double *tr, const double *sr, double tau) {
-  CELL3
+  MARCH3(c_restore_load(P, i, j, k, tr, sr, tau))
+}
+__device__ __forceinline__ void c_restore_load(const KP &P, const int i, const int j, const int k, const double *tr, const double *sr, double tau) {
   F3(taurstrf, i, j, k) = tau;
   if (i > P.im || j > P.jm) return;
   const size_t n = ((size_t)(k - 1) * P.jm + (size_t)(j - 1)) * P.im + (size_t)(i - 1);   // (im,jm,kb) record
@@ -527,8 +618,11 @@ __device__ __forceinline__ double gpow15(double x) {
   const double sc = __builtin_bit_cast(double, sbits);
   return __builtin_fma(tm, sc, sc);
 }
+__device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, const int k, const double *si, const double *ti, double *rhoo);
 __global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
-  CELL3
+  MARCH3(c_dens(P, i, j, k, si, ti, rhoo))
+}
+__device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, const int k, const double *si, const double *ti, double *rhoo) {
   if (k > P.kbm1 || i > P.im || j > P.jm) return;
   const double tr = G3(ti, i, j, k) + P.tbias;
   const double sr = G3(si, i, j, k) + P.sbias;
@@ -545,8 +639,11 @@ __global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
 // ---------------------------------------------------------------------------------------------
 // realvertvl -- solver.f:2024-2067.  The zero-gradient edge copies (:2057-2060) become a clamped
 // source index; the mask (:2062-2064) is applied on store.
+__device__ __forceinline__ void c_realvertvl(const KP &P, const int i, const int j, const int k);
 __global__ void k_realvertvl(KP P) {
-  CELL3
+  MARCH3(c_realvertvl(P, i, j, k))
+}
+__device__ __forceinline__ void c_realvertvl(const KP &P, const int i, const int j, const int k) {
   double v = 0.;
   if (k <= P.kbm1 && i <= P.im && j <= P.jm) {
     const int a = (P.W && i == 1) ? 2 : ((P.E && i == P.im) ? P.imm1 : i);
@@ -577,44 +674,44 @@ __global__ void k_fill(double *p, size_t n, double v) {
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-void launch_advct_a(pomgpu_ctx *c) { LAUNCH(c, k_advct_a, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_advct_b(pomgpu_ctx *c) { LAUNCH(c, k_advct_b, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_advct_c(pomgpu_ctx *c) { LAUNCH(c, k_advct_c, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_aam(pomgpu_ctx *c) { LAUNCH(c, k_aam, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb) { LAUNCH(c, k_roundtrip, grid3(c->P, c->P.kb), blk2(), c->P, a, b, fix_kb); }
+void launch_advct_a(pomgpu_ctx *c) { LAUNCH(c, k_advct_a, gridm(c->P), blk2(), c->P); }
+void launch_advct_b(pomgpu_ctx *c) { LAUNCH(c, k_advct_b, gridm(c->P), blk2(), c->P); }
+void launch_advct_c(pomgpu_ctx *c) { LAUNCH(c, k_advct_c, gridm(c->P), blk2(), c->P); }
+void launch_aam(pomgpu_ctx *c) { LAUNCH(c, k_aam, gridm(c->P), blk2(), c->P); }
+void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb) { LAUNCH(c, k_roundtrip, gridm(c->P), blk2(), c->P, a, b, fix_kb); }
 void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf) {
-  LAUNCH(c, k_advq_flux, grid3(c->P, c->P.kb), blk2(), c->P, q, qb, xf, yf);
+  LAUNCH(c, k_advq_flux, gridm(c->P), blk2(), c->P, q, qb, xf, yf);
 }
 void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *xf, const double *yf, int zero_else) {
-  LAUNCH(c, k_advq_step, grid3(c->P, c->P.kb), blk2(), c->P, q, qb, qf, xf, yf, zero_else);
+  LAUNCH(c, k_advq_step, gridm(c->P), blk2(), c->P, q, qb, qf, xf, yf, zero_else);
 }
-void launch_q_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_q_filter, grid3(c->P, c->P.kb), blk2(), c->P, mask); }
-void launch_mask_q(pomgpu_ctx *c) { LAUNCH(c, k_mask_q, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_q_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_q_filter, gridm(c->P), blk2(), c->P, mask); }
+void launch_mask_q(pomgpu_ctx *c) { LAUNCH(c, k_mask_q, gridm(c->P), blk2(), c->P); }
 void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {
-  LAUNCH(c, k_advt1, grid3(c->P, c->P.kb), blk2(), c->P, (const double *)fb, (const double *)f, fclim, ff);
+  LAUNCH(c, k_advt1, gridm(c->P), blk2(), c->P, (const double *)fb, (const double *)f, fclim, ff);
   LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f);
 }
 void launch_copy_kb(pomgpu_ctx *c, double *f) { LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f); }
-void launch_advt2_mass(pomgpu_ctx *c) { LAUNCH(c, k_advt2_mass, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_advt2_mass(pomgpu_ctx *c) { LAUNCH(c, k_advt2_mass, gridm(c->P), blk2(), c->P); }
 void launch_advt2_step(pomgpu_ctx *c, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
-  LAUNCH(c, k_advt2_step, grid3(c->P, c->P.kb), blk2(), c->P, fbmem, f, eta, ff, itera);
+  LAUNCH(c, k_advt2_step, gridm(c->P), blk2(), c->P, fbmem, f, eta, ff, itera);
 }
-void launch_mask3(pomgpu_ctx *c, double *a, const double *m2) { LAUNCH(c, k_mask3, grid3(c->P, c->P.kb), blk2(), c->P, a, m2); }
-void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, grid3(c->P, c->P.kb), blk2(), c->P, ff); }
-void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, grid3(c->P, c->P.kb), blk2(), c->P, dst, src); }
-void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, grid3(c->P, c->P.kb), blk2(), c->P, fb, fc, ff); }
+void launch_mask3(pomgpu_ctx *c, double *a, const double *m2) { LAUNCH(c, k_mask3, gridm(c->P), blk2(), c->P, a, m2); }
+void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, gridm(c->P), blk2(), c->P, ff); }
+void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, gridm(c->P), blk2(), c->P, dst, src); }
+void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, gridm(c->P), blk2(), c->P, fb, fc, ff); }
 void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
-  LAUNCH(c, k_advt2_fused, grid3(c->P, c->P.kb), blk2(), c->P, fb, f, fc, ff);
+  LAUNCH(c, k_advt2_fused, gridm(c->P), blk2(), c->P, fb, f, fc, ff);
 }
-void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, grid3(c->P, c->P.kb), blk2(), c->P, mask); }
-void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_mask_w(pomgpu_ctx *c) { LAUNCH(c, k_mask_w, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_restore(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore, grid3(c->P, c->P.kb), blk2(), c->P, fold, fnew); }
-void launch_restore_shift(pomgpu_ctx *c) { LAUNCH(c, k_restore_shift, grid3(c->P, c->P.kb), blk2(), c->P); }
-void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau) { LAUNCH(c, k_restore_load, grid3(c->P, c->P.kb), blk2(), c->P, tr, sr, tau); }
-void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, grid3(c->P, c->P.kb), blk2(), c->P, si, ti, rhoo); }
-void launch_realvertvl(pomgpu_ctx *c) { LAUNCH(c, k_realvertvl, grid3(c->P, c->P.kb), blk2(), c->P); }
+void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, gridm(c->P), blk2(), c->P, mask); }
+void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, gridm(c->P), blk2(), c->P); }
+void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, gridm(c->P), blk2(), c->P); }
+void launch_mask_w(pomgpu_ctx *c) { LAUNCH(c, k_mask_w, gridm(c->P), blk2(), c->P); }
+void launch_restore(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore, gridm(c->P), blk2(), c->P, fold, fnew); }
+void launch_restore_shift(pomgpu_ctx *c) { LAUNCH(c, k_restore_shift, gridm(c->P), blk2(), c->P); }
+void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau) { LAUNCH(c, k_restore_load, gridm(c->P), blk2(), c->P, tr, sr, tau); }
+void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, gridm(c->P), blk2(), c->P, si, ti, rhoo); }
+void launch_realvertvl(pomgpu_ctx *c) { LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P); }
 void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;

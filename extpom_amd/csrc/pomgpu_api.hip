@@ -149,6 +149,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   P.iml = d->im_local; P.jml = d->jm_local;
   P.W = d->n_west == -1; P.E = d->n_east == -1; P.S = d->n_south == -1; P.N = d->n_north == -1;
   P.n2 = (size_t)P.iml * P.jml; P.n3 = P.n2 * P.kb;
+  set_band_geometry(P);
   size_t off = 0; int s = 0;
 #define BD_(name, shape) P.bdoff[s++] = off; off += BDN_##shape;
 #define BDN_J ((size_t)P.jml)
@@ -178,6 +179,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   alloc(&P.bd, nbd);
   for (int n = 0; n < POMGPU_NSCR3; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
+  for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
   alloc(&c->d_vel, 4);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
@@ -199,6 +201,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   (void)hipFree(P.b1); (void)hipFree(P.b2); (void)hipFree(P.b3); (void)hipFree(P.bd);
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
+  for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err);
   ProfState *ps = PS(c);
@@ -252,6 +255,7 @@ static int check_masks(pomgpu_ctx *c, const double *blk2d) {
   }
   return POMGPU_OK;
 }
+static void refresh_coefs(pomgpu_ctx *c);
 extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, const double *b3, const double *bd,
                              const pom_blkcon *con, int lramp) {
   if (!c) return POMGPU_EINVAL;
@@ -270,6 +274,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
     pomgpu_set_con(c, con, lramp);
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
   }
+  if (b2) refresh_coefs(c);
   return POMGPU_OK;
 }
 extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3, double *bd, pom_blkcon *con) {
@@ -287,11 +292,18 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
   if (con) return pomgpu_get_con(c, con);
   return POMGPU_OK;
 }
+// derived 2-D coefficient arrays follow the uploaded metrics / depths
+static void refresh_coefs(pomgpu_ctx *c) {
+  launch_coef_static(c);
+  launch_coef_dt(c);
+  launch_coef_eta(c);
+}
 #define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL
 extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  refresh_coefs(c);
   return POMGPU_OK;
 }
 extern "C" int pomgpu_upload_3d(pomgpu_ctx *c, int s, const double *h) {
@@ -419,7 +431,8 @@ static void seq_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim,
 static void seq_advt2(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {   // solver.f:577-731
   KP &P = c->P;
   if (P.nitera == 1) {
-    launch_advt2_fused(c, fb, f, fclim, ff);
+    launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
+    launch_advt2_rows(c, fb, f, fclim, ff);
   } else {
     launch_advt2_mass(c);
     const double *fbmem = fb, *eta = D2(c, etb);
@@ -557,6 +570,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
   }
   launch_int_tail(c);                                         // :525-531
+  launch_coef_dt(c);                                          // dt changed: refresh the derived coefficients
   launch_realvertvl(c);                                       // :534
   xch(c, 1, D3(c, wr), P.kbm1);                               // solver.f:2055
   return POMGPU_OK;

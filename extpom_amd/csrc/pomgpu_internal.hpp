@@ -7,10 +7,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "pom_layout.h"
 
 #define POMGPU_NSCR3 8     // 3-D scratch arrays (the reference's automatic arrays that survive fusion)
 #define POMGPU_NSCR2 8     // 2-D scratch arrays
+#define POMGPU_NCOEF2 16   // derived 2-D coefficient arrays
 #define POMGPU_MAXREC 8
 #define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
 
@@ -22,11 +24,13 @@ struct KP {
   double *b1, *b2, *b3, *bd; // device mirrors of blk1d, blk2d, blk3d, bdry
   double *s3[POMGPU_NSCR3];
   double *s2[POMGPU_NSCR2];
+  double *c2[POMGPU_NCOEF2]; // derived 2-D coefficient arrays (enum pomgpu_coef2), see k_tile.hip
   size_t bdoff[80];          // offset of every bdry member inside bd
   // blkcon scalars used on the hot path
   double alpha, dte, dti, dti2, dte2, grav, kappa, ramp, rfe, rfn, rfs, rfw, rhoref, sbias, small_,
          tbias, tprni, umol, horcon, ispi, isp2i, smoth, sw, time, vmaxl;
   int mode, ntp, nadv, nbct, nbcs, nitera, npg, isplit, iext, iint, iend;
+  int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
 };
@@ -53,6 +57,32 @@ enum pom_bdry_slot_dev {
 #define BDI(name, a, k) P.bd[P.bdoff[PB_##name] + (size_t)((k)-1) * P.iml + (size_t)((a)-1)]
 
 __device__ __forceinline__ double sq(double x) { return x * x; }
+
+// Derived 2-D coefficients: sums/products of grid metrics that every face-flux formula of the
+// reference evaluates as a unit (e.g. "(dy(i,j)+dy(i-1,j))", "0.25*(dy+dy)*(dt+dt)"), formed once
+// instead of once per level and per face.  *X live on the west face of cell (i,j), *Y on its south face.
+enum pomgpu_coef2 {
+  C2_HSX, C2_HSY,      // h(i,j)+h(i-1,j), h(i,j)+h(i,j-1)                    (static)
+  C2_DYSX, C2_DXSX,    // dy(i,j)+dy(i-1,j), dx(i,j)+dx(i-1,j)                (static)
+  C2_DXSY, C2_DYSY,    // dx(i,j)+dx(i,j-1), dy(i,j)+dy(i,j-1)                (static)
+  C2_CMX, C2_CMY,      // 0.25*DYSX*(dt(i,j)+dt(i-1,j)), 0.25*DXSY*(dt(i,j)+dt(i,j-1))   (follow dt)
+  C2_HEA, C2_HFA,      // (h+etb)*art, (h+etf)*art                            (follow etb, etf)
+  C2__count
+};
+#define K2(name, i, j) P.c2[C2_##name][IX2(i, j)]
+
+// Neighbour-lane access for stencils along i.  A wavefront owns 64 consecutive i of one row; the
+// value its western / eastern neighbour lane holds replaces a second global load of the same word.
+// The two edge lanes of the wavefront have no such neighbour and evaluate `fb` (a load or a
+// recomputation) instead.  Every lane of the wavefront must reach the call.
+template <class F> __device__ __forceinline__ double lane_w(double x, F fb) {
+  const double t = __shfl_up(x, 1, 64);
+  return (threadIdx.x == 0) ? fb() : t;
+}
+template <class F> __device__ __forceinline__ double lane_e(double x, F fb) {
+  const double t = __shfl_down(x, 1, 64);
+  return (threadIdx.x == blockDim.x - 1) ? fb() : t;
+}
 
 // thread -> (i,j[,k]) maps (1-based); blockDim.x runs along i
 #define TID_I (int)(blockIdx.x * blockDim.x + threadIdx.x + 1)
@@ -99,6 +129,26 @@ void pomgpu_prof_post(pomgpu_ctx *c, int slot);
 static inline dim3 blk2() { return dim3(64, 4, 1); }
 static inline dim3 grid2(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 3) / 4, 1); }
 static inline dim3 grid3(const KP &P, int nz) { return dim3((P.iml + 63) / 64, (P.jml + 3) / 4, nz); }
+// banded, XCD-aware cell launches (decoded by MARCH3 in k_adv.hip): 1-D grid, linear id
+// L = 8*m + xcd, m = ((q*kb + (k-1))*bpl + p), band = 8*q + xcd, p = block inside the band.
+// KP.g_rb rows per band, KP.g_nbx blocks along i, KP.g_bpl blocks per band and level.
+static inline dim3 gridm(const KP &P) {
+  const long nbands = (P.jml + P.g_rb - 1) / P.g_rb;
+  const long rounds = (nbands + 7) / 8;
+  return dim3((unsigned)(8 * rounds * P.kb * P.g_bpl), 1, 1);
+}
+static inline void set_band_geometry(KP &P) {
+  long budget = 3L << 20;                       // bytes of one XCD's L2 a band may occupy per level
+  const char *e = getenv("POMGPU_BAND_BYTES");
+  if (e && atol(e) >= 1024) budget = atol(e);
+  long rows = budget / ((long)P.iml * 8 * 24);  // ~24 arrays (2-D coefficients + 3-D operands) in flight
+  rows = (rows / 4) * 4;
+  if (rows < 4) rows = 4;
+  if (rows > ((P.jml + 3) / 4) * 4) rows = ((P.jml + 3) / 4) * 4;
+  P.g_rb = (int)rows;
+  P.g_nbx = (P.iml + 63) / 64;
+  P.g_bpl = P.g_nbx * (int)(rows / 4);
+}
 
 // kernel launchers implemented in the k_*.hip files (one per fused phase of the step)
 // k_ext.hip
@@ -154,6 +204,11 @@ void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_uv_filter(pomgpu_ctx *c);
+// k_tile.hip
+void launch_coef_static(pomgpu_ctx *c);
+void launch_coef_dt(pomgpu_ctx *c);
+void launch_coef_eta(pomgpu_ctx *c);
+void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
 // k_bc.hip
 void launch_bcond4_edges(pomgpu_ctx *c);
 void launch_bcond6_edges(pomgpu_ctx *c);

@@ -45,20 +45,25 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
+// Lanes along x are run as workgroups of width 1 (blockDim.x = 1, gridDim.x scaled): global indices
+// blockIdx.x*blockDim.x+threadIdx.x are unchanged, and every lane is both the first and the last
+// lane of its "wavefront", so the neighbour-lane helpers (lane_w / lane_e) always take their
+// edge-lane path and the value of the shuffle below is never used.
+static inline double __shfl_up(double x, unsigned, int) { return x; }
+static inline double __shfl_down(double x, unsigned, int) { return x; }
 template <typename K, typename... A>
 static inline void emu_launch(K kern, dim3 g, dim3 b, const A &...a) {
-  gridDim = g;
-  blockDim = b;
+  gridDim = dim3(g.x * b.x, g.y, g.z);
+  blockDim = dim3(1, b.y, b.z);
   for (unsigned bz = 0; bz < g.z; bz++)
     for (unsigned by = 0; by < g.y; by++)
-      for (unsigned bx = 0; bx < g.x; bx++) {
+      for (unsigned bx = 0; bx < g.x * b.x; bx++) {
         blockIdx = dim3(bx, by, bz);
         for (unsigned tz = 0; tz < b.z; tz++)
-          for (unsigned ty = 0; ty < b.y; ty++)
-            for (unsigned tx = 0; tx < b.x; tx++) {
-              threadIdx = dim3(tx, ty, tz);
-              kern(a...);
-            }
+          for (unsigned ty = 0; ty < b.y; ty++) {
+            threadIdx = dim3(0, ty, tz);
+            kern(a...);
+          }
       }
 }
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emu_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
