@@ -138,7 +138,13 @@ def main():
     case, im, jm, kb, desc = WORKLOADS[args.workload]
     tile = pdist.tile_for_rank(rank, world, im, jm)
     st = build_state(args.workload, tile)
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    stream = None
+    if world > 1:
+        # kernels and the exchange's pack/unpack must share ONE stream (torch's default stream has
+        # handle 0, which the C ABI reads as "create your own")
+        ts = torch.cuda.Stream()
+        torch.cuda.set_stream(ts)
+        stream = ts.cuda_stream
     g = gpu_initialise(st, local, stream)
     if world > 1:
         from extpom_amd.halo import Halo

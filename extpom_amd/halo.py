@@ -27,9 +27,12 @@ class _DevPtr:
 
 
 class Halo:
-    def __init__(self, tile, group=None):
+    def __init__(self, tile, group=None, staged=False):
+        """staged=True moves the packed edges through host memory (device tensors over a gloo group:
+        used by the 2-ranks-on-one-GPU test; RCCL needs one GPU per rank)."""
         self.t = tile
         self.group = group
+        self.staged = staged
         self.count = 0
 
     # ---- tensors --------------------------------------------------------------------------
@@ -46,6 +49,8 @@ class Halo:
             if nb < 0:
                 continue
             send = torch.cat([take(a, side).reshape(-1) for a in arrays]).contiguous()
+            if self.staged:
+                send = send.cpu()
             r = torch.empty_like(send)
             bufs.append(send)
             recv[side] = r
@@ -55,6 +60,8 @@ class Halo:
             return
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if self.staged:
+            recv = {side: r.to(arrays[0].device) for side, r in recv.items()}
         for side, r in recv.items():
             off = 0
             for a in arrays:

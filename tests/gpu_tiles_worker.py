@@ -1,0 +1,88 @@
+"""Launched by tests/test_gpu_multitile.py: 2 ranks, BOTH on GPU 0 (RCCL needs one GPU per rank, so
+the packed edges are staged through the host over gloo), each running the HIP path on its tile with
+the C-ABI exchange hook; rank 0 then compares against the single-tile CPU oracle."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from extpom_amd import decomp
+from extpom_amd.cases import finish_initial, make_case
+from extpom_amd.halo import Halo
+from extpom_amd.layout import BLK2D, BLK3D
+
+IM, JM, KB, STEPS = 97, 61, 16, 3
+SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
+
+
+def worker(rank, world, split, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from extpom_amd.model import PomGpu
+    nx, ny = (2, 1) if split == "x" else (1, 2)
+    iml, jml = decomp.local_size(IM, JM, nx, ny)
+    tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
+    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10)
+    # kernels and torch's pack/unpack must share ONE stream; torch's default stream has handle 0, which
+    # the C ABI reads as "create your own", so make a real stream current and hand that over
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    g = PomGpu(st, device=0, stream=ts.cuda_stream)
+    halo = Halo(tile, staged=True)
+    g.set_exchange(halo.gpu_hook(torch.device("cuda", 0)))
+
+    def dens(s, a, b, c):
+        g.upload(s); g.call("dens", a, b, c); g.download(s)
+
+    def baropg(s):
+        g.upload(s); g.call("baropg"); g.download(s)
+
+    finish_initial(st, dens, baropg)
+    g.upload(st)
+    g.run(STEPS)
+    g.download()
+    np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
+             n=halo.count, **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main(split):
+    import tempfile
+    from oracle.pyoracle import OracleTile, oracle_finish_initial
+    out = tempfile.mkdtemp()
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(worker, args=(2, split, port, out), nprocs=2, join=True)
+    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10)
+    oracle_finish_initial(g)
+    OracleTile(g).run(STEPS)
+    bad = []
+    for r in range(2):
+        z = np.load(os.path.join(out, f"tile{r}.npz"))
+        io, jo, im, jm = int(z["i_off"]), int(z["j_off"]), int(z["im"]), int(z["jm"])
+        assert int(z["n"]) > 100
+        sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)
+        sl_i = slice(0 if io == 0 else 1, im if io + im == IM else im - 1)
+        for n in BLK2D + BLK3D:
+            if n in SCRATCH:
+                continue
+            ref = g.field(n)[..., jo:jo + jm, io:io + im][..., sl_j, sl_i]
+            got = z[n][..., :jm, :im][..., sl_j, sl_i]
+            if not np.array_equal(ref, got):
+                bad.append((r, n, float(np.abs(ref - got).max())))
+    if bad:
+        print("MISMATCH", bad[:20])
+        sys.exit(1)
+    print("TILES-OK", split)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "x")

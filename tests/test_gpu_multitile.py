@@ -1,0 +1,19 @@
+"""The N>1 path on real hardware, as far as a 1-GPU box allows: 2 ranks share GPU 0, every
+exchange point of the step goes through the C-ABI hook and extpom_amd.halo (edges staged through
+the host over gloo, because RCCL wants one GPU per rank), and the owned cells of both tiles must
+equal the single-tile CPU oracle bit for bit -- in an x split and in a y split."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["x", "y"])
+def test_two_tiles_on_one_gpu_match_single_tile_oracle(split):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py"), split], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
