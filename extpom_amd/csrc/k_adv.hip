@@ -54,22 +54,19 @@ __device__ __forceinline__ void c_advct_a(const KP &P, const int i, const int j,
   if (k <= P.kbm1) {
     const bool iin = (i >= 2 && i <= P.imm1);
     if (iin && j >= 2 && j <= P.jmm1)
-      cv = .25 * ((v_(i, j + 1, k) + v_(i, j, k)) * (dy_(i + 1, j) - dy_(i - 1, j)) -
-                  (u_(i + 1, j, k) + u_(i, j, k)) * (dx_(i, j + 1) - dx_(i, j - 1))) / (dx_(i, j) * dy_(i, j));
-    if (iin)
-      xf = .125 * ((dt_(i + 1, j) + dt_(i, j)) * u_(i + 1, j, k) + (dt_(i, j) + dt_(i - 1, j)) * u_(i, j, k)) *
-           (u_(i + 1, j, k) + u_(i, j, k));
+      cv = .25 * ((v_(i, j + 1, k) + v_(i, j, k)) * K2(CVA, i, j) - (u_(i + 1, j, k) + u_(i, j, k)) * K2(CVB, i, j)) /
+           F2(art, i, j);                                          // art = dx*dy
+    if (iin)                                                       // DTSX(i+1,j) = dt(i+1,j)+dt(i,j)
+      xf = .125 * (K2(DTSX, i + 1, j) * u_(i + 1, j, k) + K2(DTSX, i, j) * u_(i, j, k)) * (u_(i + 1, j, k) + u_(i, j, k));
     if (i >= 2 && j >= 2)
-      yf = .125 * ((dt_(i, j) + dt_(i, j - 1)) * v_(i, j, k) + (dt_(i - 1, j) + dt_(i - 1, j - 1)) * v_(i - 1, j, k)) *
-           (u_(i, j, k) + u_(i, j - 1, k));
+      yf = .125 * (K2(DTSY, i, j) * v_(i, j, k) + K2(DTSY, i - 1, j) * v_(i - 1, j, k)) * (u_(i, j, k) + u_(i, j - 1, k));
     if (iin && j >= 2) {
       xf = xf - dt_(i, j) * aam_(i, j, k) * 2. * (ub_(i + 1, j, k) - ub_(i, j, k)) / dx_(i, j);
-      const double dtaam = .25 * (dt_(i, j) + dt_(i - 1, j) + dt_(i, j - 1) + dt_(i - 1, j - 1)) *
-                           (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
-      yf = yf - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) +
-                         (vb_(i, j, k) - vb_(i - 1, j, k)) / (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)));
+      const double dtaam = .25 * K2(DT4, i, j) * (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
+      const double dx4 = K2(DX4, i, j);
+      yf = yf - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / K2(DY4, i, j) + (vb_(i, j, k) - vb_(i - 1, j, k)) / dx4);
       xf = dy_(i, j) * xf;
-      yf = .25 * (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)) * yf;
+      yf = .25 * dx4 * yf;
     }
   }
   G3(P.s3[0], i, j, k) = cv;
@@ -95,18 +92,15 @@ __device__ __forceinline__ void c_advct_b(const KP &P, const int i, const int j,
                        G3(cv, i - 1, j, k) * dt_(i - 1, j) * (v_(i - 1, j + 1, k) + v_(i - 1, j, k)));
     }
     if (i >= 2 && j >= 2)
-      xg = .125 * ((dt_(i, j) + dt_(i - 1, j)) * u_(i, j, k) + (dt_(i, j - 1) + dt_(i - 1, j - 1)) * u_(i, j - 1, k)) *
-           (v_(i, j, k) + v_(i - 1, j, k));
-    if (j >= 2 && j <= P.jmm1) {
-      yg = .125 * ((dt_(i, j + 1) + dt_(i, j)) * v_(i, j + 1, k) + (dt_(i, j) + dt_(i, j - 1)) * v_(i, j, k)) *
-           (v_(i, j + 1, k) + v_(i, j, k));
+      xg = .125 * (K2(DTSX, i, j) * u_(i, j, k) + K2(DTSX, i, j - 1) * u_(i, j - 1, k)) * (v_(i, j, k) + v_(i - 1, j, k));
+    if (j >= 2 && j <= P.jmm1) {                                   // DTSY(i,j+1) = dt(i,j+1)+dt(i,j)
+      yg = .125 * (K2(DTSY, i, j + 1) * v_(i, j + 1, k) + K2(DTSY, i, j) * v_(i, j, k)) * (v_(i, j + 1, k) + v_(i, j, k));
       if (i >= 2) {
-        const double dtaam = .25 * (dt_(i, j) + dt_(i - 1, j) + dt_(i, j - 1) + dt_(i - 1, j - 1)) *
-                             (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
-        xg = xg - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) +
-                           (vb_(i, j, k) - vb_(i - 1, j, k)) / (dx_(i, j) + dx_(i - 1, j) + dx_(i, j - 1) + dx_(i - 1, j - 1)));
+        const double dtaam = .25 * K2(DT4, i, j) * (aam_(i, j, k) + aam_(i - 1, j, k) + aam_(i, j - 1, k) + aam_(i - 1, j - 1, k));
+        const double dy4 = K2(DY4, i, j);
+        xg = xg - dtaam * ((ub_(i, j, k) - ub_(i, j - 1, k)) / dy4 + (vb_(i, j, k) - vb_(i - 1, j, k)) / K2(DX4, i, j));
         yg = yg - dt_(i, j) * aam_(i, j, k) * 2. * (vb_(i, j + 1, k) - vb_(i, j, k)) / dy_(i, j);
-        xg = .25 * (dy_(i, j) + dy_(i - 1, j) + dy_(i, j - 1) + dy_(i - 1, j - 1)) * xg;
+        xg = .25 * dy4 * xg;
         yg = dx_(i, j) * yg;
       }
     }
@@ -462,6 +456,58 @@ __device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int 
   F3(sb, i, j, k) = s + .5 * P.smoth * (vf + F3(sb, i, j, k) - 2. * s);
   F3(s, i, j, k) = vf;
 }
+// mode_internal, tracer tail in ONE pass (nadv=2 path): the in-place round trips of advt2 on tb/sb
+// (solver.f:691,715), bcond(4)'s mask (bounds_forcing.f:233-240), the Asselin filter and rotation of
+// t,s (advance.f:444-449), restore_interior's interpolation, relaxation and mask
+// (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 10 writes per cell instead
+// of the 38 array passes of the five separate kernels.
+__device__ __forceinline__ double dens_point(const KP &P, double si, double ti, int i, int j, int k);
+__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt);
+__global__ void k_ts_update(KP P, double fold, double fnew, int rt) {
+  MARCH3(c_ts_update(P, i, j, k, fold, fnew, rt))
+}
+__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt) {
+  const bool act = (i <= P.im && j <= P.jm), lev = (k <= P.kbm1);
+  const double m = F2(fsm, i, j);
+  double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
+  if (lev && act) {                                                    // bcond(4) mask
+    uf = uf * m;
+    vf = vf * m;
+    F3(uf, i, j, k) = uf;
+    F3(vf, i, j, k) = vf;
+  }
+  double tb = F3(tb, i, j, k), sb = F3(sb, i, j, k);
+  if (rt) {                                                            // fb = fb-fclim ... fb = fb+fclim
+    const double tc = F3(tclim, i, j, k), sc = F3(sclim, i, j, k);
+    tb = (tb - tc) + tc;
+    sb = (sb - sc) + sc;
+  }
+  const double t0 = F3(t, i, j, k), s0 = F3(s, i, j, k);
+  double tbn = t0 + .5 * P.smoth * (uf + tb - 2. * t0);                // advance.f:444-449
+  double sbn = s0 + .5 * P.smoth * (vf + sb - 2. * s0);
+  double tn = uf, sn = vf;
+  if (lev) {
+    if (act) {                                                         // restore_interior
+      const double tr = fold * F3(trstrb, i, j, k) + fnew * F3(trstrf, i, j, k);
+      const double sr = fold * F3(srstrb, i, j, k) + fnew * F3(srstrf, i, j, k);
+      const double ta = fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
+      F3(trstr, i, j, k) = tr;
+      F3(srstr, i, j, k) = sr;
+      F3(taurstr, i, j, k) = ta;
+      const double c = 2. * P.dti / 86400.;
+      tn = tn + c * ta * (tr - tn);
+      tbn = tbn + c * ta * (tr - tbn);
+      sn = sn + c * ta * (sr - sn);
+      sbn = sbn + c * ta * (sr - sbn);
+    }
+    tn = tn * m; tbn = tbn * m; sn = sn * m; sbn = sbn * m;
+  }
+  F3(t, i, j, k) = tn;
+  F3(tb, i, j, k) = tbn;
+  F3(s, i, j, k) = sn;
+  F3(sb, i, j, k) = sbn;
+  if (lev && act) F3(rho, i, j, k) = dens_point(P, sn, tn, i, j, k);
+}
 __device__ __forceinline__ void c_mask_ts(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_ts(KP P) {   // the mask of bcond(4) alone
   MARCH3(c_mask_ts(P, i, j, k))
@@ -622,10 +668,9 @@ __device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, co
 __global__ void k_dens(KP P, const double *si, const double *ti, double *rhoo) {
   MARCH3(c_dens(P, i, j, k, si, ti, rhoo))
 }
-__device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, const int k, const double *si, const double *ti, double *rhoo) {
-  if (k > P.kbm1 || i > P.im || j > P.jm) return;
-  const double tr = G3(ti, i, j, k) + P.tbias;
-  const double sr = G3(si, i, j, k) + P.sbias;
+__device__ __forceinline__ double dens_point(const KP &P, double si, double ti, int i, int j, int k) {
+  const double tr = ti + P.tbias;
+  const double sr = si + P.sbias;
   const double tr2 = tr * tr, tr3 = tr2 * tr, tr4 = tr3 * tr;
   const double p = P.grav * P.rhoref * (-F1(zz, k) * h_(i, j)) * 1.e-5;
   double rhor = -0.157406 + 6.793952e-2 * tr - 9.095290e-3 * tr2 + 1.001685e-4 * tr3 - 1.120083e-6 * tr4 + 6.536332e-9 * tr4 * tr;
@@ -633,7 +678,11 @@ __device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, co
          (-5.72466e-3 + 1.0227e-4 * tr - 1.6546e-6 * tr2) * gpow15(fabs(sr)) + 4.8314e-4 * sr * sr;
   const double cr = 1449.1 + .0821 * p + 4.55 * tr - .045 * tr2 + 1.34 * (sr - 35.);
   rhor = rhor + 1.e5 * p / (cr * cr) * (1. - 2. * p / (cr * cr));
-  G3(rhoo, i, j, k) = rhor / P.rhoref * F2(fsm, i, j);
+  return rhor / P.rhoref * F2(fsm, i, j);
+}
+__device__ __forceinline__ void c_dens(const KP &P, const int i, const int j, const int k, const double *si, const double *ti, double *rhoo) {
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  G3(rhoo, i, j, k) = dens_point(P, G3(si, i, j, k), G3(ti, i, j, k), i, j, k);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -652,10 +701,10 @@ __device__ __forceinline__ void c_realvertvl(const KP &P, const int i, const int
       const double zzk = F1(zz, k);
 #define TPS(ii, jj) (zzk * dt_(ii, jj) + F2(et, ii, jj))
       const double tc = TPS(a, b);
-      const double dxr = 2.0 / (dx_(a + 1, b) + dx_(a, b));
-      const double dxl = 2.0 / (dx_(a, b) + dx_(a - 1, b));
-      const double dyt = 2.0 / (dy_(a, b + 1) + dy_(a, b));
-      const double dyb = 2.0 / (dy_(a, b) + dy_(a, b - 1));
+      const double dxr = K2(R2DXSX, a + 1, b);    // 2.0/(dx(i+1,j)+dx(i,j))
+      const double dxl = K2(R2DXSX, a, b);        // 2.0/(dx(i,j)+dx(i-1,j))
+      const double dyt = K2(R2DYSY, a, b + 1);    // 2.0/(dy(i,j+1)+dy(i,j))
+      const double dyb = K2(R2DYSY, a, b);        // 2.0/(dy(i,j)+dy(i,j-1))
       v = 0.5 * (w_(a, b, k) + w_(a, b, k + 1)) +
           0.5 * (u_(a + 1, b, k) * (TPS(a + 1, b) - tc) * dxr + u_(a, b, k) * (tc - TPS(a - 1, b)) * dxl +
                  v_(a, b + 1, k) * (TPS(a, b + 1) - tc) * dyt + v_(a, b, k) * (tc - TPS(a, b - 1)) * dyb) +
@@ -703,6 +752,7 @@ void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double
 void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   LAUNCH(c, k_advt2_fused, gridm(c->P), blk2(), c->P, fb, f, fc, ff);
 }
+void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt) { LAUNCH(c, k_ts_update, gridm(c->P), blk2(), c->P, fold, fnew, rt); }
 void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, gridm(c->P), blk2(), c->P, mask); }
 void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, gridm(c->P), blk2(), c->P); }
 void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, gridm(c->P), blk2(), c->P); }

@@ -27,6 +27,13 @@ __global__ void k_coef_static(KP P) {
   K2(DXSX, i, j) = F2(dx, i, j) + F2(dx, iw, j);
   K2(DXSY, i, j) = F2(dx, i, j) + F2(dx, i, js);
   K2(DYSY, i, j) = F2(dy, i, j) + F2(dy, i, js);
+  K2(DX4, i, j) = F2(dx, i, j) + F2(dx, iw, j) + F2(dx, i, js) + F2(dx, iw, js);
+  K2(DY4, i, j) = F2(dy, i, j) + F2(dy, iw, j) + F2(dy, i, js) + F2(dy, iw, js);
+  const int ie = i < P.iml ? i + 1 : P.iml, jn = j < P.jml ? j + 1 : P.jml;
+  K2(CVA, i, j) = F2(dy, ie, j) - F2(dy, iw, j);
+  K2(CVB, i, j) = F2(dx, i, jn) - F2(dx, i, js);
+  K2(R2DXSX, i, j) = 2.0 / (F2(dx, i, j) + F2(dx, iw, j));
+  K2(R2DYSY, i, j) = 2.0 / (F2(dy, i, j) + F2(dy, i, js));
 }
 __global__ void k_coef_dt(KP P) {
   const int i = TID_I, j = TID_J;
@@ -34,6 +41,9 @@ __global__ void k_coef_dt(KP P) {
   const int iw = i > 1 ? i - 1 : 1, js = j > 1 ? j - 1 : 1;
   K2(CMX, i, j) = 0.25 * (F2(dy, iw, j) + F2(dy, i, j)) * (F2(dt, iw, j) + F2(dt, i, j));
   K2(CMY, i, j) = 0.25 * (F2(dx, i, js) + F2(dx, i, j)) * (F2(dt, i, js) + F2(dt, i, j));
+  K2(DTSX, i, j) = F2(dt, i, j) + F2(dt, iw, j);
+  K2(DTSY, i, j) = F2(dt, i, j) + F2(dt, i, js);
+  K2(DT4, i, j) = F2(dt, i, j) + F2(dt, iw, j) + F2(dt, i, js) + F2(dt, iw, js);
 }
 __global__ void k_coef_eta(KP P) {
   const int i = TID_I, j = TID_J;
@@ -243,6 +253,97 @@ __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const
   if (icol) G3(ff, i, j, P.kb) = G3(ff, i, j, P.kb) * fsm;                                    // :1899, level kb
 }
 
+// ---- advq, flux + step fused (single tile) -- solver.f:411-477 -----------------------------------------
+// Same structure as k_advt2_col: column-resident face coefficients, software-pipelined level loop,
+// neighbour-lane operands.  The reference exchanges xflux/yflux between the flux and the step
+// loops (:458-459); with all neighbours -1 that exchange is a no-op and the two halves fuse: the
+// fluxes never reach memory.  Used only when the context has no exchange hook (one tile).
+struct LevQ {
+  double q_c, q_s, q_n, qb_c, qb_s, qb_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c;
+  double q_w, qb_w, am_w;         // lane 0 only
+  double q_e, qb_e, am_e, u_e;    // last lane only
+};
+__device__ __forceinline__ LevQ advq_load(const KP &P, const double *q, const double *qb, int iw, int i, int ie, int js, int j, int jn,
+                                          int k) {
+  LevQ L;
+  L.q_c = G3(q, i, j, k);    L.q_s = G3(q, i, js, k);    L.q_n = G3(q, i, jn, k);
+  L.qb_c = G3(qb, i, j, k);  L.qb_s = G3(qb, i, js, k);  L.qb_n = G3(qb, i, jn, k);
+  L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
+  L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
+  L.w_c = F3(w, i, j, k);
+  L.q_w = L.qb_w = L.am_w = L.q_e = L.qb_e = L.am_e = L.u_e = 0.;
+  if (threadIdx.x == 0) { L.q_w = G3(q, iw, j, k); L.qb_w = G3(qb, iw, j, k); L.am_w = F3(aam, iw, j, k); }
+  if (threadIdx.x == blockDim.x - 1) {
+    L.q_e = G3(q, ie, j, k); L.qb_e = G3(qb, ie, j, k); L.am_e = F3(aam, ie, j, k); L.u_e = F3(u, ie, j, k);
+  }
+  return L;
+}
+struct CoefQ { double dts, hs, msk, ds_den, ds_num; };
+__device__ __forceinline__ CoefQ coefq_x(const KP &P, int i, int j) {
+  CoefQ c; c.dts = K2(DTSX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.ds_den = K2(DXSX, i, j); c.ds_num = K2(DYSX, i, j); return c;
+}
+__device__ __forceinline__ CoefQ coefq_y(const KP &P, int i, int j) {
+  CoefQ c; c.dts = K2(DTSY, i, j); c.hs = K2(HSY, i, j); c.msk = F2(dvm, i, j); c.ds_den = K2(DYSY, i, j); c.ds_num = K2(DXSY, i, j); return c;
+}
+// flux through the face between a "lo" (west/south) and a "hi" cell at w-level k (:428-453)
+__device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double q_lo, double vel_k, double vel_km1, double am_hi_k,
+                                            double am_lo_k, double am_hi_m, double am_lo_m, double qb_hi, double qb_lo) {
+  double x = .125 * (q_hi + q_lo) * c.dts * (vel_k + vel_km1);
+  x = x - .25 * (am_hi_k + am_lo_k + am_hi_m + am_lo_m) * c.hs * (qb_hi - qb_lo) * c.msk / c.ds_den;
+  return .5 * c.ds_num * x;
+}
+__global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const double *qb, double *qf, int zero_else) {
+  const int i0 = TID_I, j0 = TID_J;
+  if (j0 > P.jml) return;
+  const bool icol = (i0 <= P.iml);
+  const int i = icol ? i0 : P.iml, j = j0;
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
+  const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  const bool last = (threadIdx.x == blockDim.x - 1);
+  const CoefQ cw = coefq_x(P, i, j), cs = coefq_y(P, i, j), cn = coefq_y(P, i, jn);
+  CoefQ ce = cw;
+  if (last) ce = coefq_x(P, ie, j);
+  const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
+  const int kb = P.kb, kbm1 = P.kbm1;
+  LevQ cur = advq_load(P, q, qb, iw, i, ie, js, j, jn, 1), nxt = cur, prv = cur;
+  double am_w_prv = 0.;                       // aam(i-1,j,L-1) as seen by this lane
+  double wq_pp = 0., wq_p = 0.;               // w*q of levels L-2 and L-1
+  double xe_p = 0., xw_p = 0., yn_p = 0., ys_p = 0., qb_p = 0.;   // faces and qb of level L-1, waiting for w(L)*q(L)
+  for (int L = 1; L <= kb; L++) {
+    if (L + 1 <= kb) nxt = advq_load(P, q, qb, iw, i, ie, js, j, jn, L + 1);
+    const double am_w = lane_w(cur.am_c, [&] { return cur.am_w; });
+    double xe_c = 0., xw_c = 0., yn_c = 0., ys_c = 0.;
+    if (L >= 2 && L <= kbm1) {
+      const double q_w = lane_w(cur.q_c, [&] { return cur.q_w; });
+      const double qb_w = lane_w(cur.qb_c, [&] { return cur.qb_w; });
+      const double xw = advq_face(cw, cur.q_c, q_w, cur.u_c, prv.u_c, cur.am_c, am_w, prv.am_c, am_w_prv, cur.qb_c, qb_w);
+      double xl = 0.;
+      if (last) xl = advq_face(ce, cur.q_e, cur.q_c, cur.u_e, prv.u_e, cur.am_e, cur.am_c, prv.am_e, prv.am_c, cur.qb_e, cur.qb_c);
+      xw_c = xw;
+      xe_c = lane_e(xw, [&] { return xl; });
+      ys_c = advq_face(cs, cur.q_c, cur.q_s, cur.v_c, prv.v_c, cur.am_c, cur.am_s, prv.am_c, prv.am_s, cur.qb_c, cur.qb_s);
+      yn_c = advq_face(cn, cur.q_n, cur.q_c, cur.v_n, prv.v_n, cur.am_n, cur.am_c, prv.am_n, prv.am_c, cur.qb_n, cur.qb_c);
+    }
+    const double wq_c = cur.w_c * cur.q_c;
+    if (icol) {
+      const int k = L - 1;                                   // level completed in this iteration
+      if (in && k >= 2 && k <= kbm1) {
+        double r = (wq_pp - wq_c) * art / (F1(dz, k) + F1(dz, k - 1)) + xe_p - xw_p + yn_p - ys_p;   // :465-468
+        r = (hea * qb_p - P.dti2 * r) / hfa;                                                    // :469-471
+        G3(qf, i, j, k) = r;
+      } else if (zero_else && k >= 1) {
+        G3(qf, i, j, k) = 0.;
+      }
+    }
+    wq_pp = wq_p; wq_p = wq_c; qb_p = cur.qb_c;
+    xe_p = xe_c; xw_p = xw_c; yn_p = yn_c; ys_p = ys_c;
+    am_w_prv = am_w;
+    prv = cur; cur = nxt;
+  }
+  if (icol && zero_else) G3(qf, i, j, kb) = 0.;
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 void launch_coef_static(pomgpu_ctx *c) { LAUNCH(c, k_coef_static, grid2(c->P), blk2(), c->P); }
 void launch_coef_dt(pomgpu_ctx *c) { LAUNCH(c, k_coef_dt, grid2(c->P), blk2(), c->P); }
@@ -256,6 +357,9 @@ static dim3 grid_rows(const KP &P) {
   const long band_rows = strips * ROWS_PER_STRIP;
   const int nbands = (int)((P.jml + band_rows - 1) / band_rows);
   return dim3((P.iml + 63) / 64, (unsigned)(strips / 4), (unsigned)(nbands * P.kb));
+}
+void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
+  LAUNCH(c, k_advq_col, grid2(c->P), blk2(), c->P, q, qb, qf, zero_else);
 }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);

@@ -407,6 +407,7 @@ static void seq_baropg(pomgpu_ctx *c) {                       // solver.f:848-94
 }
 static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair, int zero_else) {   // solver.f:411-477
   KP &P = c->P;
+  if (!c->exch) { launch_coef_eta(c); launch_advq_col(c, q, qb, qf, zero_else); return; }
   double *xf = P.s3[pair ? 2 : 0], *yf = P.s3[pair ? 3 : 1];
   launch_advq_flux(c, q, qb, xf, yf);
   xch(c, 2, xf, P.kbm1, yf, P.kbm1);                          // :458-459
@@ -428,7 +429,7 @@ static void seq_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim,
   launch_advt1(c, fb, f, fclim, ff);
   seq_fb_fix(c, fb, fclim);
 }
-static void seq_advt2(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {   // solver.f:577-731
+static void seq_advt2(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff, bool defer_roundtrip = false) {   // solver.f:577-731
   KP &P = c->P;
   if (P.nitera == 1) {
     launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
@@ -448,7 +449,29 @@ static void seq_advt2(pomgpu_ctx *c, double *fb, double *f, const double *fclim,
     launch_advt2_diff(c, fb, fclim, ff);                      // :691-726
   }
   xch(c, 1, ff, P.kbm1);                                      // :728
-  seq_fb_fix(c, fb, fclim);
+  if (defer_roundtrip) launch_copy_kb(c, fb);                 // :618; the round trip :691,:715 rides in k_ts_update
+  else seq_fb_fix(c, fb, fclim);
+}
+// host half of restore_interior: record reads/shifts; returns the interpolation weights
+static int restore_prepare(pomgpu_ctx *c, double *fold_out, double *fnew_out) {   // bounds_forcing.f:1034-1087
+  const pom_blkcon &k = c->con;
+  const double trst = 30.;
+  const int irst = (int)(trst * 86400. / k.dti);
+  const int ntime = (int)(k.time / trst);
+  auto load = [&](int n) -> int {
+    if (n < 1 || n > POMGPU_MAXREC || !c->rec_t[n])
+      return fail(c, POMGPU_EINVAL, "restore_interior: record %d was not supplied (pomgpu_set_restore_record)", n);
+    launch_restore_load(c, c->rec_t[n], c->rec_s[n], 1. / trst);
+    return POMGPU_OK;
+  };
+  if (k.iint == 2) { int rc = load((k.iint / irst) + 1); if (rc) return rc; }
+  if (k.iint == 2 || (irst > 0 && k.iint % irst == 0)) {
+    launch_restore_shift(c);
+    if (k.iint != k.iend) { int rc = load((k.iint + irst) / irst + 1); if (rc) return rc; }
+  }
+  *fnew_out = k.time / trst - ntime;
+  *fold_out = 1. - *fnew_out;
+  return POMGPU_OK;
 }
 static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.f:1023-1121
   KP &P = c->P;
@@ -530,7 +553,11 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     launch_vertvl(c, 1);                                      // :396-398
     xch(c, 1, D3(c, w), P.kb);                                // :400
     // :403-409 (uf = vf = 0 is folded into the advq step kernels)
-    {
+    launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
+    if (!c->exch) {                                           // one tile: flux and step halves fuse (no exchange between them)
+      launch_advq_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), 1);
+      launch_advq_col(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);
+    } else {
       double *x0 = P.s3[0], *y0 = P.s3[1], *x1 = P.s3[2], *y1 = P.s3[3];
       launch_advq_flux(c, D3(c, q2), D3(c, q2b), x0, y0);
       launch_advq_flux(c, D3(c, q2l), D3(c, q2lb), x1, y1);
@@ -547,8 +574,8 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
         seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
       } else if (k.nadv == 2) {
-        seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
-        seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
+        seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), true);
+        seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf), true);
       } else {
         return fail(c, POMGPU_EINVAL, "Error: invalid value for nadv");
       }
@@ -556,10 +583,10 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       launch_proft(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct);   // :439-440
       launch_proft(c, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs);
       launch_bcond4_edges(c);                                 // :442
-      launch_ts_filter(c, 1);                                 // :444-449
-      int rc = seq_restore_interior(c);                       // :452
+      double fold, fnew;
+      int rc = restore_prepare(c, &fold, &fnew);              // :452 (record handling)
       if (rc) return rc;
-      launch_dens(c, D3(c, s), D3(c, t), D3(c, rho));         // :454
+      launch_ts_update(c, fold, fnew, k.nadv == 2);           // :444-454 in one pass
     }
     launch_advu_profu(c, 1, 1);                               // :459-462
     launch_advv_profv(c, 1, 1);

@@ -12,7 +12,7 @@
 
 #define POMGPU_NSCR3 8     // 3-D scratch arrays (the reference's automatic arrays that survive fusion)
 #define POMGPU_NSCR2 8     // 2-D scratch arrays
-#define POMGPU_NCOEF2 16   // derived 2-D coefficient arrays
+#define POMGPU_NCOEF2 24   // derived 2-D coefficient arrays
 #define POMGPU_MAXREC 8
 #define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
 
@@ -67,8 +67,14 @@ enum pomgpu_coef2 {
   C2_DXSY, C2_DYSY,    // dx(i,j)+dx(i,j-1), dy(i,j)+dy(i,j-1)                (static)
   C2_CMX, C2_CMY,      // 0.25*DYSX*(dt(i,j)+dt(i-1,j)), 0.25*DXSY*(dt(i,j)+dt(i,j-1))   (follow dt)
   C2_HEA, C2_HFA,      // (h+etb)*art, (h+etf)*art                            (follow etb, etf)
+  C2_DTSX, C2_DTSY,    // dt(i,j)+dt(i-1,j), dt(i,j)+dt(i,j-1)                (follow dt)
+  C2_DT4,              // dt(i,j)+dt(i-1,j)+dt(i,j-1)+dt(i-1,j-1)             (follow dt)
+  C2_DX4, C2_DY4,      // the same four-point sums of dx and dy               (static)
+  C2_CVA, C2_CVB,      // dy(i+1,j)-dy(i-1,j), dx(i,j+1)-dx(i,j-1)            (static; curvature terms)
+  C2_R2DXSX, C2_R2DYSY,// 2.0/DXSX, 2.0/DYSY                                  (static; realvertvl's dxl/dyb)
   C2__count
 };
+static_assert(C2__count <= POMGPU_NCOEF2, "raise POMGPU_NCOEF2");
 #define K2(name, i, j) P.c2[C2_##name][IX2(i, j)]
 
 // Neighbour-lane access for stencils along i.  A wavefront owns 64 consecutive i of one row; the
@@ -184,6 +190,7 @@ void launch_copy3(pomgpu_ctx *c, double *dst, const double *src);
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff);
 void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
 void launch_ts_filter(pomgpu_ctx *c, int mask);
+void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt);
 void launch_mask_ts(pomgpu_ctx *c);
 void launch_mask_uv(pomgpu_ctx *c);
 void launch_mask_w(pomgpu_ctx *c);
@@ -209,6 +216,7 @@ void launch_coef_static(pomgpu_ctx *c);
 void launch_coef_dt(pomgpu_ctx *c);
 void launch_coef_eta(pomgpu_ctx *c);
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
+void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else);
 // k_bc.hip
 void launch_bcond4_edges(pomgpu_ctx *c);
 void launch_bcond6_edges(pomgpu_ctx *c);
