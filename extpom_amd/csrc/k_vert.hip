@@ -355,68 +355,84 @@ __global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsu
 __global__ void k_advu_profu(KP P, int do_adv, int do_prof) {
   COL2
   if (i > P.im || j > P.jm) return;
-  double rhs[POMGPU_KBMAX], ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
+  double ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
   const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
   const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  if (do_adv) {
-    if (i >= 2) {
-      // vertical advective flux at w-levels (:744-751); 0 at k=1 and k=kb
-      double fk = 0.;
-      double hc = 0., step_a = 0., step_d = 0., aru = 0.;
-      if (in) {
-        aru = F2(aru, i, j);
-        hc = P.grav * .125 * (dt_(i, j) + dt_(i - 1, j)) *
-             (F2(egf, i, j) - F2(egf, i - 1, j) + F2(egb, i, j) - F2(egb, i - 1, j) + (F2(e_atmos, i, j) - F2(e_atmos, i - 1, j)) * 2.) *
-             (dy_(i, j) + dy_(i - 1, j));
-        step_a = (h_(i, j) + F2(etb, i, j) + h_(i - 1, j) + F2(etb, i - 1, j)) * aru;
-        step_d = (h_(i, j) + F2(etf, i, j) + h_(i - 1, j) + F2(etf, i - 1, j)) * aru;
-      }
-      for (int k = 1; k <= kbm1; k++) {
-        const double fn = (k + 1 <= kbm1) ? .25 * (w_(i, j, k + 1) + w_(i - 1, j, k + 1)) * (u_(i, j, k + 1) + u_(i, j, k)) : 0.;
-        if (in) {
-          double r = F3(advx, i, j, k) + (fk - fn) * aru / F1(dz, k) -
-                     aru * .25 * (F2(cor, i, j) * dt_(i, j) * (v_(i, j + 1, k) + v_(i, j, k)) +
-                                  F2(cor, i - 1, j) * dt_(i - 1, j) * (v_(i - 1, j + 1, k) + v_(i - 1, j, k))) +
-                     hc + F3(drhox, i, j, k);                                              // :758-769
-          rhs[k - 1] = (step_a * F3(ub, i, j, k) - 2. * P.dti2 * r) / step_d;              // :778-782
-        } else {
-          rhs[k - 1] = fk;
-        }
-        fk = fn;
-      }
-      rhs[kb - 1] = 0.;
-    } else {
-      for (int k = 1; k <= kb; k++) rhs[k - 1] = 0.;
-    }
-    if (!do_prof || !in) {
-      for (int k = 1; k <= kb; k++) F3(uf, i, j, k) = rhs[k - 1];
-      return;
+  // ---- columns outside the interior: the reference leaves the vertical-flux values of advu there
+  if (!in) {
+    if (!do_adv) return;
+    double fk = 0.;
+    F3(uf, i, j, 1) = 0.;
+    for (int k = 2; k <= kbm1; k++) {
+      fk = (i >= 2) ? .25 * (w_(i, j, k) + w_(i - 1, j, k)) * (u_(i, j, k) + u_(i, j, k - 1)) : 0.;   // :744-751
+      F3(uf, i, j, k) = fk;
     }
     F3(uf, i, j, kb) = 0.;
-  } else {
-    if (!in) return;
-    for (int k = 1; k <= kbm1; k++) rhs[k - 1] = F3(uf, i, j, k);
+    return;
   }
-  // profu on an interior column
+  // ---- interior column
+  const double ar = F2(aru, i, j);
+  const double hc = P.grav * .125 * (dt_(i, j) + dt_(i - 1, j)) *
+                    (F2(egf, i, j) - F2(egf, i - 1, j) + F2(egb, i, j) - F2(egb, i - 1, j) + (F2(e_atmos, i, j) - F2(e_atmos, i - 1, j)) * 2.) *
+                    (dy_(i, j) + dy_(i - 1, j));
+  const double step_a = (h_(i, j) + F2(etb, i, j) + h_(i - 1, j) + F2(etb, i - 1, j)) * ar;
+  const double step_d = (h_(i, j) + F2(etf, i, j) + h_(i - 1, j) + F2(etf, i - 1, j)) * ar;
+  // right-hand side of level k = the leapfrog step of advu (:758-782); fk/fn: vertical flux at levels k, k+1
+#define RHS(k, fk, fn)                                                                                   \
+  ((step_a * F3(ub, i, j, k) -                                                                            \
+    2. * P.dti2 * (F3(advx, i, j, k) + ((fk) - (fn)) * ar / F1(dz, k) -                                   \
+                   ar * .25 * (F2(cor, i, j) * dt_(i, j) * (v_(i, j + 1, k) + v_(i, j, k)) +                   \
+                               F2(cor, i - 1, j) * dt_(i - 1, j) * (v_(i - 1, j + 1, k) + v_(i - 1, j, k))) + \
+                   hc + F3(drhox, i, j, k))) /                                                            \
+   step_d)
+#define VFLUX(k) (.25 * (w_(i, j, k) + w_(i - 1, j, k)) * (u_(i, j, k) + u_(i, j, (k)-1)))
+  if (do_adv && !do_prof) {                                // advu alone
+    double fk = 0.;
+    for (int k = 1; k <= kbm1; k++) {
+      const double fn = (k + 1 <= kbm1) ? VFLUX(k + 1) : 0.;
+      F3(uf, i, j, k) = RHS(k, fk, fn);
+      fk = fn;
+    }
+    F3(uf, i, j, kb) = 0.;
+    return;
+  }
+  // profu: forward sweep; with do_adv the right-hand side is formed on the fly and never stored
   const double dh = (h_(i, j) + F2(etf, i, j) + h_(i - 1, j) + F2(etf, i - 1, j)) * .5;
-#define KMU(k) ((F3(km, i, j, k) + F3(km, i - 1, j, k)) * .5)
-#define ACO(k) (((k) <= kbm2) ? -P.dti2 * (KMU((k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
-#define CCO(k) (-P.dti2 * (KMU(k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
-  const double a1 = ACO(1);
-  ee[0] = a1 / (a1 - 1.);
-  gg[0] = (-P.dti2 * F2(wusurf, i, j) / (-F1(dz, 1) * dh) - rhs[0]) / (a1 - 1.);
-  for (int k = 2; k <= kbm2; k++) {
-    const double a = ACO(k), c = CCO(k);
-    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
-    ee[k - 1] = a * g;
-    gg[k - 1] = (c * gg[k - 2] - rhs[k - 1]) * g;
+#define KMA(k) ((F3(km, i, j, k) + F3(km, i - 1, j, k)) * .5)
+  double fk = 0.;
+  double km_c = KMA(1), km_n = KMA(2);                      // averaged km at levels k and k+1
+  double rhs_k = 0., g_prev = 0., e_prev = 0.;
+  for (int k = 1; k <= kbm1; k++) {
+    if (do_adv) {
+      const double fn = (k + 1 <= kbm1) ? VFLUX(k + 1) : 0.;
+      rhs_k = RHS(k, fk, fn);
+      fk = fn;
+    } else {
+      rhs_k = F3(uf, i, j, k);
+    }
+    // a(k) = -dti2*(c(k+1)+umol)/(dz(k)*dzz(k)*dh*dh), c(k) = -dti2*(c(k)+umol)/(dz(k)*dzz(k-1)*dh*dh)   (:1712-1729)
+    const double a = (k <= kbm2) ? -P.dti2 * (km_n + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.;
+    if (k == 1) {
+      e_prev = a / (a - 1.);
+      g_prev = (-P.dti2 * F2(wusurf, i, j) / (-F1(dz, 1) * dh) - rhs_k) / (a - 1.);
+      ee[0] = e_prev; gg[0] = g_prev;
+    } else if (k <= kbm2) {
+      const double c = -P.dti2 * (km_c + P.umol) / (F1(dz, k) * F1(dzz, k - 1) * dh * dh);
+      const double g = 1. / (a + c * (1. - e_prev) - 1.);
+      e_prev = a * g;
+      g_prev = (c * g_prev - rhs_k) * g;
+      ee[k - 1] = e_prev; gg[k - 1] = g_prev;
+    }
+    km_c = km_n;
+    if (k + 2 <= kb) km_n = KMA(k + 2);
   }
+  // here km_c = averaged km at kb, the loop's last c-level was kbm1: recompute c(kbm1) from KMA(kbm1)
   const double tps = 0.5 * (F2(cbc, i, j) + F2(cbc, i - 1, j)) *
                      sqrt(sq(F3(ub, i, j, kbm1)) +
                           sq(.25 * (F3(vb, i, j, kbm1) + F3(vb, i, j + 1, kbm1) + F3(vb, i - 1, j, kbm1) + F3(vb, i - 1, j + 1, kbm1))));
-  const double c = CCO(kbm1);
+  const double c = -P.dti2 * (KMA(kbm1) + P.umol) / (F1(dz, kbm1) * F1(dzz, kbm2) * dh * dh);
   const double m = F2(dum, i, j);
-  double x = (c * gg[kbm2 - 1] - rhs[kbm1 - 1]) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
+  double x = (c * gg[kbm2 - 1] - rhs_k) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
   x = x * m;
   F3(uf, i, j, kbm1) = x;
   F2(wubot, i, j) = -tps * x;
@@ -424,76 +440,95 @@ __global__ void k_advu_profu(KP P, int do_adv, int do_prof) {
     x = (ee[ki - 1] * x + gg[ki - 1]) * m;
     F3(uf, i, j, ki) = x;
   }
+  if (do_adv) F3(uf, i, j, kb) = 0.;
   F2(tps, i, j) = tps;
-#undef KMU
-#undef ACO
-#undef CCO
+#undef RHS
+#undef VFLUX
+#undef KMA
 }
 
 // advv + profv -- solver.f:791-845, :1783-1877
 __global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
   COL2
   if (i > P.im || j > P.jm) return;
-  double rhs[POMGPU_KBMAX], ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
+  double ee[POMGPU_KBMAX], gg[POMGPU_KBMAX];
   const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
   const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  if (do_adv) {
-    if (j >= 2) {
-      double fk = 0.;
-      double hc = 0., step_a = 0., step_d = 0., arv = 0.;
-      if (in) {
-        arv = F2(arv, i, j);
-        hc = P.grav * .125 * (dt_(i, j) + dt_(i, j - 1)) *
-             (F2(egf, i, j) - F2(egf, i, j - 1) + F2(egb, i, j) - F2(egb, i, j - 1) + (F2(e_atmos, i, j) - F2(e_atmos, i, j - 1)) * 2.) *
-             (dx_(i, j) + dx_(i, j - 1));
-        step_a = (h_(i, j) + F2(etb, i, j) + h_(i, j - 1) + F2(etb, i, j - 1)) * arv;
-        step_d = (h_(i, j) + F2(etf, i, j) + h_(i, j - 1) + F2(etf, i, j - 1)) * arv;
-      }
-      for (int k = 1; k <= kbm1; k++) {
-        const double fn = (k + 1 <= kbm1) ? .25 * (w_(i, j, k + 1) + w_(i, j - 1, k + 1)) * (v_(i, j, k + 1) + v_(i, j, k)) : 0.;
-        if (in) {
-          double r = F3(advy, i, j, k) + (fk - fn) * arv / F1(dz, k) +
-                     arv * .25 * (F2(cor, i, j) * dt_(i, j) * (u_(i + 1, j, k) + u_(i, j, k)) +
-                                  F2(cor, i, j - 1) * dt_(i, j - 1) * (u_(i + 1, j - 1, k) + u_(i, j - 1, k))) +
-                     hc + F3(drhoy, i, j, k);                                              // :815-826
-          rhs[k - 1] = (step_a * F3(vb, i, j, k) - 2. * P.dti2 * r) / step_d;              // :835-839
-        } else {
-          rhs[k - 1] = fk;
-        }
-        fk = fn;
-      }
-      rhs[kb - 1] = 0.;
-    } else {
-      for (int k = 1; k <= kb; k++) rhs[k - 1] = 0.;
-    }
-    if (!do_prof || !in) {
-      for (int k = 1; k <= kb; k++) F3(vf, i, j, k) = rhs[k - 1];
-      return;
+  // ---- columns outside the interior: the reference leaves the vertical-flux values of advv there
+  if (!in) {
+    if (!do_adv) return;
+    double fk = 0.;
+    F3(vf, i, j, 1) = 0.;
+    for (int k = 2; k <= kbm1; k++) {
+      fk = (j >= 2) ? .25 * (w_(i, j, k) + w_(i, j - 1, k)) * (v_(i, j, k) + v_(i, j, k - 1)) : 0.;   // :801-808
+      F3(vf, i, j, k) = fk;
     }
     F3(vf, i, j, kb) = 0.;
-  } else {
-    if (!in) return;
-    for (int k = 1; k <= kbm1; k++) rhs[k - 1] = F3(vf, i, j, k);
+    return;
   }
+  // ---- interior column
+  const double ar = F2(arv, i, j);
+  const double hc = P.grav * .125 * (dt_(i, j) + dt_(i, j - 1)) *
+                    (F2(egf, i, j) - F2(egf, i, j - 1) + F2(egb, i, j) - F2(egb, i, j - 1) + (F2(e_atmos, i, j) - F2(e_atmos, i, j - 1)) * 2.) *
+                    (dx_(i, j) + dx_(i, j - 1));
+  const double step_a = (h_(i, j) + F2(etb, i, j) + h_(i, j - 1) + F2(etb, i, j - 1)) * ar;
+  const double step_d = (h_(i, j) + F2(etf, i, j) + h_(i, j - 1) + F2(etf, i, j - 1)) * ar;
+  // right-hand side of level k = the leapfrog step of advv (:815-839); fk/fn: vertical flux at levels k, k+1
+#define RHS(k, fk, fn)                                                                                   \
+  ((step_a * F3(vb, i, j, k) -                                                                            \
+    2. * P.dti2 * (F3(advy, i, j, k) + ((fk) - (fn)) * ar / F1(dz, k) +                                   \
+                   ar * .25 * (F2(cor, i, j) * dt_(i, j) * (u_(i + 1, j, k) + u_(i, j, k)) +                   \
+                               F2(cor, i, j - 1) * dt_(i, j - 1) * (u_(i + 1, j - 1, k) + u_(i, j - 1, k))) + \
+                   hc + F3(drhoy, i, j, k))) /                                                            \
+   step_d)
+#define VFLUX(k) (.25 * (w_(i, j, k) + w_(i, j - 1, k)) * (v_(i, j, k) + v_(i, j, (k)-1)))
+  if (do_adv && !do_prof) {                                // advv alone
+    double fk = 0.;
+    for (int k = 1; k <= kbm1; k++) {
+      const double fn = (k + 1 <= kbm1) ? VFLUX(k + 1) : 0.;
+      F3(vf, i, j, k) = RHS(k, fk, fn);
+      fk = fn;
+    }
+    F3(vf, i, j, kb) = 0.;
+    return;
+  }
+  // profv: forward sweep; with do_adv the right-hand side is formed on the fly and never stored
   const double dh = .5 * (h_(i, j) + F2(etf, i, j) + h_(i, j - 1) + F2(etf, i, j - 1));
-#define KMV(k) ((F3(km, i, j, k) + F3(km, i, j - 1, k)) * .5)
-#define ACO(k) (((k) <= kbm2) ? -P.dti2 * (KMV((k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
-#define CCO(k) (-P.dti2 * (KMV(k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
-  const double a1 = ACO(1);
-  ee[0] = a1 / (a1 - 1.);
-  gg[0] = (-P.dti2 * F2(wvsurf, i, j) / (-F1(dz, 1) * dh) - rhs[0]) / (a1 - 1.);
-  for (int k = 2; k <= kbm2; k++) {
-    const double a = ACO(k), c = CCO(k);
-    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
-    ee[k - 1] = a * g;
-    gg[k - 1] = (c * gg[k - 2] - rhs[k - 1]) * g;
+#define KMA(k) ((F3(km, i, j, k) + F3(km, i, j - 1, k)) * .5)
+  double fk = 0.;
+  double km_c = KMA(1), km_n = KMA(2);                      // averaged km at levels k and k+1
+  double rhs_k = 0., g_prev = 0., e_prev = 0.;
+  for (int k = 1; k <= kbm1; k++) {
+    if (do_adv) {
+      const double fn = (k + 1 <= kbm1) ? VFLUX(k + 1) : 0.;
+      rhs_k = RHS(k, fk, fn);
+      fk = fn;
+    } else {
+      rhs_k = F3(vf, i, j, k);
+    }
+    // a(k) = -dti2*(c(k+1)+umol)/(dz(k)*dzz(k)*dh*dh), c(k) = -dti2*(c(k)+umol)/(dz(k)*dzz(k-1)*dh*dh)   (:1810-1827)
+    const double a = (k <= kbm2) ? -P.dti2 * (km_n + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.;
+    if (k == 1) {
+      e_prev = a / (a - 1.);
+      g_prev = (-P.dti2 * F2(wvsurf, i, j) / (-F1(dz, 1) * dh) - rhs_k) / (a - 1.);
+      ee[0] = e_prev; gg[0] = g_prev;
+    } else if (k <= kbm2) {
+      const double c = -P.dti2 * (km_c + P.umol) / (F1(dz, k) * F1(dzz, k - 1) * dh * dh);
+      const double g = 1. / (a + c * (1. - e_prev) - 1.);
+      e_prev = a * g;
+      g_prev = (c * g_prev - rhs_k) * g;
+      ee[k - 1] = e_prev; gg[k - 1] = g_prev;
+    }
+    km_c = km_n;
+    if (k + 2 <= kb) km_n = KMA(k + 2);
   }
+  // here km_c = averaged km at kb, the loop's last c-level was kbm1: recompute c(kbm1) from KMA(kbm1)
   const double tps = 0.5 * (F2(cbc, i, j) + F2(cbc, i, j - 1)) *
                      sqrt(sq(.25 * (F3(ub, i, j, kbm1) + F3(ub, i + 1, j, kbm1) + F3(ub, i, j - 1, kbm1) + F3(ub, i + 1, j - 1, kbm1))) +
                           sq(F3(vb, i, j, kbm1)));
-  const double c = CCO(kbm1);
+  const double c = -P.dti2 * (KMA(kbm1) + P.umol) / (F1(dz, kbm1) * F1(dzz, kbm2) * dh * dh);
   const double m = F2(dvm, i, j);
-  double x = (c * gg[kbm2 - 1] - rhs[kbm1 - 1]) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
+  double x = (c * gg[kbm2 - 1] - rhs_k) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (ee[kbm2 - 1] - 1.) * c);
   x = x * m;
   F3(vf, i, j, kbm1) = x;
   F2(wvbot, i, j) = -tps * x;
@@ -501,10 +536,11 @@ __global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
     x = (ee[ki - 1] * x + gg[ki - 1]) * m;
     F3(vf, i, j, ki) = x;
   }
+  if (do_adv) F3(vf, i, j, kb) = 0.;
   F2(tps, i, j) = tps;
-#undef KMV
-#undef ACO
-#undef CCO
+#undef RHS
+#undef VFLUX
+#undef KMA
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 import csv, glob, os, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")) + glob.glob(os.path.join(root, "pmc_*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in acc.values() for c in k})

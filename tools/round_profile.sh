@@ -1,0 +1,16 @@
+#!/bin/bash
+# round-end measurement on a GPU box: tests, bench lines, rocprofv3 kernel stats and HBM-traffic counters
+# (separate --pmc passes, never mixed with trace domains other than --kernel-trace)
+TAG=${1:-r1}
+export TMPDIR=/tmp
+O=gpurun_out/$TAG; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -2 $O/gputests.log
+python bench.py > $O/bench_basin2048.json 2> $O/bench_basin2048.err; tail -c 600 $O/bench_basin2048.json; echo
+python bench.py --workload seamount256 --steps 20 > $O/bench_seamount256.json 2>/dev/null
+python bench.py --workload basin1024 --steps 5 > $O/bench_basin1024.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
+for set in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$set -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$set.log 2>&1
+done
+python3 tools/pmc_summarise.py $O > $O/pmc_summary.csv 2>&1 || true
+ls $O
