@@ -152,93 +152,27 @@ __global__ void k_profq_prod(KP P) {
     ccm = cck;
   }
 }
-// (3) everything else: length scale, stability, two Thomas solves, new km/kh/kq
+// (3) everything else: length scale, stability, two Thomas solves, new km/kh/kq.
+//     ONE forward walk over the column does everything that is local to a level -- |q2b|, |q2lb|,
+//     length scale, gh -> sm/sh, dtef, the new km/kh/kq -- and advances BOTH forward eliminations
+//     (q2 and q2l share a, c and prod); one backward walk finishes uf and vf.  Every operand is read
+//     once and every result written once; only the four elimination vectors ee1,gg1,ee2,gg2 are
+//     private per-thread arrays.  (The first cut re-read l three times and dtef twice and kept gh
+//     and two generations of ee/gg: 53 GB of HBM traffic per launch at 2048x1536x50 against 26 GB
+//     algorithmic, rocprofv3 FETCH_SIZE/WRITE_SIZE.)
 __global__ void k_profq(KP P) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
   const double *prod = P.s3[0];
-  double ee[POMGPU_KBMAX], gg[POMGPU_KBMAX], gh[POMGPU_KBMAX];
+  double ee1[POMGPU_KBMAX], gg1[POMGPU_KBMAX], ee2[POMGPU_KBMAX], gg2[POMGPU_KBMAX];
   const int kb = P.kb, kbm1 = P.kbm1;
   const double dh = h_(i, j) + F2(etf, i, j);
   const double utau2 = G2(P.s2[4], i, j);
   const double l0 = surfl * utau2 / P.grav;                                                 // :1299
   const double umol2 = 2. * P.umol;
-  // buoyancy gradient, length scale, gh -- :1322-1356
-  double ccm = profq_cc(P, i, j, 1);
-  gh[0] = 0.;
-  gh[kb - 1] = 0.;
-  F3(l, i, j, 1) = P.kappa * l0;
-  F3(l, i, j, kb) = 0.;
-  for (int k = 2; k <= kbm1; k++) {
-    const double cck = profq_cc(P, i, j, k);
-    const double q2b = fabs(F3(q2b, i, j, k)), q2lb = fabs(F3(q2lb, i, j, k));
-    F3(q2b, i, j, k) = q2b;
-    F3(q2lb, i, j, k) = q2lb;
-    const double bg = profq_boygr(P, i, j, k, ccm, cck);
-    double l = fabs(q2lb / q2b);
-    if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
-    F3(l, i, j, k) = l;
-    gh[k - 1] = fmin(sq(l) * bg / q2b, .028);
-    ccm = cck;
-  }
-  // dtef (stf = 1) -- :1380-1392
-  for (int k = 1; k <= kb; k++)
-    F3(dtef, i, j, k) = sqrt(fabs(F3(q2b, i, j, k))) * 1. / (b1 * F3(l, i, j, k) + P.small_);
-  // q2 solve -- :1258-1267 (a, c), :1296-1297, :1394-1413
-  ee[0] = 0.;
-  gg[0] = P.cb_profq * utau2;
-  {
-    double kqm = F3(kq, i, j, 1), kqc = F3(kq, i, j, 2);
-    for (int k = 2; k <= kbm1; k++) {
-      const double kqp = F3(kq, i, j, k + 1);
-      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);
-      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
-      double g = 1. / (a + c * (1. - ee[k - 2]) - (2. * P.dti2 * F3(dtef, i, j, k) + 1.));
-      ee[k - 1] = a * g;
-      gg[k - 1] = (-2. * P.dti2 * G3(prod, i, j, k) + c * gg[k - 2] - F3(uf, i, j, k)) * g;
-      kqm = kqc; kqc = kqp;
-    }
-  }
-  {
-    double x = F3(uf, i, j, kb);
-    for (int ki = kbm1; ki >= 1; ki--) {
-      x = ee[ki - 1] * x + gg[ki - 1];
-      F3(uf, i, j, ki) = (ki >= 2) ? fabs(x) : x;                                           // :1467
-    }
-  }
-  // q2l solve -- :1417-1455
-  F3(vf, i, j, 1) = 0.;
-  F3(vf, i, j, kb) = 0.;
-  ee[1] = 0.;
-  gg[1] = -P.kappa * F1(z, 2) * dh * F3(q2, i, j, 2);
-  const double vbot = P.kappa * (1 + F1(z, kbm1)) * dh * F3(q2, i, j, kbm1);
-  for (int k = 2; k <= kbm1; k++) {
-    const double zk = F1(z, k);
-    F3(dtef, i, j, k) = F3(dtef, i, j, k) *
-                        (1. + e2 * sq((1. / fabs(zk - F1(z, 1)) + 1. / fabs(zk - F1(z, kb))) * F3(l, i, j, k) / (dh * P.kappa)));
-  }
-  {
-    double kqm = F3(kq, i, j, 2), kqc = F3(kq, i, j, 3 <= kb ? 3 : kb);
-    for (int k = 3; k <= kbm1; k++) {
-      const double kqp = F3(kq, i, j, k + 1);
-      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);
-      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
-      const double rhs = (k == kbm1) ? vbot : F3(vf, i, j, k);
-      double g = 1. / (a + c * (1. - ee[k - 2]) - (P.dti2 * F3(dtef, i, j, k) + 1.));
-      ee[k - 1] = a * g;
-      gg[k - 1] = (P.dti2 * (-G3(prod, i, j, k) * F3(l, i, j, k) * e1) + c * gg[k - 2] - rhs) * g;
-      kqm = kqc; kqc = kqp;
-    }
-  }
-  {
-    double x = 0.;   // vf(kb)
-    for (int ki = kbm1; ki >= 2; ki--) {
-      x = ee[ki - 1] * x + gg[ki - 1];
-      F3(vf, i, j, ki) = fabs(x);                                                           // :1468
-    }
-  }
-  // stability functions and new mixing coefficients -- :1474-1506, cosmetics+mask :1510-1535
+  const double z1 = F1(z, 1), zkb = F1(z, kb);
+  // stability-function constants (stf = 1) -- :1474-1483
   const double coef4 = 18. * a1 * a1 + 9. * a1 * a2, coef5 = 9. * a1 * a2;
   const double coef1 = a2 * (1. - 6. * a1 / b1 * 1.), coef2 = 3. * a2 * b2 / 1. + 18. * a1 * a2,
                coef3 = a1 * (1. - 3. * c1 - 6. * a1 / b1 * 1.);
@@ -247,24 +181,77 @@ __global__ void k_profq(KP P) {
   const bool repl = (P.W && i == 1) || (P.E && i == P.im) || (P.S && j == 1) || (P.N && j == P.jm);
   const int ti = (P.W && i == 2) ? 1 : ((P.E && i == P.imm1) ? P.im : 0);
   const int tj = (P.S && j == 2) ? 1 : ((P.N && j == P.jmm1) ? P.jm : 0);
+  const double fsm_c = F2(fsm, i, j);
+  // boundary values of the two solves -- :1296-1297, :1417-1425
+  const double vbot = P.kappa * (1 + F1(z, kbm1)) * dh * F3(q2, i, j, kbm1);
+  const double ufbot = F3(uf, i, j, kb);
+  ee1[0] = 0.;
+  gg1[0] = P.cb_profq * utau2;
+  double e1p = 0., g1p = gg1[0];          // ee1, gg1 of level k-1
+  double e2p = 0., g2p = 0.;              // ee2, gg2 of level k-1
+  double ccm = 0., rhom = 0.;             // sound speed and density of level k-1
+  double kqm = 0., kqc = F3(kq, i, j, 1), kqp = F3(kq, i, j, 2);   // OLD kq at k-1, k, k+1
   for (int k = 1; k <= kb; k++) {
-    const double g = gh[k - 1];
-    const double sh = coef1 / (1. - coef2 * g);
-    double sm = coef3 + sh * coef4 * g;
-    sm = sm / (1. - coef5 * g);
-    const double pl = F3(l, i, j, k) * sqrt(fabs(F3(q2, i, j, k)));
-    if (repl) continue;
-    const double kq = (pl * .41 * sh + F3(kq, i, j, k)) * .5;
-    const double km = (pl * sm + F3(km, i, j, k)) * .5;
-    const double kh = (pl * sh + F3(kh, i, j, k)) * .5;
-    // own cell: in place.  Physical-edge cells that copy this column are written to the staging
-    // arrays s3[1..3] (their own threads are still reading the old kq) and moved by k_profq_rim.
-    {
-      const double m = F2(fsm, i, j);
-      F3(kq, i, j, k) = kq * m;
-      F3(km, i, j, k) = km * m;
-      F3(kh, i, j, k) = kh * m;
+    const bool mid = (k >= 2 && k <= kbm1);
+    // ---- level-local quantities
+    double cck = 0., rhok = 0.;
+    if (k <= kbm1) { cck = profq_cc(P, i, j, k); rhok = F3(rho, i, j, k); }
+    double q2b = F3(q2b, i, j, k);
+    double l, gh = 0.;
+    if (mid) {
+      q2b = fabs(q2b);                                                                      // :1325-1326
+      const double q2lb = fabs(F3(q2lb, i, j, k));
+      F3(q2b, i, j, k) = q2b;
+      F3(q2lb, i, j, k) = q2lb;
+      const double bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * h_(i, j)) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
+      l = fabs(q2lb / q2b);                                                                 // :1338-1344
+      if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
+      gh = fmin(sq(l) * bg / q2b, .028);
+    } else {
+      l = (k == 1) ? P.kappa * l0 : 0.;                                                     // :1351-1354
     }
+    F3(l, i, j, k) = l;
+    const double dtef1 = sqrt(fabs(q2b)) * 1. / (b1 * l + P.small_);                        // :1388-1389
+    double dtef2 = dtef1;
+    if (mid) dtef2 = dtef1 * (1. + e2 * sq((1. / fabs(F1(z, k) - z1) + 1. / fabs(F1(z, k) - zkb)) * l / (dh * P.kappa)));   // :1429-1432
+    F3(dtef, i, j, k) = dtef2;
+    // ---- both forward eliminations -- :1394-1404, :1436-1446
+    if (mid) {
+      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);      // :1261-1264
+      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
+      const double pr = G3(prod, i, j, k);
+      const double g = 1. / (a + c * (1. - e1p) - (2. * P.dti2 * dtef1 + 1.));
+      e1p = a * g;
+      g1p = (-2. * P.dti2 * pr + c * g1p - F3(uf, i, j, k)) * g;
+      ee1[k - 1] = e1p;
+      gg1[k - 1] = g1p;
+      if (k == 2) {
+        e2p = 0.;
+        g2p = -P.kappa * F1(z, 2) * dh * F3(q2, i, j, 2);
+      } else {
+        const double rhs = (k == kbm1) ? vbot : F3(vf, i, j, k);
+        const double g2 = 1. / (a + c * (1. - e2p) - (P.dti2 * dtef2 + 1.));
+        e2p = a * g2;
+        g2p = (P.dti2 * (-pr * l * e1) + c * g2p - rhs) * g2;
+      }
+      ee2[k - 1] = e2p;
+      gg2[k - 1] = g2p;
+    }
+    // ---- new mixing coefficients -- :1484-1503, cosmetics + mask :1510-1535
+    if (!repl) {
+      const double sh = coef1 / (1. - coef2 * gh);
+      double sm = coef3 + sh * coef4 * gh;
+      sm = sm / (1. - coef5 * gh);
+      const double pl = l * sqrt(fabs(F3(q2, i, j, k)));
+      const double kq = (pl * .41 * sh + kqc) * .5;
+      const double km = (pl * sm + F3(km, i, j, k)) * .5;
+      const double kh = (pl * sh + F3(kh, i, j, k)) * .5;
+      // own cell: in place (old kq lives on in kqm/kqc/kqp).  Physical-edge cells that copy this
+      // column are written to the staging arrays s3[1..3] (their own threads still read the old
+      // kq) and moved by k_profq_rim.
+      F3(kq, i, j, k) = kq * fsm_c;
+      F3(km, i, j, k) = km * fsm_c;
+      F3(kh, i, j, k) = kh * fsm_c;
 #define PUT(ii, jj)                                  \
   {                                                  \
     const double m = F2(fsm, ii, jj);                \
@@ -272,10 +259,28 @@ __global__ void k_profq(KP P) {
     G3(P.s3[2], ii, jj, k) = kh * m;                 \
     G3(P.s3[3], ii, jj, k) = kq * m;                 \
   }
-    if (ti) PUT(ti, j)
-    if (tj) PUT(i, tj)
-    if (ti && tj) PUT(ti, tj)
+      if (ti) PUT(ti, j)
+      if (tj) PUT(i, tj)
+      if (ti && tj) PUT(ti, tj)
 #undef PUT
+    }
+    ccm = cck; rhom = rhok;
+    kqm = kqc; kqc = kqp;
+    if (k + 2 <= kb) kqp = F3(kq, i, j, k + 2);
+  }
+  // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468
+  {
+    double x = ufbot, y = 0.;
+    for (int ki = kbm1; ki >= 1; ki--) {
+      x = ee1[ki - 1] * x + gg1[ki - 1];
+      F3(uf, i, j, ki) = (ki >= 2) ? fabs(x) : x;
+      if (ki >= 2) {
+        y = ee2[ki - 1] * y + gg2[ki - 1];
+        F3(vf, i, j, ki) = fabs(y);
+      }
+    }
+    F3(vf, i, j, 1) = 0.;
+    F3(vf, i, j, kb) = 0.;
   }
 }
 
