@@ -147,9 +147,8 @@ def main():
         stream = ts.cuda_stream
     g = gpu_initialise(st, local, stream)
     if world > 1:
-        from extpom_amd.halo import Halo
-        halo = Halo(tile)
-        g.set_exchange(halo.gpu_hook(torch.device("cuda", local)))
+        from extpom_amd.halo import DeviceHalo
+        halo = DeviceHalo(g, tile, torch.device("cuda", local))
 
     def barrier():
         g.sync()

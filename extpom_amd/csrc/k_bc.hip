@@ -189,3 +189,64 @@ void launch_bcondorl3(pomgpu_ctx *c) {
   const int len = P.im > P.jm ? P.im : P.jm;
   LAUNCH(c, k_bcondorl3, dim3((len + 63) / 64, 6, P.kbm1), dim3(64, 1, 1), c->P);
 }
+
+// ---- halo pack / unpack (parallel_mpi.f:154-351 pack loops) ----------------------------------------
+// One launch moves the edge columns (dir 0) or rows (dir 1) of up to 8 arrays.  grid.x covers the
+// edge length, grid.y the levels of the deepest array, grid.z the arrays.
+struct HaloArgs { double *ptr[8]; int nz[8]; size_t off[8]; int count; };
+__global__ void k_halo_pack(KP P, HaloArgs A, int dir, double *to_lo, double *to_hi) {
+  const int t = TID_I, k = (int)blockIdx.y + 1, a = (int)blockIdx.z;
+  const int len = dir == 0 ? P.jm : P.im;
+  if (t > len || k > A.nz[a]) return;
+  const double *p = A.ptr[a];
+  const size_t o = A.off[a] * (size_t)len + (size_t)(k - 1) * len + (size_t)(t - 1);
+  if (dir == 0) {
+    if (to_lo) to_lo[o] = G3(p, 2, t, k);
+    if (to_hi) to_hi[o] = G3(p, P.imm1, t, k);
+  } else {
+    if (to_lo) to_lo[o] = G3(p, t, 2, k);
+    if (to_hi) to_hi[o] = G3(p, t, P.jmm1, k);
+  }
+}
+__global__ void k_halo_unpack(KP P, HaloArgs A, int dir, const double *from_lo, const double *from_hi) {
+  const int t = TID_I, k = (int)blockIdx.y + 1, a = (int)blockIdx.z;
+  const int len = dir == 0 ? P.jm : P.im;
+  if (t > len || k > A.nz[a]) return;
+  double *p = A.ptr[a];
+  const size_t o = A.off[a] * (size_t)len + (size_t)(k - 1) * len + (size_t)(t - 1);
+  if (dir == 0) {
+    if (from_lo) G3(p, 1, t, k) = from_lo[o];
+    if (from_hi) G3(p, P.im, t, k) = from_hi[o];
+  } else {
+    if (from_lo) G3(p, t, 1, k) = from_lo[o];
+    if (from_hi) G3(p, t, P.jm, k) = from_hi[o];
+  }
+}
+static int halo_args(pomgpu_ctx *c, double *const *dev, const int *nz, int count, HaloArgs &A, int &nzmax) {
+  if (count < 1 || count > 8) return -1;
+  size_t off = 0;
+  nzmax = 0;
+  A.count = count;
+  for (int n = 0; n < 8; n++) { A.ptr[n] = NULL; A.nz[n] = 0; A.off[n] = 0; }
+  for (int n = 0; n < count; n++) {
+    if (!dev[n] || nz[n] < 1 || nz[n] > c->P.kb) return -1;
+    A.ptr[n] = dev[n]; A.nz[n] = nz[n]; A.off[n] = off;
+    off += (size_t)nz[n];
+    if (nz[n] > nzmax) nzmax = nz[n];
+  }
+  return 0;
+}
+int launch_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi) {
+  HaloArgs A; int nzmax;
+  if (halo_args(c, dev, nz, count, A, nzmax)) return -1;
+  const int len = dir == 0 ? c->P.jm : c->P.im;
+  LAUNCH(c, k_halo_pack, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, dir, to_lo, to_hi);
+  return 0;
+}
+int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo, const double *from_hi) {
+  HaloArgs A; int nzmax;
+  if (halo_args(c, dev, nz, count, A, nzmax)) return -1;
+  const int len = dir == 0 ? c->P.jm : c->P.im;
+  LAUNCH(c, k_halo_unpack, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, dir, from_lo, from_hi);
+  return 0;
+}

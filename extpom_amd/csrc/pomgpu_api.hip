@@ -351,6 +351,16 @@ extern "C" int pomgpu_set_exchange(pomgpu_ctx *c, pomgpu_exchange_fn fn, void *u
   return POMGPU_OK;
 }
 
+extern "C" int pomgpu_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi) {
+  if (!c || !dev || !nz || (dir != 0 && dir != 1)) return POMGPU_EINVAL;
+  return launch_halo_pack(c, dev, nz, count, dir, to_lo, to_hi) ? fail(c, POMGPU_EINVAL, "halo_pack: bad array list") : POMGPU_OK;
+}
+extern "C" int pomgpu_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo,
+                                  const double *from_hi) {
+  if (!c || !dev || !nz || (dir != 0 && dir != 1)) return POMGPU_EINVAL;
+  return launch_halo_unpack(c, dev, nz, count, dir, from_lo, from_hi) ? fail(c, POMGPU_EINVAL, "halo_unpack: bad array list") : POMGPU_OK;
+}
+
 // host address of a COMMON array -> device mirror (Fortran passes array actuals by reference)
 static double *dev3(pomgpu_ctx *c, const double *host) {
   if (!c->host3 || !host) return NULL;

@@ -221,5 +221,7 @@ void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *q
 void launch_bcond4_edges(pomgpu_ctx *c);
 void launch_bcond6_edges(pomgpu_ctx *c);
 void launch_bcondorl3(pomgpu_ctx *c);
+int launch_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi);
+int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo, const double *from_hi);
 // k_reduce.hip
 void launch_check_velocity(pomgpu_ctx *c);

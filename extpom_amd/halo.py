@@ -114,3 +114,62 @@ class Halo:
         def fn(a):          # a: numpy (nz, ny, nx)
             self.exchange([torch.from_numpy(a)])
         return fn
+
+
+class DeviceHalo:
+    """The exchange hook for the HIP path: `Halo`'s semantics with the packing done by the library.
+
+    Per program point and phase: ONE pack launch (pomgpu_halo_pack: every array's edge into one
+    contiguous buffer per neighbour), ONE batch_isend_irecv (a grouped ncclSend/ncclRecv over xGMI),
+    ONE unpack launch -- all on the stream the kernels run on; no per-array torch ops, no
+    host-device synchronisation (RCCL path).  Buffers are allocated once.
+    """
+
+    def __init__(self, gpu, tile, device, group=None, staged=False):
+        import ctypes
+        self.g, self.t, self.group, self.staged = gpu, tile, group, staged
+        self.count = 0
+        n = 8 * gpu.st.kb * max(tile.im, tile.jm)
+        mk = lambda: torch.empty(n, dtype=torch.float64, device=device)
+        self.buf = {(d, w, side): mk() for d in (0, 1) for w in ("s", "r") for side in ("lo", "hi")}
+        self._vp = ctypes.c_void_p
+        L = gpu.L
+
+        def hook(user, ptrs, nz, count):
+            self.count += 1
+            total = 0
+            for a in range(count):
+                total += nz[a]
+            for d in (0, 1):
+                lo_nb, hi_nb = (tile.n_west, tile.n_east) if d == 0 else (tile.n_south, tile.n_north)
+                if lo_nb < 0 and hi_nb < 0:
+                    continue
+                m = total * (tile.jm if d == 0 else tile.im)
+                b = self.buf
+                ptr = lambda t, on: self._vp(t.data_ptr()) if on else None
+                rc = L.pomgpu_halo_pack(gpu.h, ptrs, nz, count, d, ptr(b[d, "s", "lo"], lo_nb >= 0), ptr(b[d, "s", "hi"], hi_nb >= 0))
+                if rc:
+                    raise RuntimeError("pomgpu_halo_pack failed")
+                ops, staged_recv = [], []
+                for nb, side in ((hi_nb, "hi"), (lo_nb, "lo")):
+                    if nb < 0:
+                        continue
+                    snd, rcv = b[d, "s", side][:m], b[d, "r", side][:m]
+                    if staged:
+                        snd = snd.cpu()
+                        host = torch.empty_like(snd)
+                        staged_recv.append((host, rcv))
+                        rcv = host
+                    ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
+                    ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                for host, dev in staged_recv:
+                    dev.copy_(host)
+                rc = L.pomgpu_halo_unpack(gpu.h, ptrs, nz, count, d, ptr(b[d, "r", "lo"], lo_nb >= 0), ptr(b[d, "r", "hi"], hi_nb >= 0))
+                if rc:
+                    raise RuntimeError("pomgpu_halo_unpack failed")
+
+        from .lib import EXCHANGE_FN
+        self._cb = EXCHANGE_FN(hook)
+        gpu._chk(L.pomgpu_set_exchange(gpu.h, self._cb, None), "set_exchange")

@@ -45,6 +45,8 @@ _SIGS = {
     "pomgpu_device_2d": (_P, [_P, _I]),
     "pomgpu_device_3d": (_P, [_P, _I]),
     "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
+    "pomgpu_halo_pack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
+    "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pomgpu_run": (_I, [_P, _I]),
     "pomgpu_advq": (_I, [_P, _P, _P, _P]),

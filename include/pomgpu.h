@@ -88,6 +88,16 @@ double *pomgpu_device_3d(pomgpu_ctx *ctx, int slot3d);
 typedef void (*pomgpu_exchange_fn)(void *user, double *const *dev, const int *nz, int count);
 int pomgpu_set_exchange(pomgpu_ctx *ctx, pomgpu_exchange_fn fn, void *user);
 
+/* Pack / unpack helpers for the hook (one kernel launch per direction instead of one copy per
+ * array and edge).  dir 0 = east/west phase, 1 = north/south phase.  pack: the edge the western
+ * (southern) neighbour needs -- column 2 (row 2) of every array -- goes to `to_lo`, column im-1
+ * (row jm-1) to `to_hi`, arrays concatenated, each nz x jm (nz x im) doubles, level-major.  unpack:
+ * `from_lo` (sent by the western / southern neighbour) lands in column 1 (row 1), `from_hi` in
+ * column im (row jm).  A NULL buffer skips that side.  Buffers are device memory. */
+int pomgpu_halo_pack(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi);
+int pomgpu_halo_unpack(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, int dir, const double *from_lo,
+                       const double *from_hi);
+
 /* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
 int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
 int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */

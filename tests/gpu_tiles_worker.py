@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from extpom_amd import decomp
 from extpom_amd.cases import finish_initial, make_case
-from extpom_amd.halo import Halo
+from extpom_amd.halo import DeviceHalo
 from extpom_amd.layout import BLK2D, BLK3D
 
 IM, JM, KB, STEPS = 97, 61, 16, 3
@@ -35,8 +35,7 @@ def worker(rank, world, split, port, out):
     ts = torch.cuda.Stream()
     torch.cuda.set_stream(ts)
     g = PomGpu(st, device=0, stream=ts.cuda_stream)
-    halo = Halo(tile, staged=True)
-    g.set_exchange(halo.gpu_hook(torch.device("cuda", 0)))
+    halo = DeviceHalo(g, tile, torch.device("cuda", 0), staged=True)
 
     def dens(s, a, b, c):
         g.upload(s); g.call("dens", a, b, c); g.download(s)
