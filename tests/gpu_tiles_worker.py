@@ -26,7 +26,7 @@ def worker(rank, world, split, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from extpom_amd.model import PomGpu
-    nx, ny = (2, 1) if split == "x" else (1, 2)
+    nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
     st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10)
@@ -59,12 +59,13 @@ def main(split):
     from oracle.pyoracle import OracleTile, oracle_finish_initial
     out = tempfile.mkdtemp()
     port = 29700 + (os.getpid() % 200)
-    mp.spawn(worker, args=(2, split, port, out), nprocs=2, join=True)
+    world = 4 if split == "xy" else 2
+    mp.spawn(worker, args=(world, split, port, out), nprocs=world, join=True)
     g = make_case("island", IM, JM, KB, dte=6.0, isplit=10)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
     bad = []
-    for r in range(2):
+    for r in range(world):
         z = np.load(os.path.join(out, f"tile{r}.npz"))
         io, jo, im, jm = int(z["i_off"]), int(z["j_off"]), int(z["im"]), int(z["jm"])
         assert int(z["n"]) > 100

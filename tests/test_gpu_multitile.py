@@ -1,7 +1,8 @@
 """The N>1 path on real hardware, as far as a 1-GPU box allows: 2 ranks share GPU 0, every
 exchange point of the step goes through the C-ABI hook and extpom_amd.halo (edges staged through
 the host over gloo, because RCCL wants one GPU per rank), and the owned cells of both tiles must
-equal the single-tile CPU oracle bit for bit -- in an x split and in a y split."""
+equal the single-tile CPU oracle bit for bit -- in an x split, a y split and a 2x2 split (4 ranks:
+corner cells travel through both exchange phases)."""
 import os
 import subprocess
 import sys
@@ -12,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["x", "y"])
+@pytest.mark.parametrize("split", ["x", "y", "xy"])
 def test_two_tiles_on_one_gpu_match_single_tile_oracle(split):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py"), split], capture_output=True,
                        text=True, timeout=900)

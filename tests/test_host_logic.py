@@ -92,7 +92,7 @@ def test_c_abi_library_exports_every_declared_symbol():
 def test_two_rank_halo_exchange_is_decomposition_invariant():
     """world_size-2 gloo run: the CPU oracle on a 2x1 (and 1x2) split, with extpom_amd.halo doing
     every exchange, must equal the single-tile run bit for bit"""
-    for split in ("x", "y"):
+    for split in ("x", "y", "xy"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "halo_worker.py"), split],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
