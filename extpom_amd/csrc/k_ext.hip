@@ -78,6 +78,68 @@ __global__ void k_advave_c(KP P) {
   F2(advva, i, j) = adv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// advave, single tile, mode != 2: advua and advva in ONE pass -- solver.f:16-121.
+// With all neighbours -1 the six exchanges inside advave are no-ops, so the flux arrays need not
+// exist: every flux is a function of (i,j) evaluated where it is needed, in exactly the index ranges
+// in which the reference writes its zero-initialised arrays; the (i-1) / (i+1) instances come from
+// the neighbour lane (halo-lane wavefronts, pomgpu_internal.hpp).  fluxua, fluxva, tps (pure scratch in the reference) are not materialised.
+// 8 reads + 2 writes instead of the 31 array passes of the three kernels above.
+__device__ __forceinline__ double advave_tps(const KP &P, int i, int j) {                   // :47-53; 2<=i<=im, 2<=j<=jm
+  return .25 * (d_(i, j) + d_(i - 1, j) + d_(i, j - 1) + d_(i - 1, j - 1)) *
+         (aam2d_(i, j) + aam2d_(i, j - 1) + aam2d_(i - 1, j) + aam2d_(i - 1, j - 1)) *
+         ((uab_(i, j) - uab_(i, j - 1)) / K2(DY4, i, j) + (vab_(i, j) - vab_(i - 1, j)) / K2(DX4, i, j));
+}
+__device__ __forceinline__ double advave_fu(const KP &P, int i, int j) {                    // fluxua, u half; 2<=j<=jm
+  if (i < 2 || i > P.imm1) return 0.;
+  double f = .125 * ((d_(i + 1, j) + d_(i, j)) * ua_(i + 1, j) + (d_(i, j) + d_(i - 1, j)) * ua_(i, j)) * (ua_(i + 1, j) + ua_(i, j));
+  f = f - d_(i, j) * 2. * aam2d_(i, j) * (uab_(i + 1, j) - uab_(i, j)) / dx_(i, j);
+  return f * dy_(i, j);
+}
+__device__ __forceinline__ double advave_fv(const KP &P, int i, int j, double tps) {        // fluxva, u half; 2<=i<=im, 2<=j<=jm
+  const double f = .125 * ((d_(i, j) + d_(i, j - 1)) * va_(i, j) + (d_(i - 1, j) + d_(i - 1, j - 1)) * va_(i - 1, j)) *
+                   (ua_(i, j) + ua_(i, j - 1));
+  return (f - tps) * .25 * K2(DX4, i, j);
+}
+__device__ __forceinline__ double advave_gu(const KP &P, int i, int j, double tps) {        // fluxua, v half; 2<=i<=im, 2<=j<=jm
+  const double f = .125 * ((d_(i, j) + d_(i - 1, j)) * ua_(i, j) + (d_(i, j - 1) + d_(i - 1, j - 1)) * ua_(i, j - 1)) *
+                   (va_(i - 1, j) + va_(i, j));
+  return (f - tps) * .25 * K2(DY4, i, j);
+}
+__device__ __forceinline__ double advave_gv(const KP &P, int i, int j) {                    // fluxva, v half; 2<=i<=im
+  if (j < 2 || j > P.jmm1) return 0.;
+  double f = .125 * ((d_(i, j + 1) + d_(i, j)) * va_(i, j + 1) + (d_(i, j) + d_(i, j - 1)) * va_(i, j)) * (va_(i, j + 1) + va_(i, j));
+  f = f - d_(i, j) * 2. * aam2d_(i, j) * (vab_(i, j + 1) - vab_(i, j)) / dy_(i, j);
+  return f * dx_(i, j);
+}
+__global__ void k_advave_fused(KP P) {
+  const int lane = HALO_LANE, i0 = HALO_COL, j = TID_J;
+  if (j > P.jml) return;                                   // a whole wavefront (one row)
+  const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.im ? P.im : i0);      // halo / padding lanes shadow a valid column
+  const bool row = (j >= 2 && j <= P.jmm1);                // rows on which advua/advva are formed
+  const bool in = out && row && (i0 >= 2 && i0 <= P.imm1);
+  double fu = 0., gu = 0., tps = 0.;
+  if (row) {
+    fu = advave_fu(P, i, j);
+    if (i >= 2) { tps = advave_tps(P, i, j); gu = advave_gu(P, i, j, tps); }
+  }
+  const double fu_w = halo_w(fu, [&] { return (row && i >= 2) ? advave_fu(P, i - 1, j) : 0.; });
+  const double gu_e = halo_e(gu, [&] { return (row && i + 1 <= P.im) ? advave_gu(P, i + 1, j, advave_tps(P, i + 1, j)) : 0.; });
+  double au = 0., av = 0.;
+  if (in) {
+    au = fu - fu_w + advave_fv(P, i, j + 1, advave_tps(P, i, j + 1)) - advave_fv(P, i, j, tps);      // :65-66
+    av = gu_e - gu + advave_gv(P, i, j) - advave_gv(P, i, j - 1);                                   // :116-117
+  }
+  if (out) {
+    F2(advua, i0, j) = au;                                 // advua = 0., advva = 0. elsewhere (:16,:73)
+    F2(advva, i0, j) = av;
+  }
+}
+
 // advave, mode==2 only: bottom stress and curvature terms -- solver.f:123-195
 __global__ void k_advave_m2a(KP P) {
   const int i = TID_I, j = TID_J;
@@ -301,6 +363,7 @@ __global__ void k_int_tail(KP P) {
 void launch_advave_a(pomgpu_ctx *c) { LAUNCH(c, k_advave_a, grid2(c->P), blk2(), c->P); }
 void launch_advave_b(pomgpu_ctx *c) { LAUNCH(c, k_advave_b, grid2(c->P), blk2(), c->P); }
 void launch_advave_c(pomgpu_ctx *c) { LAUNCH(c, k_advave_c, grid2(c->P), blk2(), c->P); }
+void launch_advave_fused(pomgpu_ctx *c) { LAUNCH(c, k_advave_fused, grid2_halo(c->P), blk2(), c->P); }
 void launch_advave_m2a(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2a, grid2(c->P), blk2(), c->P); }
 void launch_advave_m2b(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2b, grid2(c->P), blk2(), c->P); }
 void launch_vint(pomgpu_ctx *c) { LAUNCH(c, k_vint, grid2(c->P), blk2(), c->P); }

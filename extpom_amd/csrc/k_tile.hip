@@ -149,30 +149,22 @@ __global__ void __launch_bounds__(256) k_advt2_rows(KP P, const double *fb, cons
 //   * the level loop is software-pipelined: iteration L issues the loads of level L+1, evaluates
 //     the faces of level L from registers filled one iteration earlier, and finishes level L-1
 //     (whose bottom face is the top face of level L, evaluated once);
-//   * west operands and the east face come from the neighbour lane (lane_w / lane_e).
-// Per cell: 13 aligned 512-byte wavefront loads (was 56 in the cell kernel), 3 face evaluations
+//   * west operands and the east face come from the neighbour lane of a halo-lane wavefront
+//     (pomgpu_internal.hpp): no lane ever loads in the middle of an iteration -- vmcnt counts in
+//     order, so such a load would wait for the whole prefetch batch of the next level.
+// Per cell: 13 512-byte wavefront loads (was 56 in the cell kernel), 3 face evaluations
 // in x/y (was 4) and 1 in z (was 2).
-struct LevT {
-  double fb_c, fb_s, fb_n, fc_c, fc_s, fc_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c;
-  double fb_w, fc_w, am_w;        // west operands: only lane 0 loads them (the others get them by shuffle)
-  double fb_e, fc_e, am_e, u_e;   // east-face operands: only the last lane loads them
-};
+struct LevT { double fb_c, fb_s, fb_n, fc_c, fc_s, fc_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
 // every load of a level is issued here, in one batch, BEFORE the level that is being computed
 // needs anything: vmcnt counts in order, so a load issued in the middle of the arithmetic would
 // make the wave wait for the whole prefetch batch of the next level
-__device__ __forceinline__ LevT advt2_load(const KP &P, const double *fb, const double *fcl, int iw, int i, int ie, int js, int j,
-                                           int jn, int k) {
+__device__ __forceinline__ LevT advt2_load(const KP &P, const double *fb, const double *fcl, int i, int js, int j, int jn, int k) {
   LevT L;
   L.fb_c = G3(fb, i, j, k);  L.fb_s = G3(fb, i, js, k);  L.fb_n = G3(fb, i, jn, k);
   L.fc_c = G3(fcl, i, j, k); L.fc_s = G3(fcl, i, js, k); L.fc_n = G3(fcl, i, jn, k);
   L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
   L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
   L.w_c = F3(w, i, j, k);
-  L.fb_w = L.fc_w = L.am_w = L.fb_e = L.fc_e = L.am_e = L.u_e = 0.;
-  if (threadIdx.x == 0) { L.fb_w = G3(fb, iw, j, k); L.fc_w = G3(fcl, iw, j, k); L.am_w = F3(aam, iw, j, k); }
-  if (threadIdx.x == blockDim.x - 1) {
-    L.fb_e = G3(fb, ie, j, k); L.fc_e = G3(fcl, ie, j, k); L.am_e = F3(aam, ie, j, k); L.u_e = F3(u, ie, j, k);
-  }
   return L;
 }
 struct CoefT { double cm, hs, msk, ds_num, ds_den; };   // mass-flux coefficient, h sum, mask, metric sums of one face
@@ -192,42 +184,42 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   return f;
 }
 __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
-  const int i0 = TID_I, j0 = TID_J;
+  const int lane = HALO_LANE, i0 = HALO_COL, j0 = TID_J;
   if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
-  const bool icol = (i0 <= P.iml);
-  const int i = icol ? i0 : P.iml, j = j0;                  // lanes past the array edge shadow the last column
+  const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);   // this lane owns an output column
+#ifdef POMGPU_EMU
+  if (!icol) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0), j = j0;   // halo / padding lanes shadow a valid column
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
   const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
   const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  const bool last = (threadIdx.x == blockDim.x - 1);
   const double fsm = F2(fsm, i, j);
-  // column-resident coefficients of the west, south and north faces, of the east face on the last
-  // lane, and of the cell
+  // column-resident coefficients of the west, south and north faces and of the cell
   const CoefT cw = coef_x(P, i, j), cs = coef_y(P, i, j), cn = coef_y(P, i, jn);
-  CoefT ce = cw;
-  if (last) ce = coef_x(P, ie, j);
   const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
   const double f1 = G3(f, i, j, 1);
   const int kbm1 = P.kbm1;
-  LevT cur = advt2_load(P, fb, fcl, iw, i, ie, js, j, jn, 1), nxt = cur;
+  LevT cur = advt2_load(P, fb, fcl, i, js, j, jn, 1), nxt = cur;
   // carried from level L-1 to its completion in iteration L
   double p_adv = 0., p_dif = 0., p_fb = 0., p_zu = 0.;
   for (int L = 1; L <= kbm1 + 1; L++) {
-    if (L + 1 <= kbm1) nxt = advt2_load(P, fb, fcl, iw, i, ie, js, j, jn, L + 1);   // in flight during this iteration
+    if (L + 1 <= kbm1) nxt = advt2_load(P, fb, fcl, i, js, j, jn, L + 1);          // in flight during this iteration
     const double ffk = (L >= 2 && !in && icol) ? G3(ff, i, j, L - 1) : 0.;
     double zu = 0.;                                                                // top face of level L (0 below kbm1)
     double s_adv = 0., s_dif = 0.;
     if (L <= kbm1) {
-      const double fb_w = lane_w(cur.fb_c, [&] { return cur.fb_w; });
-      const double fc_w = lane_w(cur.fc_c, [&] { return cur.fc_w; });
-      const double am_w = lane_w(cur.am_c, [&] { return cur.am_w; });
+      const double fb_w = halo_w(cur.fb_c, [&] { return G3(fb, iw, j, L); });
+      const double fc_w = halo_w(cur.fc_c, [&] { return G3(fcl, iw, j, L); });
+      const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
       const FaceT xw = advt2_face(P, cw, cur.u_c, cur.fb_c, fb_w, cur.fc_c, fc_w, cur.am_c, am_w);
-      FaceT xl;
-      xl.adv = xl.dif = 0.;
-      if (last) xl = advt2_face(P, ce, cur.u_e, cur.fb_e, cur.fb_c, cur.fc_e, cur.fc_c, cur.am_e, cur.am_c);
+      auto east = [&] {                                     // emulation only: the east face from memory
+        return advt2_face(P, coef_x(P, ie, j), F3(u, ie, j, L), G3(fb, ie, j, L), cur.fb_c, G3(fcl, ie, j, L), cur.fc_c,
+                          F3(aam, ie, j, L), cur.am_c);
+      };
       FaceT xe;
-      xe.adv = lane_e(xw.adv, [&] { return xl.adv; });
-      xe.dif = lane_e(xw.dif, [&] { return xl.dif; });
+      xe.adv = halo_e(xw.adv, [&] { return east().adv; });
+      xe.dif = halo_e(xw.dif, [&] { return east().dif; });
       const FaceT ys = advt2_face(P, cs, cur.v_c, cur.fb_c, cur.fb_s, cur.fc_c, cur.fc_s, cur.am_c, cur.am_s);
       const FaceT yn = advt2_face(P, cn, cur.v_n, cur.fb_n, cur.fb_c, cur.fc_n, cur.fc_c, cur.am_n, cur.am_c);
       s_adv = xe.adv - xw.adv + yn.adv - ys.adv;                                              // solver.f:670-671
@@ -258,24 +250,14 @@ __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const
 // neighbour-lane operands.  The reference exchanges xflux/yflux between the flux and the step
 // loops (:458-459); with all neighbours -1 that exchange is a no-op and the two halves fuse: the
 // fluxes never reach memory.  Used only when the context has no exchange hook (one tile).
-struct LevQ {
-  double q_c, q_s, q_n, qb_c, qb_s, qb_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c;
-  double q_w, qb_w, am_w;         // lane 0 only
-  double q_e, qb_e, am_e, u_e;    // last lane only
-};
-__device__ __forceinline__ LevQ advq_load(const KP &P, const double *q, const double *qb, int iw, int i, int ie, int js, int j, int jn,
-                                          int k) {
+struct LevQ { double q_c, q_s, q_n, qb_c, qb_s, qb_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
+__device__ __forceinline__ LevQ advq_load(const KP &P, const double *q, const double *qb, int i, int js, int j, int jn, int k) {
   LevQ L;
   L.q_c = G3(q, i, j, k);    L.q_s = G3(q, i, js, k);    L.q_n = G3(q, i, jn, k);
   L.qb_c = G3(qb, i, j, k);  L.qb_s = G3(qb, i, js, k);  L.qb_n = G3(qb, i, jn, k);
   L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
   L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
   L.w_c = F3(w, i, j, k);
-  L.q_w = L.qb_w = L.am_w = L.q_e = L.qb_e = L.am_e = L.u_e = 0.;
-  if (threadIdx.x == 0) { L.q_w = G3(q, iw, j, k); L.qb_w = G3(qb, iw, j, k); L.am_w = F3(aam, iw, j, k); }
-  if (threadIdx.x == blockDim.x - 1) {
-    L.q_e = G3(q, ie, j, k); L.qb_e = G3(qb, ie, j, k); L.am_e = F3(aam, ie, j, k); L.u_e = F3(u, ie, j, k);
-  }
   return L;
 }
 struct CoefQ { double dts, hs, msk, ds_den, ds_num; };
@@ -293,35 +275,36 @@ __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double 
   return .5 * c.ds_num * x;
 }
 __global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const double *qb, double *qf, int zero_else) {
-  const int i0 = TID_I, j0 = TID_J;
+  const int lane = HALO_LANE, i0 = HALO_COL, j0 = TID_J;
   if (j0 > P.jml) return;
-  const bool icol = (i0 <= P.iml);
-  const int i = icol ? i0 : P.iml, j = j0;
+  const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);
+#ifdef POMGPU_EMU
+  if (!icol) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0), j = j0;
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
   const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
   const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  const bool last = (threadIdx.x == blockDim.x - 1);
   const CoefQ cw = coefq_x(P, i, j), cs = coefq_y(P, i, j), cn = coefq_y(P, i, jn);
-  CoefQ ce = cw;
-  if (last) ce = coefq_x(P, ie, j);
   const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
   const int kb = P.kb, kbm1 = P.kbm1;
-  LevQ cur = advq_load(P, q, qb, iw, i, ie, js, j, jn, 1), nxt = cur, prv = cur;
+  LevQ cur = advq_load(P, q, qb, i, js, j, jn, 1), nxt = cur, prv = cur;
   double am_w_prv = 0.;                       // aam(i-1,j,L-1) as seen by this lane
   double wq_pp = 0., wq_p = 0.;               // w*q of levels L-2 and L-1
   double xe_p = 0., xw_p = 0., yn_p = 0., ys_p = 0., qb_p = 0.;   // faces and qb of level L-1, waiting for w(L)*q(L)
   for (int L = 1; L <= kb; L++) {
-    if (L + 1 <= kb) nxt = advq_load(P, q, qb, iw, i, ie, js, j, jn, L + 1);
-    const double am_w = lane_w(cur.am_c, [&] { return cur.am_w; });
+    if (L + 1 <= kb) nxt = advq_load(P, q, qb, i, js, j, jn, L + 1);
+    const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
     double xe_c = 0., xw_c = 0., yn_c = 0., ys_c = 0.;
     if (L >= 2 && L <= kbm1) {
-      const double q_w = lane_w(cur.q_c, [&] { return cur.q_w; });
-      const double qb_w = lane_w(cur.qb_c, [&] { return cur.qb_w; });
+      const double q_w = halo_w(cur.q_c, [&] { return G3(q, iw, j, L); });
+      const double qb_w = halo_w(cur.qb_c, [&] { return G3(qb, iw, j, L); });
       const double xw = advq_face(cw, cur.q_c, q_w, cur.u_c, prv.u_c, cur.am_c, am_w, prv.am_c, am_w_prv, cur.qb_c, qb_w);
-      double xl = 0.;
-      if (last) xl = advq_face(ce, cur.q_e, cur.q_c, cur.u_e, prv.u_e, cur.am_e, cur.am_c, prv.am_e, prv.am_c, cur.qb_e, cur.qb_c);
       xw_c = xw;
-      xe_c = lane_e(xw, [&] { return xl; });
+      xe_c = halo_e(xw, [&] {                               // emulation only: the east face from memory
+        return advq_face(coefq_x(P, ie, j), G3(q, ie, j, L), cur.q_c, F3(u, ie, j, L), F3(u, ie, j, L - 1), F3(aam, ie, j, L), cur.am_c,
+                         F3(aam, ie, j, L - 1), prv.am_c, G3(qb, ie, j, L), cur.qb_c);
+      });
       ys_c = advq_face(cs, cur.q_c, cur.q_s, cur.v_c, prv.v_c, cur.am_c, cur.am_s, prv.am_c, prv.am_s, cur.qb_c, cur.qb_s);
       yn_c = advq_face(cn, cur.q_n, cur.q_c, cur.v_n, prv.v_n, cur.am_n, cur.am_c, prv.am_n, prv.am_c, cur.qb_n, cur.qb_c);
     }
@@ -344,6 +327,149 @@ __global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const d
   if (icol && zero_else) G3(qf, i, j, kb) = 0.;
 }
 
+// ---- advct, all three phases fused (single tile) -- solver.f:201-408 ------------------------------------
+// The reference forms curv, xflux, yflux, exchanges them, forms advx and a second set of fluxes,
+// exchanges, forms advy: 27 array passes through the three cell kernels of k_adv.hip (PMC: 33.7 GB per
+// launch against 8.8 GB for "read u,v,ub,vb,aam, write advx,advy").  With all neighbours -1 nothing is
+// exchanged and every flux is a function of the five operands around (i,j,k), so the fluxes stay in
+// registers.  There is no vertical coupling; the level loop exists to keep the 28 two-dimensional
+// coefficients of a column in registers and to have the next level's 15 row loads in flight.
+//
+// Lane map: a wavefront covers 64 consecutive columns but only lanes 1..62 own an output column;
+// lanes 0 and 63 are HALO lanes that load their column and feed the shuffles (lane 0 supplies the
+// west operands / west face flux of lane 1, lane 63 the east operands / corner flux of lane 62), so
+// no lane ever needs a mid-iteration fallback load (vmcnt is in-order) and no flux is evaluated
+// from memory.  Wave w covers columns 62w .. 62w+63.
+struct LevC { double u_c, u_s, u_n, v_c, v_s, v_n, ub_c, ub_s, ub_n, vb_c, vb_s, vb_n, am_c, am_s, am_n; };
+__device__ __forceinline__ LevC advct_load(const KP &P, int i, int js, int j, int jn, int k) {
+  LevC L;
+  L.u_c = F3(u, i, j, k);    L.u_s = F3(u, i, js, k);    L.u_n = F3(u, i, jn, k);
+  L.v_c = F3(v, i, j, k);    L.v_s = F3(v, i, js, k);    L.v_n = F3(v, i, jn, k);
+  L.ub_c = F3(ub, i, j, k);  L.ub_s = F3(ub, i, js, k);  L.ub_n = F3(ub, i, jn, k);
+  L.vb_c = F3(vb, i, j, k);  L.vb_s = F3(vb, i, js, k);  L.vb_n = F3(vb, i, jn, k);
+  L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
+  return L;
+}
+// the same quantities evaluated from memory (emulation fallbacks only); i, j inside the tile
+__device__ double advct_xf_mem(const KP &P, int i, int j, int k) {                 // x-eq. xflux, 2<=j
+  if (i < 2 || i > P.imm1) return 0.;
+  double xf = .125 * (K2(DTSX, i + 1, j) * F3(u, i + 1, j, k) + K2(DTSX, i, j) * F3(u, i, j, k)) * (F3(u, i + 1, j, k) + F3(u, i, j, k));
+  xf = xf - F2(dt, i, j) * F3(aam, i, j, k) * 2. * (F3(ub, i + 1, j, k) - F3(ub, i, j, k)) / F2(dx, i, j);
+  return F2(dy, i, j) * xf;
+}
+__device__ double advct_curv_mem(const KP &P, int i, int j, int k) {
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return 0.;
+  return .25 * ((F3(v, i, j + 1, k) + F3(v, i, j, k)) * K2(CVA, i, j) - (F3(u, i + 1, j, k) + F3(u, i, j, k)) * K2(CVB, i, j)) / F2(art, i, j);
+}
+__device__ double advct_xg_mem(const KP &P, int i, int j, int k) {                 // y-eq. xflux at corner (i,j), 2<=i, 2<=j<=jmm1
+  double xg = .125 * (K2(DTSX, i, j) * F3(u, i, j, k) + K2(DTSX, i, j - 1) * F3(u, i, j - 1, k)) * (F3(v, i, j, k) + F3(v, i - 1, j, k));
+  const double dtaam = .25 * K2(DT4, i, j) * (F3(aam, i, j, k) + F3(aam, i - 1, j, k) + F3(aam, i, j - 1, k) + F3(aam, i - 1, j - 1, k));
+  const double dy4 = K2(DY4, i, j);
+  xg = xg - dtaam * ((F3(ub, i, j, k) - F3(ub, i, j - 1, k)) / dy4 + (F3(vb, i, j, k) - F3(vb, i - 1, j, k)) / K2(DX4, i, j));
+  return .25 * dy4 * xg;
+}
+__global__ void __launch_bounds__(256) k_advct_col(KP P) {
+  const int lane = HALO_LANE, i0 = HALO_COL, j = TID_J;      // 1-based column of this lane (0 for the very first halo lane)
+  if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
+  const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
+  const bool jrow = (j >= 2 && j <= P.jmm1);
+  const bool iin = (i0 >= 2 && i0 <= P.imm1);
+  const bool in = out && iin && jrow;
+  const int kb = P.kb, kbm1 = P.kbm1;
+  if (!jrow) {                                              // rim rows: advx = advy = 0 (solver.f:211,:317)
+    if (out)
+      for (int k = 1; k <= kb; k++) { F3(advx, i, j, k) = 0.; F3(advy, i, j, k) = 0.; }
+    return;
+  }
+  // column-resident coefficients
+  const double dtsx_c = K2(DTSX, i, j), dtsx_s = K2(DTSX, i, js);
+  const double dtsx_e = halo_e(dtsx_c, [&] { return K2(DTSX, ie, j); });
+  const double dtsy_c = K2(DTSY, i, j), dtsy_n = K2(DTSY, i, jn), dtsy_s = K2(DTSY, i, js);
+  const double dtsy_w = halo_w(dtsy_c, [&] { return K2(DTSY, iw, j); });
+  const double dtsy_nw = halo_w(dtsy_n, [&] { return K2(DTSY, iw, jn); });
+  const double dt4_c = K2(DT4, i, j), dt4_n = K2(DT4, i, jn);
+  const double dx4_c = K2(DX4, i, j), dx4_n = K2(DX4, i, jn), dy4_c = K2(DY4, i, j), dy4_n = K2(DY4, i, jn);
+  const double dt_c = F2(dt, i, j), dx_c = F2(dx, i, j), dy_c = F2(dy, i, j);
+  const double dt_s = F2(dt, i, js), dx_s = F2(dx, i, js), dy_s = F2(dy, i, js);
+  const double cva_c = K2(CVA, i, j), cvb_c = K2(CVB, i, j), art_c = F2(art, i, j);
+  const double cva_s = K2(CVA, i, js), cvb_s = K2(CVB, i, js), art_s = F2(art, i, js);
+  const double aru = F2(aru, i, j), arv = F2(arv, i, j);
+  const bool srow = (j - 1 >= 2);                           // row j-1 carries y-eq. fluxes / curv
+  const bool curvx = (i0 >= (P.W ? 3 : 2)), curvy = (j >= (P.S ? 3 : 2));
+  LevC c = advct_load(P, i, js, j, jn, 1), nxt = c;
+  for (int k = 1; k <= kbm1; k++) {
+    if (k + 1 <= kbm1) nxt = advct_load(P, i, js, j, jn, k + 1);      // in flight during this iteration
+    const double u_e = halo_e(c.u_c, [&] { return F3(u, ie, j, k); });
+    const double u_se = halo_e(c.u_s, [&] { return F3(u, ie, js, k); });
+    const double ub_e = halo_e(c.ub_c, [&] { return F3(ub, ie, j, k); });
+    const double v_w = halo_w(c.v_c, [&] { return F3(v, iw, j, k); });
+    const double v_nw = halo_w(c.v_n, [&] { return F3(v, iw, jn, k); });
+    const double vb_w = halo_w(c.vb_c, [&] { return F3(vb, iw, j, k); });
+    const double vb_nw = halo_w(c.vb_n, [&] { return F3(vb, iw, jn, k); });
+    const double am_w = halo_w(c.am_c, [&] { return F3(aam, iw, j, k); });
+    const double am_sw = halo_w(c.am_s, [&] { return F3(aam, iw, js, k); });
+    const double am_nw = halo_w(c.am_n, [&] { return F3(aam, iw, jn, k); });
+    // x-equation xflux at the cell centre (:233-239, :257-262, :275); 0 outside 2..imm1
+    double xf = 0., cv = 0.;
+    if (iin) {
+      xf = .125 * (dtsx_e * u_e + dtsx_c * c.u_c) * (u_e + c.u_c);
+      xf = xf - dt_c * c.am_c * 2. * (ub_e - c.ub_c) / dx_c;
+      xf = dy_c * xf;
+      cv = .25 * ((c.v_n + c.v_c) * cva_c - (u_e + c.u_c) * cvb_c) / art_c;                    // :217-227
+    }
+    const double ctx = cv * dt_c * (c.v_n + c.v_c);                                            // :296-297
+    const double xf_w = halo_w(xf, [&] { return advct_xf_mem(P, i - 1, j, k); });
+    const double ctx_w = halo_w(ctx, [&] {
+      return advct_curv_mem(P, i - 1, j, k) * F2(dt, i - 1, j) * (F3(v, i - 1, j + 1, k) + F3(v, i - 1, j, k));
+    });
+    // corner (i,j): y-flux of the x-equation and x-flux of the y-equation share dtaam and the shear bracket
+    const double dtaam = .25 * dt4_c * (c.am_c + am_w + c.am_s + am_sw);                       // :264-266
+    const double br = (c.ub_c - c.ub_s) / dy4_c + (c.vb_c - vb_w) / dx4_c;
+    double yf_c = .125 * (dtsy_c * c.v_c + dtsy_w * v_w) * (c.u_c + c.u_s);                    // :244-250
+    yf_c = yf_c - dtaam * br;                                                                  // :267-272
+    yf_c = .25 * dx4_c * yf_c;                                                                 // :276-277
+    double xg = .125 * (dtsx_c * c.u_c + dtsx_s * c.u_s) * (c.v_c + v_w);                      // :322-328
+    xg = xg - dtaam * br;                                                                      // :348-353
+    xg = .25 * dy4_c * xg;                                                                     // :363-364
+    const double xg_e = halo_e(xg, [&] { return advct_xg_mem(P, i + 1, j, k); });
+    // corner (i,j+1): y-flux of the x-equation only
+    const double dtaam_n = .25 * dt4_n * (c.am_n + am_nw + c.am_c + am_w);
+    double yf_n = .125 * (dtsy_n * c.v_n + dtsy_nw * v_nw) * (c.u_n + c.u_c);
+    yf_n = yf_n - dtaam_n * ((c.ub_n - c.ub_c) / dy4_n + (c.vb_n - vb_nw) / dx4_n);
+    yf_n = .25 * dx4_n * yf_n;
+    // y-equation yflux at the centres of rows j and j-1 (:333-339, :355-358, :365)
+    double yg_c = .125 * (dtsy_n * c.v_n + dtsy_c * c.v_c) * (c.v_n + c.v_c);
+    yg_c = yg_c - dt_c * c.am_c * 2. * (c.vb_n - c.vb_c) / dy_c;
+    yg_c = dx_c * yg_c;
+    double yg_s = 0., cv_s = 0.;
+    if (srow) {
+      yg_s = .125 * (dtsy_c * c.v_c + dtsy_s * c.v_s) * (c.v_c + c.v_s);
+      yg_s = yg_s - dt_s * c.am_s * 2. * (c.vb_c - c.vb_s) / dy_s;
+      yg_s = dx_s * yg_s;
+      if (iin) cv_s = .25 * ((c.v_c + c.v_s) * cva_s - (u_se + c.u_s) * cvb_s) / art_s;
+    }
+    if (out) {
+      double ax = 0., ay = 0.;
+      if (in) {
+        ax = xf - xf_w + yf_n - yf_c;                                                          // :284-288
+        if (curvx) ax = ax - aru * .25 * (ctx + ctx_w);                                        // :291-301
+        ay = xg_e - xg + yg_c - yg_s;                                                          // :374-378
+        if (curvy) ay = ay + arv * .25 * (cv * dt_c * (u_e + c.u_c) + cv_s * dt_s * (u_se + c.u_s));   // :381-391
+      }
+      F3(advx, i, j, k) = ax;
+      F3(advy, i, j, k) = ay;
+    }
+    c = nxt;
+  }
+  if (out) { F3(advx, i, j, kb) = 0.; F3(advy, i, j, kb) = 0.; }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 void launch_coef_static(pomgpu_ctx *c) { LAUNCH(c, k_coef_static, grid2(c->P), blk2(), c->P); }
 void launch_coef_dt(pomgpu_ctx *c) { LAUNCH(c, k_coef_dt, grid2(c->P), blk2(), c->P); }
@@ -359,9 +485,12 @@ static dim3 grid_rows(const KP &P) {
   return dim3((P.iml + 63) / 64, (unsigned)(strips / 4), (unsigned)(nbands * P.kb));
 }
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
-  LAUNCH(c, k_advq_col, grid2(c->P), blk2(), c->P, q, qb, qf, zero_else);
+  LAUNCH(c, k_advq_col, grid2_halo(c->P), blk2(), c->P, q, qb, qf, zero_else);
+}
+void launch_advct_col(pomgpu_ctx *c) {
+  LAUNCH(c, k_advct_col, grid2_halo(c->P), blk2(), c->P);
 }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);
-  else LAUNCH(c, k_advt2_col, grid2(c->P), blk2(), c->P, fb, f, fc, ff);
+  else LAUNCH(c, k_advt2_col, grid2_halo(c->P), blk2(), c->P, fb, f, fc, ff);
 }

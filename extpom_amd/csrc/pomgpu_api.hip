@@ -390,6 +390,7 @@ static void xch(pomgpu_ctx *c, int count, ...) {
 // ---- sequences (each mirrors one reference subroutine) ----------------------------------------
 static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
   KP &P = c->P;
+  if (!c->exch && P.mode != 2) { launch_advave_fused(c); return; }   // one tile: nothing to exchange, the fluxes stay in registers
   launch_advave_a(c);
   xch(c, 2, P.s2[0], 1, P.s2[1], 1);                          // :60-61
   launch_advave_b(c);
@@ -404,6 +405,7 @@ static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
 }
 static void seq_advct(pomgpu_ctx *c) {                        // solver.f:201-408
   KP &P = c->P;
+  if (!c->exch) { launch_advct_col(c); return; }              // one tile: nothing to exchange, fluxes stay in registers
   launch_advct_a(c);
   xch(c, 2, P.s3[0], P.kbm1, P.s3[1], P.kbm1);                // :229, :279
   launch_advct_b(c);

@@ -90,6 +90,21 @@ template <class F> __device__ __forceinline__ double lane_e(double x, F fb) {
   return (threadIdx.x == blockDim.x - 1) ? fb() : t;
 }
 
+// Halo-lane variant: a wavefront covers 64 consecutive columns, lanes 1..62 own an output column,
+// lanes 0 and 63 only load their column and feed the shuffles (wave w covers columns 62w..62w+63,
+// HALO_COL below).  No lane ever takes a fallback path, so there are no dependent second-phase
+// loads and no flux is evaluated twice by a whole wavefront for the sake of one lane.
+#ifdef POMGPU_EMU   // host emulation runs one lane at a time: neighbour values are recomputed from memory
+template <class F> __device__ __forceinline__ double halo_w(double, F fb) { return fb(); }
+template <class F> __device__ __forceinline__ double halo_e(double, F fb) { return fb(); }
+#else
+template <class F> __device__ __forceinline__ double halo_w(double x, F) { return __shfl_up(x, 1, 64); }
+template <class F> __device__ __forceinline__ double halo_e(double x, F) { return __shfl_down(x, 1, 64); }
+#endif
+#define HALO_LANE (int)((blockIdx.x * blockDim.x + threadIdx.x) & 63)
+#define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
+static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
+
 // thread -> (i,j[,k]) maps (1-based); blockDim.x runs along i
 #define TID_I (int)(blockIdx.x * blockDim.x + threadIdx.x + 1)
 #define TID_J (int)(blockIdx.y * blockDim.y + threadIdx.y + 1)
@@ -161,6 +176,8 @@ static inline void set_band_geometry(KP &P) {
 void launch_advave_a(pomgpu_ctx *c);
 void launch_advave_b(pomgpu_ctx *c);
 void launch_advave_c(pomgpu_ctx *c);
+void launch_advave_fused(pomgpu_ctx *c);
+void launch_advct_col(pomgpu_ctx *c);
 void launch_advave_m2a(pomgpu_ctx *c);
 void launch_advave_m2b(pomgpu_ctx *c);
 void launch_vint(pomgpu_ctx *c);

@@ -8,6 +8,7 @@
 // (extpom_amd/lib.py) knows nothing about it and fails loudly without a real HIP device.
 // Kernels that use cross-lane or LDS operations (k_reduce.hip) are not emulated.
 #pragma once
+#define POMGPU_EMU 1
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
