@@ -39,7 +39,12 @@ NML = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
 # SURVEY 8(a)/(d).  bytes per launch = passes * 8 B * im*jm*kb of the tile.
 KERNEL_PASSES = {
     "k_advt2_fused": 7,      # a13: R fb,fclim,u,v,w,aam  W ff
-    "k_profq": 21,           # a10 minus the separately launched production term: R kq,km,kh,t,s,rho,q2b,q2lb,q2,uf,vf,prod W q2b,q2lb,l,dtef,uf,vf,kq,km,kh
+    "k_profq": 22,           # a10, one tile (production term formed in the kernel): R kq,km,kh,t,s,rho,q2b,q2lb,q2,uf,vf,u,v W q2b,q2lb,l,dtef,uf,vf,kq,km,kh
+    "k_profq/tiles": 21,     # several tiles: prod comes from k_profq_prod (exchanged): R ...,prod instead of u,v
+    "k_advct_col": 7,        # a2, one tile: R u,v,ub,vb,aam W advx,advy
+    "k_advq_col": 7,         # a9, one tile: R q,qb,u,v,w,aam W qf
+    "k_advt2_col": 7,        # a13: R fb,fclim,u,v,w,aam W ff
+    "k_ts_update": 22,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,6 restore fields W t,tb,s,sb,rho,3 restore fields
     "k_profq_prod": 9,       # R km,kh,t,s,rho,u,v (+1 k-shifted reuse counted once) W prod  -> 7R+1W (+1)
     "k_advq_flux": 7,        # a9 first half: R q,qb,u,v,aam W xflux,yflux
     "k_advq_step": 6,        # a9 second half: R q,qb,w,xflux,yflux W qf
@@ -187,7 +192,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = cells * args.steps / dt
         nl, tms = timed.get(dom, (0, 0.0))
-        passes = KERNEL_PASSES.get(dom)
+        passes = KERNEL_PASSES.get(dom + "/tiles" if world > 1 and dom + "/tiles" in KERNEL_PASSES else dom)
         roof = None
         if nl and passes:
             ach = passes * 8.0 * tile_cells / (tms / nl * 1e-3) / 1e9

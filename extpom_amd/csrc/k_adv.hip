@@ -459,7 +459,7 @@ __device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int 
 // mode_internal, tracer tail in ONE pass (nadv=2 path): the in-place round trips of advt2 on tb/sb
 // (solver.f:691,715), bcond(4)'s mask (bounds_forcing.f:233-240), the Asselin filter and rotation of
 // t,s (advance.f:444-449), restore_interior's interpolation, relaxation and mask
-// (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 10 writes per cell instead
+// (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 8 writes per cell instead
 // of the 38 array passes of the five separate kernels.
 __device__ __forceinline__ double dens_point(const KP &P, double si, double ti, int i, int j, int k);
 __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt);
@@ -471,10 +471,8 @@ __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int 
   const double m = F2(fsm, i, j);
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
   if (lev && act) {                                                    // bcond(4) mask
-    uf = uf * m;
-    vf = vf * m;
-    F3(uf, i, j, k) = uf;
-    F3(vf, i, j, k) = vf;
+    uf = uf * m;                                                       // not stored: the only reader of the masked uf/vf is this
+    vf = vf * m;                                                       // filter; advu/advv rewrite both arrays next (advance.f:459-460)
   }
   double tb = F3(tb, i, j, k), sb = F3(sb, i, j, k);
   if (rt) {                                                            // fb = fb-fclim ... fb = fb+fclim

@@ -160,7 +160,7 @@ __global__ void k_profq_prod(KP P) {
 //     private per-thread arrays.  (The first cut re-read l three times and dtef twice and kept gh
 //     and two generations of ee/gg: 53 GB of HBM traffic per launch at 2048x1536x50 against 26 GB
 //     algorithmic, rocprofv3 FETCH_SIZE/WRITE_SIZE.)
-__global__ void k_profq(KP P) {
+__global__ void k_profq(KP P, int fuse_prod) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
@@ -191,6 +191,12 @@ __global__ void k_profq(KP P) {
   double e2p = 0., g2p = 0.;              // ee2, gg2 of level k-1
   double ccm = 0., rhom = 0.;             // sound speed and density of level k-1
   double kqm = 0., kqc = F3(kq, i, j, 1), kqp = F3(kq, i, j, 2);   // OLD kq at k-1, k, k+1
+  // fuse_prod (one tile, nothing to exchange at :1374): the shear + buoyancy production of k_profq_prod
+  // is formed here from the same sound speed / density / km / kh this walk reads anyway, instead of
+  // being written by a kernel of its own and read back
+  const bool pin = fuse_prod && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  const int ie = i < P.iml ? i + 1 : i, jn = j < P.jml ? j + 1 : j;
+  double ucm = 0., uem = 0., vcm = 0., vnm = 0.;                   // u(i), u(i+1), v(j), v(j+1) of level k-1
   for (int k = 1; k <= kb; k++) {
     const bool mid = (k >= 2 && k <= kbm1);
     // ---- level-local quantities
@@ -198,12 +204,14 @@ __global__ void k_profq(KP P) {
     if (k <= kbm1) { cck = profq_cc(P, i, j, k); rhok = F3(rho, i, j, k); }
     double q2b = F3(q2b, i, j, k);
     double l, gh = 0.;
+    double uck = 0., uek = 0., vck = 0., vnk = 0., bg = 0.;
+    if (pin && k <= kbm1) { uck = u_(i, j, k); uek = u_(ie, j, k); vck = v_(i, j, k); vnk = v_(i, jn, k); }
     if (mid) {
       q2b = fabs(q2b);                                                                      // :1325-1326
       const double q2lb = fabs(F3(q2lb, i, j, k));
       F3(q2b, i, j, k) = q2b;
       F3(q2lb, i, j, k) = q2lb;
-      const double bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * h_(i, j)) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
+      bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * h_(i, j)) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
       l = fabs(q2lb / q2b);                                                                 // :1338-1344
       if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
       gh = fmin(sq(l) * bg / q2b, .028);
@@ -219,7 +227,17 @@ __global__ void k_profq(KP P) {
     if (mid) {
       const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);      // :1261-1264
       const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
-      const double pr = G3(prod, i, j, k);
+      double pr;
+      if (!fuse_prod) {
+        pr = G3(prod, i, j, k);
+      } else if (pin) {                                                                     // :1359-1373, as k_profq_prod
+        const double sef = 1., shiw = 0.;
+        const double km = F3(km, i, j, k);
+        pr = km * .25 * sef * (sq(uck - ucm + uek - uem) + sq(vck - vcm + vnk - vnm)) / sq(F1(dzz, k - 1) * dh) - shiw * km * bg;
+        pr = pr + F3(kh, i, j, k) * bg;
+      } else {
+        pr = 0.;
+      }
       const double g = 1. / (a + c * (1. - e1p) - (2. * P.dti2 * dtef1 + 1.));
       e1p = a * g;
       g1p = (-2. * P.dti2 * pr + c * g1p - F3(uf, i, j, k)) * g;
@@ -265,6 +283,7 @@ __global__ void k_profq(KP P) {
 #undef PUT
     }
     ccm = cck; rhom = rhok;
+    ucm = uck; uem = uek; vcm = vck; vnm = vnk;
     kqm = kqc; kqc = kqp;
     if (k + 2 <= kb) kqp = F3(kq, i, j, k + 2);
   }
@@ -349,6 +368,95 @@ __global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsu
       G3(f, i, j, ki) = x;
     }
   }
+#undef RAD
+#undef ACOEF
+#undef CCOEF
+}
+
+// proft with the elimination vectors in REGISTERS.  The private ee/gg arrays of k_proft live in
+// scratch memory: written on the way down, read on the way up, i.e. four extra array passes through
+// L2/HBM per solve (PMC: 7.2 passes per launch for 3 algorithmic).  The VGPR file is the largest
+// on-chip memory of a CU (512 KB): with the level loops fully unrolled (trip count = template KBT,
+// the smallest instantiated bound >= kb) every ee[k]/gg[k] has a compile-time index and is a
+// register.
+//   * Phase A issues EVERY load of the column up front, into the registers that will later hold the
+//     elimination vectors: f(k) sits in gg[k-1] until level k turns it into gg(k-1), kh(k) sits in
+//     ee[k-1] until level k has used it as its c-coefficient and writes ee(k-1) there.  No extra
+//     registers, ~2*kb loads in flight per lane, and a fence keeps the scheduler from sinking them
+//     to their uses (it does: one load in flight, 560 ns per level, measured).
+//   * Levels past kb are computed on clamped operands and discarded by selects -- no branch inside
+//     the sweeps.
+// SW = 1 compiles the short-wave penetration terms (nbc 2 or 4) in.  Arithmetic is the same
+// expression sequence as k_proft.  When SW = 0 the term dti2*(rad(k)-rad(k+1))/(dh*dz(k)) is +0
+// exactly (dti2 > 0, dh*dz > 0), written as "+ 0.".
+template <int KBT, int SW>
+__global__ void __launch_bounds__(128) k_proft_reg(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  const double r_[5] = {.58, .62, .67, .77, .78}, ad1_[5] = {.35, .60, 1.0, 1.5, 1.4}, ad2_[5] = {23., 20., 17., 14., 7.9};
+  double ee[KBT], gg[KBT];
+  const int kbm1 = P.kbm1, kbm2 = P.kbm2;
+#define KC(k) ((k) < kbm1 ? (k) : kbm1)                       /* clamp a level index into the column */
+  // ---- phase A: all loads
+#pragma unroll
+  for (int k = 2; k <= KBT - 1; k++) ee[k - 1] = F3(kh, i, j, KC(k));
+#pragma unroll
+  for (int k = 2; k <= KBT - 2; k++) gg[k - 1] = G3(f, i, j, KC(k));
+  const double f_1 = G3(f, i, j, 1), f_kbm1 = G3(f, i, j, kbm1);
+  const double dh = h_(i, j) + F2(etf, i, j);
+  const double swr = SW ? F2(swrad, i, j) : 0.;
+  const double wfs = G2(wfsurf, i, j), fs = G2(fsurf, i, j);
+  SCHED_FENCE();
+  // ---- phase B: forward elimination
+  const double r = r_[P.ntp - 1], ad1 = ad1_[P.ntp - 1], ad2 = ad2_[P.ntp - 1];
+#define RAD(k) ((SW && (k) <= kbm1) ? swr * (r * exp(F1(z, KC(k)) * dh / ad1) + (1. - r) * exp(F1(z, KC(k)) * dh / ad2)) : 0.)
+#define ACOEF(k, khn) (-P.dti2 * ((khn) + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC(k)) * dh * dh))       /* khn = kh(k+1) */
+#define CCOEF(k, khk) (-P.dti2 * ((khk) + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC((k)-1)) * dh * dh))   /* khk = kh(k)   */
+  const double a1 = ACOEF(1, ee[1]);
+  double radk = RAD(1);
+  if (nbc == 1) {
+    ee[0] = a1 / (a1 - 1.);
+    double g = P.dti2 * wfs / (F1(dz, 1) * dh) - f_1;
+    gg[0] = g / (a1 - 1.);
+  } else if (nbc == 2) {
+    ee[0] = a1 / (a1 - 1.);
+    double g = P.dti2 * (wfs + radk - RAD(2)) / (F1(dz, 1) * dh) - f_1;
+    gg[0] = g / (a1 - 1.);
+  } else {
+    ee[0] = 0.;
+    gg[0] = fs;
+  }
+  radk = RAD(2);
+  double e_last = ee[0], g_last = gg[0], rad_last = radk, kh_last = ee[1];   // ee, gg of level kbm2; rad, kh of level kbm1
+#pragma unroll
+  for (int k = 2; k <= KBT - 2; k++) {
+    const double a = ACOEF(k, ee[k]), c = CCOEF(k, ee[k - 1]);
+    const bool fin = (k == kbm2);
+    kh_last = fin ? ee[k] : kh_last;
+    const double radn = RAD(k + 1);
+    const double g = 1. / (a + c * (1. - ee[k - 2]) - 1.);
+    ee[k - 1] = a * g;
+    if (SW) gg[k - 1] = (c * gg[k - 2] - gg[k - 1] + P.dti2 * (radk - radn) / (dh * F1(dz, KC(k)))) * g;
+    else gg[k - 1] = (c * gg[k - 2] - gg[k - 1] + 0.) * g;
+    radk = radn;
+    e_last = fin ? ee[k - 1] : e_last;
+    g_last = fin ? gg[k - 1] : g_last;
+    rad_last = fin ? radk : rad_last;
+  }
+  // ---- phase C: bottom value and back substitution
+  {
+    const double c = CCOEF(kbm1, kh_last);
+    double x;
+    if (SW) x = (c * g_last - f_kbm1 + P.dti2 * (rad_last - 0.) / (dh * F1(dz, kbm1))) / (c * (1. - e_last) - 1.);
+    else x = (c * g_last - f_kbm1 + 0.) / (c * (1. - e_last) - 1.);
+    G3(f, i, j, kbm1) = x;
+#pragma unroll
+    for (int ki = KBT - 2; ki >= 1; ki--) {
+      const double xn = (ee[ki - 1] * x + gg[ki - 1]);
+      if (ki <= kbm2) { x = xn; G3(f, i, j, ki) = x; }
+    }
+  }
+#undef KC
 #undef RAD
 #undef ACOEF
 #undef CCOEF
@@ -584,16 +692,29 @@ void launch_int_uvmean(pomgpu_ctx *c) { LAUNCH(c, k_int_uvmean, colgrid(c->P), c
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
 void launch_profq_prod(pomgpu_ctx *c) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); }
-void launch_profq(pomgpu_ctx *c) {
-  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P);
+void launch_profq(pomgpu_ctx *c, int fuse_prod) {
+  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod);
   const KP &P = c->P;
   if (P.W || P.E || P.S || P.N) {
     const int len = P.im > P.jm ? P.im : P.jm;
     LAUNCH(c, k_profq_rim, dim3((len + 63) / 64, 4, P.kb), dim3(64, 1, 1), c->P);
   }
 }
+template <int KBT>
+static void launch_proft_reg(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  if (nbc == 2 || nbc == 4) LAUNCHN(c, "k_proft", (k_proft_reg<KBT, 1>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  else LAUNCHN(c, "k_proft", (k_proft_reg<KBT, 0>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+}
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
-  LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  const int kb = c->P.kb;
+  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64) LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  else if (kb <= 24) launch_proft_reg<24>(c, f, wfsurf, fsurf, nbc);
+  else if (kb <= 32) launch_proft_reg<32>(c, f, wfsurf, fsurf, nbc);
+  else if (kb <= 40) launch_proft_reg<40>(c, f, wfsurf, fsurf, nbc);
+  else if (kb <= 44) launch_proft_reg<44>(c, f, wfsurf, fsurf, nbc);
+  else if (kb <= 50) launch_proft_reg<50>(c, f, wfsurf, fsurf, nbc);
+  else if (kb <= 56) launch_proft_reg<56>(c, f, wfsurf, fsurf, nbc);
+  else launch_proft_reg<64>(c, f, wfsurf, fsurf, nbc);
 }
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advu_profu, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advv_profv, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }

@@ -429,9 +429,10 @@ static void seq_profq(pomgpu_ctx *c) {                        // solver.f:1212-1
   KP &P = c->P;
   launch_profq_bc(c);
   xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
+  if (!c->exch) { launch_profq(c, 1); return; }               // one tile: prod is formed inside the solve kernel
   launch_profq_prod(c);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
-  launch_profq(c);
+  launch_profq(c, 0);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
   launch_copy_kb(c, fb);                                      // solver.f:496 / :618

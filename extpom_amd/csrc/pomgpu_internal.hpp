@@ -101,6 +101,12 @@ template <class F> __device__ __forceinline__ double halo_e(double, F fb) { retu
 template <class F> __device__ __forceinline__ double halo_w(double x, F) { return __shfl_up(x, 1, 64); }
 template <class F> __device__ __forceinline__ double halo_e(double x, F) { return __shfl_down(x, 1, 64); }
 #endif
+// nothing may be scheduled across this point (keeps a block of prefetch loads together and early)
+#ifdef POMGPU_EMU
+#define SCHED_FENCE()
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define HALO_LANE (int)((blockIdx.x * blockDim.x + threadIdx.x) & 63)
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
@@ -142,6 +148,15 @@ void pomgpu_prof_post(pomgpu_ctx *c, int slot);
 #define LAUNCH(c, kern, grid, block, ...)                                        \
   do {                                                                           \
     int _s = (c)->prof_on ? pomgpu_prof_slot((c), #kern) : -1;                   \
+    if (_s >= 0) pomgpu_prof_pre(c);                                             \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
+  } while (0)
+
+// same with an explicit profile name (template kernels: several instantiations share one name)
+#define LAUNCHN(c, name, kern, grid, block, ...)                                 \
+  do {                                                                           \
+    int _s = (c)->prof_on ? pomgpu_prof_slot((c), name) : -1;                    \
     if (_s >= 0) pomgpu_prof_pre(c);                                             \
     hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
     if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
@@ -223,7 +238,7 @@ void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
 void launch_profq_prod(pomgpu_ctx *c);
-void launch_profq(pomgpu_ctx *c);
+void launch_profq(pomgpu_ctx *c, int fuse_prod);
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
