@@ -140,6 +140,128 @@ __global__ void k_advave_fused(KP P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// advave, single tile, TWO columns per lane.  PMC of the kernel above: 56 wavefront loads per cell,
+// 74 % L1/TA busy, 124 us per launch for 0.3 GB -- bound by the NUMBER of load instructions (an
+// 8-byte-per-lane load occupies the texture-address path as long as a 16-byte one; micro-benchmark
+// tools/micro/ta_width.hip: 65 us -> 37 us for a 9-point stencil over 6 arrays).  Here a lane owns
+// the columns (i, i+1), i odd: every operand row is ONE aligned 16-byte load, all i-1 / i+1 operands
+// come from the neighbour lane (halo-lane wavefronts: lanes 1..62 own 124 output columns), and the
+// four rows j-2..j+1 are loaded once: 27 loads per two cells.  Needs an even leading dimension.
+struct AdvaveCell {   // operands of one cell: C(entre), W(est), E(ast) at rows m2 = j-2, m1 = j-1, 0 = j, p1 = j+1
+  double d_m2, d_m1, d_0, d_p1, dW_m1, dW_0, dW_p1, dE_0;
+  double ua_m1, ua_0, ua_p1, uaE_0, va_m1, va_0, va_p1, vaW_0, vaW_p1;
+  double uab_m1, uab_0, uab_p1, uabE_0, vab_m1, vab_0, vab_p1, vabW_0, vabW_p1;
+  double am_m1, am_0, am_p1, amW_m1, amW_0, amW_p1;
+  double dx_0, dx_m1, dy_0, dy_m1, DX4_0, DX4_p1, DY4_0, DY4_p1;
+};
+struct AdvaveOut { double fu, gu, fv0, fvP, gv0, gvM; };
+// the fluxes of one cell -- the expressions of advave_fu/tps/fv/gu/gv above on register operands.
+// fu_on: 2 <= i <= imm1; w_on: i >= 2 (corner quantities exist); sm1: row j-1 lies in 2..jmm1
+__device__ __forceinline__ AdvaveOut advave_cell(const AdvaveCell &c, bool fu_on, bool w_on, bool sm1) {
+  AdvaveOut r;
+  r.fu = r.gu = r.fv0 = r.fvP = r.gv0 = r.gvM = 0.;
+  if (fu_on) {
+    double f = .125 * ((c.dE_0 + c.d_0) * c.uaE_0 + (c.d_0 + c.dW_0) * c.ua_0) * (c.uaE_0 + c.ua_0);
+    f = f - c.d_0 * 2. * c.am_0 * (c.uabE_0 - c.uab_0) / c.dx_0;
+    r.fu = f * c.dy_0;
+  }
+  if (w_on) {
+    const double tps0 = .25 * (c.d_0 + c.dW_0 + c.d_m1 + c.dW_m1) * (c.am_0 + c.am_m1 + c.amW_0 + c.amW_m1) *
+                        ((c.uab_0 - c.uab_m1) / c.DY4_0 + (c.vab_0 - c.vabW_0) / c.DX4_0);
+    const double tpsP = .25 * (c.d_p1 + c.dW_p1 + c.d_0 + c.dW_0) * (c.am_p1 + c.am_0 + c.amW_p1 + c.amW_0) *
+                        ((c.uab_p1 - c.uab_0) / c.DY4_p1 + (c.vab_p1 - c.vabW_p1) / c.DX4_p1);
+    const double g = .125 * ((c.d_0 + c.dW_0) * c.ua_0 + (c.d_m1 + c.dW_m1) * c.ua_m1) * (c.vaW_0 + c.va_0);
+    r.gu = (g - tps0) * .25 * c.DY4_0;
+    const double f0 = .125 * ((c.d_0 + c.d_m1) * c.va_0 + (c.dW_0 + c.dW_m1) * c.vaW_0) * (c.ua_0 + c.ua_m1);
+    r.fv0 = (f0 - tps0) * .25 * c.DX4_0;
+    const double fP = .125 * ((c.d_p1 + c.d_0) * c.va_p1 + (c.dW_p1 + c.dW_0) * c.vaW_p1) * (c.ua_p1 + c.ua_0);
+    r.fvP = (fP - tpsP) * .25 * c.DX4_p1;
+    double gv0 = .125 * ((c.d_p1 + c.d_0) * c.va_p1 + (c.d_0 + c.d_m1) * c.va_0) * (c.va_p1 + c.va_0);
+    gv0 = gv0 - c.d_0 * 2. * c.am_0 * (c.vab_p1 - c.vab_0) / c.dy_0;
+    r.gv0 = gv0 * c.dx_0;
+    if (sm1) {
+      double gvM = .125 * ((c.d_0 + c.d_m1) * c.va_0 + (c.d_m1 + c.d_m2) * c.va_m1) * (c.va_0 + c.va_m1);
+      gvM = gvM - c.d_m1 * 2. * c.am_m1 * (c.vab_0 - c.vab_m1) / c.dy_m1;
+      r.gvM = gvM * c.dx_m1;
+    }
+  }
+  return r;
+}
+#define LD2(ptr, ii, jj) (*(const double2 *)&(ptr)[IX2(ii, jj)])
+#define A2(name) (P.b2 + (size_t)P2_##name * P.n2)
+__global__ void __launch_bounds__(256) k_advave_pair(KP P) {
+  const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int lane = g & 63;
+  const int ia0 = 2 * ((g >> 6) * 62 + lane - 1) + 1;       // first (odd, 1-based) column of this lane; -1 for the first halo lane
+  const int j = TID_J;
+  if (j > P.jml) return;                                   // a whole wavefront (one row)
+  const bool out = (lane >= 1 && lane <= 62 && ia0 <= P.iml);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int ia = ia0 < 1 ? 1 : (ia0 > P.iml - 1 ? P.iml - 1 : ia0), ib = ia + 1;   // halo / padding lanes shadow a valid pair
+  const int iw = ia > 1 ? ia - 1 : 1, ie = ib < P.iml ? ib + 1 : P.iml;
+  const int jm2 = j > 2 ? j - 2 : 1, jm1 = j > 1 ? j - 1 : 1, jp1 = j < P.jml ? j + 1 : P.jml;
+  const bool row = (j >= 2 && j <= P.jmm1);
+  double2 au = {0., 0.}, av = {0., 0.};
+  if (row) {                                               // wave-uniform
+    const double2 d_m2 = LD2(A2(d), ia, jm2), d_m1 = LD2(A2(d), ia, jm1), d_0 = LD2(A2(d), ia, j), d_p1 = LD2(A2(d), ia, jp1);
+    const double2 ua_m1 = LD2(A2(ua), ia, jm1), ua_0 = LD2(A2(ua), ia, j), ua_p1 = LD2(A2(ua), ia, jp1);
+    const double2 va_m1 = LD2(A2(va), ia, jm1), va_0 = LD2(A2(va), ia, j), va_p1 = LD2(A2(va), ia, jp1);
+    const double2 uab_m1 = LD2(A2(uab), ia, jm1), uab_0 = LD2(A2(uab), ia, j), uab_p1 = LD2(A2(uab), ia, jp1);
+    const double2 vab_m1 = LD2(A2(vab), ia, jm1), vab_0 = LD2(A2(vab), ia, j), vab_p1 = LD2(A2(vab), ia, jp1);
+    const double2 am_m1 = LD2(A2(aam2d), ia, jm1), am_0 = LD2(A2(aam2d), ia, j), am_p1 = LD2(A2(aam2d), ia, jp1);
+    const double2 dx_m1 = LD2(A2(dx), ia, jm1), dx_0 = LD2(A2(dx), ia, j), dy_m1 = LD2(A2(dy), ia, jm1), dy_0 = LD2(A2(dy), ia, j);
+    const double2 DX4_0 = LD2(P.c2[C2_DX4], ia, j), DX4_p1 = LD2(P.c2[C2_DX4], ia, jp1);
+    const double2 DY4_0 = LD2(P.c2[C2_DY4], ia, j), DY4_p1 = LD2(P.c2[C2_DY4], ia, jp1);
+    // west operands of column ia (= the east column of the lane to the west), east operands of column ib
+#define WV(v2, name, jj) halo_w((v2).y, [&] { return F2(name, iw, jj); })
+#define EV(v2, name, jj) halo_e((v2).x, [&] { return F2(name, ie, jj); })
+    AdvaveCell a, b;
+    a.d_m2 = d_m2.x; a.d_m1 = d_m1.x; a.d_0 = d_0.x; a.d_p1 = d_p1.x;
+    b.d_m2 = d_m2.y; b.d_m1 = d_m1.y; b.d_0 = d_0.y; b.d_p1 = d_p1.y;
+    a.dW_m1 = WV(d_m1, d, jm1); a.dW_0 = WV(d_0, d, j); a.dW_p1 = WV(d_p1, d, jp1); a.dE_0 = d_0.y;
+    b.dW_m1 = d_m1.x; b.dW_0 = d_0.x; b.dW_p1 = d_p1.x; b.dE_0 = EV(d_0, d, j);
+    a.ua_m1 = ua_m1.x; a.ua_0 = ua_0.x; a.ua_p1 = ua_p1.x; a.uaE_0 = ua_0.y;
+    b.ua_m1 = ua_m1.y; b.ua_0 = ua_0.y; b.ua_p1 = ua_p1.y; b.uaE_0 = EV(ua_0, ua, j);
+    a.va_m1 = va_m1.x; a.va_0 = va_0.x; a.va_p1 = va_p1.x; a.vaW_0 = WV(va_0, va, j); a.vaW_p1 = WV(va_p1, va, jp1);
+    b.va_m1 = va_m1.y; b.va_0 = va_0.y; b.va_p1 = va_p1.y; b.vaW_0 = va_0.x; b.vaW_p1 = va_p1.x;
+    a.uab_m1 = uab_m1.x; a.uab_0 = uab_0.x; a.uab_p1 = uab_p1.x; a.uabE_0 = uab_0.y;
+    b.uab_m1 = uab_m1.y; b.uab_0 = uab_0.y; b.uab_p1 = uab_p1.y; b.uabE_0 = EV(uab_0, uab, j);
+    a.vab_m1 = vab_m1.x; a.vab_0 = vab_0.x; a.vab_p1 = vab_p1.x; a.vabW_0 = WV(vab_0, vab, j); a.vabW_p1 = WV(vab_p1, vab, jp1);
+    b.vab_m1 = vab_m1.y; b.vab_0 = vab_0.y; b.vab_p1 = vab_p1.y; b.vabW_0 = vab_0.x; b.vabW_p1 = vab_p1.x;
+    a.am_m1 = am_m1.x; a.am_0 = am_0.x; a.am_p1 = am_p1.x;
+    a.amW_m1 = WV(am_m1, aam2d, jm1); a.amW_0 = WV(am_0, aam2d, j); a.amW_p1 = WV(am_p1, aam2d, jp1);
+    b.am_m1 = am_m1.y; b.am_0 = am_0.y; b.am_p1 = am_p1.y; b.amW_m1 = am_m1.x; b.amW_0 = am_0.x; b.amW_p1 = am_p1.x;
+    a.dx_0 = dx_0.x; a.dx_m1 = dx_m1.x; a.dy_0 = dy_0.x; a.dy_m1 = dy_m1.x;
+    b.dx_0 = dx_0.y; b.dx_m1 = dx_m1.y; b.dy_0 = dy_0.y; b.dy_m1 = dy_m1.y;
+    a.DX4_0 = DX4_0.x; a.DX4_p1 = DX4_p1.x; a.DY4_0 = DY4_0.x; a.DY4_p1 = DY4_p1.x;
+    b.DX4_0 = DX4_0.y; b.DX4_p1 = DX4_p1.y; b.DY4_0 = DY4_0.y; b.DY4_p1 = DY4_p1.y;
+#undef WV
+#undef EV
+    const bool sm1 = (j - 1 >= 2);
+    const AdvaveOut fa = advave_cell(a, ia >= 2 && ia <= P.imm1, ia >= 2 && ia <= P.im, sm1);
+    const AdvaveOut fb = advave_cell(b, ib >= 2 && ib <= P.imm1, ib <= P.im, sm1);
+    const double fu_w = halo_w(fb.fu, [&] { return ia >= 2 ? advave_fu(P, ia - 1, j) : 0.; });
+    const double gu_e = halo_e(fa.gu, [&] { return ib + 1 <= P.im ? advave_gu(P, ib + 1, j, advave_tps(P, ib + 1, j)) : 0.; });
+    if (ia0 >= 2 && ia0 <= P.imm1) {
+      au.x = fa.fu - fu_w + fa.fvP - fa.fv0;               // :65-66
+      av.x = fb.gu - fa.gu + fa.gv0 - fa.gvM;              // :116-117
+    }
+    if (ia0 + 1 >= 2 && ia0 + 1 <= P.imm1) {
+      au.y = fb.fu - fa.fu + fb.fvP - fb.fv0;
+      av.y = gu_e - fb.gu + fb.gv0 - fb.gvM;
+    }
+  }
+  if (out) {
+    *(double2 *)&F2(advua, ia0, j) = au;                    // advua = 0., advva = 0. outside the interior (:16,:73)
+    *(double2 *)&F2(advva, ia0, j) = av;
+  }
+}
+#undef LD2
+#undef A2
+
 // advave, mode==2 only: bottom stress and curvature terms -- solver.f:123-195
 __global__ void k_advave_m2a(KP P) {
   const int i = TID_I, j = TID_J;
@@ -363,7 +485,11 @@ __global__ void k_int_tail(KP P) {
 void launch_advave_a(pomgpu_ctx *c) { LAUNCH(c, k_advave_a, grid2(c->P), blk2(), c->P); }
 void launch_advave_b(pomgpu_ctx *c) { LAUNCH(c, k_advave_b, grid2(c->P), blk2(), c->P); }
 void launch_advave_c(pomgpu_ctx *c) { LAUNCH(c, k_advave_c, grid2(c->P), blk2(), c->P); }
-void launch_advave_fused(pomgpu_ctx *c) { LAUNCH(c, k_advave_fused, grid2_halo(c->P), blk2(), c->P); }
+void launch_advave_fused(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) LAUNCHN(c, "k_advave_fused", k_advave_pair, dim3((P.iml / 2 + 61) / 62, (P.jml + 3) / 4, 1), blk2(), c->P);
+  else LAUNCH(c, k_advave_fused, grid2_halo(c->P), blk2(), c->P);
+}
 void launch_advave_m2a(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2a, grid2(c->P), blk2(), c->P); }
 void launch_advave_m2b(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2b, grid2(c->P), blk2(), c->P); }
 void launch_vint(pomgpu_ctx *c) { LAUNCH(c, k_vint, grid2(c->P), blk2(), c->P); }

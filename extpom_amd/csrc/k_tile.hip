@@ -184,13 +184,14 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   return f;
 }
 __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
-  const int lane = HALO_LANE, i0 = HALO_COL, j0 = TID_J;
+  HALO_XCD_DECODE
+  const int j0 = j;
   if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
   const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);   // this lane owns an output column
 #ifdef POMGPU_EMU
   if (!icol) return;
 #endif
-  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0), j = j0;   // halo / padding lanes shadow a valid column
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);          // halo / padding lanes shadow a valid column
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
   const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
   const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
@@ -275,13 +276,14 @@ __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double 
   return .5 * c.ds_num * x;
 }
 __global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const double *qb, double *qf, int zero_else) {
-  const int lane = HALO_LANE, i0 = HALO_COL, j0 = TID_J;
+  HALO_XCD_DECODE
+  const int j0 = j;
   if (j0 > P.jml) return;
   const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);
 #ifdef POMGPU_EMU
   if (!icol) return;
 #endif
-  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0), j = j0;
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
   const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
   const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
@@ -369,7 +371,7 @@ __device__ double advct_xg_mem(const KP &P, int i, int j, int k) {              
   return .25 * dy4 * xg;
 }
 __global__ void __launch_bounds__(256) k_advct_col(KP P) {
-  const int lane = HALO_LANE, i0 = HALO_COL, j = TID_J;      // 1-based column of this lane (0 for the very first halo lane)
+  HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
   if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
 #ifdef POMGPU_EMU
@@ -485,12 +487,12 @@ static dim3 grid_rows(const KP &P) {
   return dim3((P.iml + 63) / 64, (unsigned)(strips / 4), (unsigned)(nbands * P.kb));
 }
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
-  LAUNCH(c, k_advq_col, grid2_halo(c->P), blk2(), c->P, q, qb, qf, zero_else);
+  LAUNCH(c, k_advq_col, grid1_halo(c->P), blk2(), c->P, q, qb, qf, zero_else);
 }
 void launch_advct_col(pomgpu_ctx *c) {
-  LAUNCH(c, k_advct_col, grid2_halo(c->P), blk2(), c->P);
+  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P);
 }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);
-  else LAUNCH(c, k_advt2_col, grid2_halo(c->P), blk2(), c->P, fb, f, fc, ff);
+  else LAUNCH(c, k_advt2_col, grid1_halo(c->P), blk2(), c->P, fb, f, fc, ff);
 }

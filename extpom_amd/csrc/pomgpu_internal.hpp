@@ -108,6 +108,27 @@ template <class F> __device__ __forceinline__ double halo_e(double x, F) { retur
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #define HALO_LANE (int)((blockIdx.x * blockDim.x + threadIdx.x) & 63)
+// XCD-aware placement of the column kernels' workgroups (64 x 4 columns each).  Workgroups are dealt
+// to the 8 XCDs round-robin in linear-id order, and every XCD has its own 4 MiB L2.  A plain
+// (bx, by) grid therefore puts vertically adjacent workgroups on different XCDs and each re-fetches
+// its two halo rows from HBM (6 rows read for 4 computed: PMC showed 10.5 array passes for 6-7
+// algorithmic).  Here the launch is 1-D: XCD x owns the band of block-rows [x*rpx, (x+1)*rpx) and walks
+// it row by row, so the ~3 block-rows an XCD has resident at any time are neighbours and the halo rows
+// are L2 hits.  The mapping is only a performance hint: any dispatch order gives the same results.
+// HALO_XCD_DECODE defines i0 (1-based column, halo-lane numbering) and j (1-based row), or returns.
+#define HALO_XCD_DECODE                                                                   \
+  const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
+  const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + 3) / 4;           \
+  const int rpx__ = (nby__ + 7) / 8;                                                      \
+  const int by__ = (L__ & 7) * rpx__ + (L__ >> 3) / nbx__;                                \
+  if ((L__ >> 3) / nbx__ >= rpx__ || by__ >= nby__) return;                               \
+  const int lane = g__ & 63;                                                              \
+  const int i0 = ((L__ >> 3) % nbx__) * 62 + lane;                                        \
+  const int j = by__ * 4 + (int)threadIdx.y + 1;
+static inline dim3 grid1_halo(const KP &P) {
+  const int nbx = (P.iml + 61) / 62, nby = (P.jml + 3) / 4, rpx = (nby + 7) / 8;
+  return dim3((unsigned)(8 * rpx * nbx), 1, 1);
+}
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
 

@@ -20,6 +20,7 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 
+struct double2 { double x, y; };
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}

@@ -52,6 +52,21 @@ def test_steps_bit_identical(case, nml, steps):
     assert g.check_velocity() == ot.vamax
 
 
+@pytest.mark.parametrize("case,im,jm", [("seamount", 66, 50), ("island", 128, 12)])
+def test_even_leading_dimension_steps(case, im, jm):
+    """an even im_local selects the two-columns-per-lane kernels (16-byte loads)"""
+    a = make_case(case, im, jm, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, 4):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
 def warm_state(case="island"):
     a = make_case(case, 65, 49, 21, dte=6.0, isplit=30)
     oracle_finish_initial(a)
