@@ -714,6 +714,96 @@ __device__ __forceinline__ void c_realvertvl(const KP &P, const int i, const int
   F3(wr, i, j, k) = v;
 }
 
+// realvertvl, column-marching.  PMC of the cell kernel above: 23 loads per cell (17 of them 2-D
+// operands re-fetched at every level), L1/TA 80 % busy, 2.2 ms for 4 algorithmic passes.  Here a
+// thread owns the water column: the fifteen 2-D operands live in registers, a level costs five
+// loads, the next level's are in flight while this one is evaluated.
+struct LevR { double w_n, u_c, u_e, v_c, v_n; };
+__device__ __forceinline__ LevR realvertvl_load(const KP &P, int a, int b, int k) {
+  LevR L;
+  L.w_n = w_(a, b, k + 1); L.u_c = u_(a, b, k); L.u_e = u_(a + 1, b, k); L.v_c = v_(a, b, k); L.v_n = v_(a, b + 1, k);
+  return L;
+}
+__global__ void __launch_bounds__(256) k_realvertvl_col(KP P) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.iml || j > P.jml) return;
+  const bool act = (i <= P.im && j <= P.jm);
+  const int a = (P.W && i == 1) ? 2 : ((P.E && i == P.im) ? P.imm1 : i);
+  const int b = (P.S && j == 1) ? 2 : ((P.N && j == P.jm) ? P.jmm1 : j);
+  const int kb = P.kb, kbm1 = P.kbm1;
+  if (!(act && a >= 2 && a <= P.imm1 && b >= 2 && b <= P.jmm1)) {
+    for (int k = 1; k <= kb; k++) F3(wr, i, j, k) = 0.;      // fsm * 0. (fsm is 0 or 1) and the untouched rim
+    return;
+  }
+  const double dt_c = dt_(a, b), dt_e = dt_(a + 1, b), dt_w = dt_(a - 1, b), dt_n = dt_(a, b + 1), dt_s = dt_(a, b - 1);
+  const double et_c = F2(et, a, b), et_e = F2(et, a + 1, b), et_w = F2(et, a - 1, b), et_n = F2(et, a, b + 1), et_s = F2(et, a, b - 1);
+  const double dxr = K2(R2DXSX, a + 1, b), dxl = K2(R2DXSX, a, b), dyt = K2(R2DYSY, a, b + 1), dyb = K2(R2DYSY, a, b);
+  const double detf = F2(etf, a, b) - F2(etb, a, b);
+  const double m = F2(fsm, i, j);
+  double w_k = w_(a, b, 1);
+  LevR c = realvertvl_load(P, a, b, 1), nxt = c;
+  for (int k = 1; k <= kbm1; k++) {
+    if (k + 1 <= kbm1) nxt = realvertvl_load(P, a, b, k + 1);
+    const double zzk = F1(zz, k);
+#define TPS(dtv, etv) (zzk * (dtv) + (etv))
+    const double tc = TPS(dt_c, et_c);
+    double v = 0.5 * (w_k + c.w_n) +
+               0.5 * (c.u_e * (TPS(dt_e, et_e) - tc) * dxr + c.u_c * (tc - TPS(dt_w, et_w)) * dxl +
+                      c.v_n * (TPS(dt_n, et_n) - tc) * dyt + c.v_c * (tc - TPS(dt_s, et_s)) * dyb) +
+               (1.0 + zzk) * detf / P.dti2;
+#undef TPS
+    F3(wr, i, j, k) = m * v;
+    w_k = c.w_n;
+    c = nxt;
+  }
+  F3(wr, i, j, kb) = 0.;
+}
+
+// Smagorinsky viscosity, two columns per lane (see k_advave_pair, k_ext.hip): the cell kernel k_aam
+// issues 14 loads per cell and runs at 78 % L1/TA busy; here seven aligned 16-byte loads serve two
+// cells and every i+-1 operand is a neighbour-lane value.  Needs an even leading dimension.
+#define LD2(ptr, ii, jj, kk) (*(const double2 *)&(ptr)[IX3(ii, jj, kk)])
+#define A3(name) (P.b3 + (size_t)P3_##name * P.n3)
+__device__ __forceinline__ double aam_point(const KP &P, double dx, double dy, double u_c, double u_e, double u_n, double u_ne, double u_s,
+                                            double u_se, double v_c, double v_n, double v_e, double v_ne, double v_w, double v_nw) {
+  return P.horcon * dx * dy *
+         sqrt(sq((u_e - u_c) / dx) + sq((v_n - v_c) / dy) +
+              .5 * sq(.25 * (u_n + u_ne - u_s - u_se) / dy + .25 * (v_e + v_ne - v_w - v_nw) / dx));
+}
+__global__ void __launch_bounds__(256) k_aam_pair(KP P) {
+  // banded XCD-aware decode as MARCH3, with 124 output columns per wavefront
+  const int g_ = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int L_ = g_ >> 6, xcd_ = L_ & 7, m_ = L_ >> 3;
+  const int nbx_ = (P.iml / 2 + 61) / 62, bpl_ = nbx_ * (P.g_rb / 4);
+  const int p_ = m_ % bpl_, t_ = m_ / bpl_;
+  const int k = t_ % P.kb + 1;
+  const int band_ = (t_ / P.kb) * 8 + xcd_;
+  const int lane = g_ & 63;
+  const int ia0 = 2 * ((p_ % nbx_) * 62 + lane - 1) + 1;
+  const int j = band_ * P.g_rb + (p_ / nbx_) * 4 + (int)threadIdx.y + 1;
+  if (k > P.kbm1 || j < 2 || j > P.jmm1) return;            // wave-uniform
+  const bool out = (lane >= 1 && lane <= 62 && ia0 <= P.iml);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int ia = ia0 < 1 ? 1 : (ia0 > P.iml - 1 ? P.iml - 1 : ia0), ib = ia + 1;
+  const int iw = ia > 1 ? ia - 1 : 1, ie = ib < P.iml ? ib + 1 : P.iml;
+  const double2 u_s = LD2(A3(u), ia, j - 1, k), u_0 = LD2(A3(u), ia, j, k), u_n = LD2(A3(u), ia, j + 1, k);
+  const double2 v_0 = LD2(A3(v), ia, j, k), v_n = LD2(A3(v), ia, j + 1, k);
+  const double2 dx = *(const double2 *)&F2(dx, ia, j), dy = *(const double2 *)&F2(dy, ia, j);
+  const double uE_s = halo_e(u_s.x, [&] { return u_(ie, j - 1, k); }), uE_0 = halo_e(u_0.x, [&] { return u_(ie, j, k); }),
+               uE_n = halo_e(u_n.x, [&] { return u_(ie, j + 1, k); });
+  const double vE_0 = halo_e(v_0.x, [&] { return v_(ie, j, k); }), vE_n = halo_e(v_n.x, [&] { return v_(ie, j + 1, k); });
+  const double vW_0 = halo_w(v_0.y, [&] { return v_(iw, j, k); }), vW_n = halo_w(v_n.y, [&] { return v_(iw, j + 1, k); });
+  if (!out) return;
+  if (ia0 >= 2 && ia0 <= P.imm1)
+    F3(aam, ia0, j, k) = aam_point(P, dx.x, dy.x, u_0.x, u_0.y, u_n.x, u_n.y, u_s.x, u_s.y, v_0.x, v_n.x, v_0.y, v_n.y, vW_0, vW_n);
+  if (ia0 + 1 <= P.imm1)
+    F3(aam, ia0 + 1, j, k) = aam_point(P, dx.y, dy.y, u_0.y, uE_0, u_n.y, uE_n, u_s.y, uE_s, v_0.y, v_n.y, vE_0, vE_n, v_0.x, v_n.x);
+}
+#undef LD2
+#undef A3
+
 __global__ void k_fill(double *p, size_t n, double v) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -724,7 +814,16 @@ __global__ void k_fill(double *p, size_t n, double v) {
 void launch_advct_a(pomgpu_ctx *c) { LAUNCH(c, k_advct_a, gridm(c->P), blk2(), c->P); }
 void launch_advct_b(pomgpu_ctx *c) { LAUNCH(c, k_advct_b, gridm(c->P), blk2(), c->P); }
 void launch_advct_c(pomgpu_ctx *c) { LAUNCH(c, k_advct_c, gridm(c->P), blk2(), c->P); }
-void launch_aam(pomgpu_ctx *c) { LAUNCH(c, k_aam, gridm(c->P), blk2(), c->P); }
+void launch_aam(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
+    const long nbands = (P.jml + P.g_rb - 1) / P.g_rb, rounds = (nbands + 7) / 8;
+    const long bpl = (long)((P.iml / 2 + 61) / 62) * (P.g_rb / 4);
+    LAUNCHN(c, "k_aam", k_aam_pair, dim3((unsigned)(8 * rounds * P.kb * bpl), 1, 1), blk2(), c->P);
+  } else {
+    LAUNCH(c, k_aam, gridm(c->P), blk2(), c->P);
+  }
+}
 void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb) { LAUNCH(c, k_roundtrip, gridm(c->P), blk2(), c->P, a, b, fix_kb); }
 void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf) {
   LAUNCH(c, k_advq_flux, gridm(c->P), blk2(), c->P, q, qb, xf, yf);
@@ -759,7 +858,10 @@ void launch_restore(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_resto
 void launch_restore_shift(pomgpu_ctx *c) { LAUNCH(c, k_restore_shift, gridm(c->P), blk2(), c->P); }
 void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau) { LAUNCH(c, k_restore_load, gridm(c->P), blk2(), c->P, tr, sr, tau); }
 void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, gridm(c->P), blk2(), c->P, si, ti, rhoo); }
-void launch_realvertvl(pomgpu_ctx *c) { LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P); }
+void launch_realvertvl(pomgpu_ctx *c) {
+  if (getenv("POMGPU_REALVERTVL_CELLS")) LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P);
+  else LAUNCHN(c, "k_realvertvl", k_realvertvl_col, grid2(c->P), blk2(), c->P);
+}
 void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
