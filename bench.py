@@ -55,6 +55,9 @@ KERNEL_PASSES = {
     "k_advv_profv": 9,
     "k_uv_filter": 10,       # a19: R uf,ub,u,vf,vb,v W ub,u,vb,v
     "k_proft": 3,            # a14: R f,kh W f
+    "k_proft_reg": 3,
+    "k_aam_pair": 3,
+    "k_realvertvl_col": 4,
     "k_ts_filter": 10,       # a15: R uf,vf,t,tb,s,sb W tb,t,sb,s (+uf,vf masks)
     "k_q_filter": 10,
     "k_restore": 13,         # R trstrb/f,srstrb/f,taurstrb/f,t,tb,s,sb W trstr,srstr,taurstr,t,tb,s,sb (not in SURVEY's 133)

@@ -819,7 +819,7 @@ void launch_aam(pomgpu_ctx *c) {
   if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
     const long nbands = (P.jml + P.g_rb - 1) / P.g_rb, rounds = (nbands + 7) / 8;
     const long bpl = (long)((P.iml / 2 + 61) / 62) * (P.g_rb / 4);
-    LAUNCHN(c, "k_aam", k_aam_pair, dim3((unsigned)(8 * rounds * P.kb * bpl), 1, 1), blk2(), c->P);
+    LAUNCHN(c, "k_aam_pair", k_aam_pair, dim3((unsigned)(8 * rounds * P.kb * bpl), 1, 1), blk2(), c->P);
   } else {
     LAUNCH(c, k_aam, gridm(c->P), blk2(), c->P);
   }
@@ -860,7 +860,7 @@ void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, doub
 void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, gridm(c->P), blk2(), c->P, si, ti, rhoo); }
 void launch_realvertvl(pomgpu_ctx *c) {
   if (getenv("POMGPU_REALVERTVL_CELLS")) LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P);
-  else LAUNCHN(c, "k_realvertvl", k_realvertvl_col, grid2(c->P), blk2(), c->P);
+  else LAUNCHN(c, "k_realvertvl_col", k_realvertvl_col, grid2(c->P), blk2(), c->P);
 }
 void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v) {
   int blocks = (int)((n + 255) / 256);

@@ -8,11 +8,18 @@
 // (fluxua, fluxva) are recomputed in registers where that needs no data from beyond the tile.
 #include "pomgpu_internal.hpp"
 
-#define d_(i, j) F2(d, i, j)
+// ua, va, d, el, elb are read through KP.x2 and written through KP.y2 in this file: the fused external
+// step (k_ext_step) reads one generation and writes the next into a second set of buffers, the host
+// swaps the two sets after every substep (pomgpu_api.hip, ext_parity).  Everywhere else x2 == y2 ==
+// the blk2d arrays and these are plain in-place accessors.
+#define d_(i, j) P.x2[X2_d][IX2(i, j)]
+#define ua_(i, j) P.x2[X2_ua][IX2(i, j)]
+#define va_(i, j) P.x2[X2_va][IX2(i, j)]
+#define el_(i, j) P.x2[X2_el][IX2(i, j)]
+#define elb_(i, j) P.x2[X2_elb][IX2(i, j)]
+#define Y2(name, i, j) P.y2[X2_##name][IX2(i, j)]
 #define dx_(i, j) F2(dx, i, j)
 #define dy_(i, j) F2(dy, i, j)
-#define ua_(i, j) F2(ua, i, j)
-#define va_(i, j) F2(va, i, j)
 #define uab_(i, j) F2(uab, i, j)
 #define vab_(i, j) F2(vab, i, j)
 #define aam2d_(i, j) F2(aam2d, i, j)
@@ -206,9 +213,9 @@ __global__ void __launch_bounds__(256) k_advave_pair(KP P) {
   const bool row = (j >= 2 && j <= P.jmm1);
   double2 au = {0., 0.}, av = {0., 0.};
   if (row) {                                               // wave-uniform
-    const double2 d_m2 = LD2(A2(d), ia, jm2), d_m1 = LD2(A2(d), ia, jm1), d_0 = LD2(A2(d), ia, j), d_p1 = LD2(A2(d), ia, jp1);
-    const double2 ua_m1 = LD2(A2(ua), ia, jm1), ua_0 = LD2(A2(ua), ia, j), ua_p1 = LD2(A2(ua), ia, jp1);
-    const double2 va_m1 = LD2(A2(va), ia, jm1), va_0 = LD2(A2(va), ia, j), va_p1 = LD2(A2(va), ia, jp1);
+    const double2 d_m2 = LD2(P.x2[X2_d], ia, jm2), d_m1 = LD2(P.x2[X2_d], ia, jm1), d_0 = LD2(P.x2[X2_d], ia, j), d_p1 = LD2(P.x2[X2_d], ia, jp1);
+    const double2 ua_m1 = LD2(P.x2[X2_ua], ia, jm1), ua_0 = LD2(P.x2[X2_ua], ia, j), ua_p1 = LD2(P.x2[X2_ua], ia, jp1);
+    const double2 va_m1 = LD2(P.x2[X2_va], ia, jm1), va_0 = LD2(P.x2[X2_va], ia, j), va_p1 = LD2(P.x2[X2_va], ia, jp1);
     const double2 uab_m1 = LD2(A2(uab), ia, jm1), uab_0 = LD2(A2(uab), ia, j), uab_p1 = LD2(A2(uab), ia, jp1);
     const double2 vab_m1 = LD2(A2(vab), ia, jm1), vab_0 = LD2(A2(vab), ia, j), vab_p1 = LD2(A2(vab), ia, jp1);
     const double2 am_m1 = LD2(A2(aam2d), ia, jm1), am_0 = LD2(A2(aam2d), ia, j), am_p1 = LD2(A2(aam2d), ia, jp1);
@@ -216,8 +223,8 @@ __global__ void __launch_bounds__(256) k_advave_pair(KP P) {
     const double2 DX4_0 = LD2(P.c2[C2_DX4], ia, j), DX4_p1 = LD2(P.c2[C2_DX4], ia, jp1);
     const double2 DY4_0 = LD2(P.c2[C2_DY4], ia, j), DY4_p1 = LD2(P.c2[C2_DY4], ia, jp1);
     // west operands of column ia (= the east column of the lane to the west), east operands of column ib
-#define WV(v2, name, jj) halo_w((v2).y, [&] { return F2(name, iw, jj); })
-#define EV(v2, name, jj) halo_e((v2).x, [&] { return F2(name, ie, jj); })
+#define WV(v2, name, jj) halo_w((v2).y, [&] { return name##_(iw, jj); })
+#define EV(v2, name, jj) halo_e((v2).x, [&] { return name##_(ie, jj); })
     AdvaveCell a, b;
     a.d_m2 = d_m2.x; a.d_m1 = d_m1.x; a.d_0 = d_0.x; a.d_p1 = d_p1.x;
     b.d_m2 = d_m2.y; b.d_m1 = d_m1.y; b.d_0 = d_0.y; b.d_p1 = d_p1.y;
@@ -325,7 +332,7 @@ __global__ void k_modeint_tail(KP P) {
     F2(adx2d, i, j) = F2(adx2d, i, j) - F2(advua, i, j);
     F2(ady2d, i, j) = F2(ady2d, i, j) - F2(advva, i, j);
   }
-  F2(egf, i, j) = F2(el, i, j) * P.ispi;
+  F2(egf, i, j) = el_(i, j) * P.ispi;
   if (i >= 2) F2(utf, i, j) = ua_(i, j) * (d_(i, j) + d_(i - 1, j)) * P.isp2i;
   if (j >= 2) F2(vtf, i, j) = va_(i, j) * (d_(i, j) + d_(i, j - 1)) * P.isp2i;
 }
@@ -340,18 +347,24 @@ __device__ __forceinline__ double flux_ua(const KP &P, int i, int j) {
 __device__ __forceinline__ double flux_va(const KP &P, int i, int j) {
   return .25 * (d_(i, j) + d_(i, j - 1)) * (dx_(i, j) + dx_(i, j - 1)) * va_(i, j);
 }
-__global__ void k_ext_elf(KP P) {
-  const int i = TID_I, j = TID_J;
-  if (i > P.iml || j > P.jml) return;
+// the new surface elevation of cell (i,j), i <= iml, j <= jml, including bcond(1) (clamp + mask)
+__device__ __forceinline__ double elf_at(const KP &P, int i, int j) {
   const int ii = (P.W && i == 1) ? 2 : ((P.E && i == P.im) ? P.imm1 : i);
   const int jj = (P.S && j == 1) ? 2 : ((P.N && j == P.jm) ? P.jmm1 : j);
-  double v = F2(elf, i, j);
+  double v;
   if (ii >= 2 && ii <= P.imm1 && jj >= 2 && jj <= P.jmm1 && i <= P.im && j <= P.jm)
-    v = F2(elb, ii, jj) +
+    v = elb_(ii, jj) +
         P.dte2 * (-(flux_ua(P, ii + 1, jj) - flux_ua(P, ii, jj) + flux_va(P, ii, jj + 1) - flux_va(P, ii, jj)) /
                       F2(art, ii, jj) -
                   F2(vfluxf, ii, jj));
-  F2(elf, i, j) = v * F2(fsm, i, j);
+  else
+    v = F2(elf, i, j);
+  return v * F2(fsm, i, j);
+}
+__global__ void k_ext_elf(KP P) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.iml || j > P.jml) return;
+  F2(elf, i, j) = elf_at(P, i, j);
 }
 
 // bcond(1) alone (for the stand-alone entry point) -- bounds_forcing.f:18-41
@@ -369,61 +382,62 @@ __global__ void k_copy2(KP P, double *dst, const double *src) {
 }
 
 // mode_external, momentum + bcond(2) -- advance.f:237-290, bounds_forcing.f:43-83
-__device__ __forceinline__ double uaf_interior(const KP &P, int i, int j) {
+// ec / ew / es: the new elevation elf at (i,j), (i-1,j), (i,j-1)
+__device__ __forceinline__ double uaf_interior(const KP &P, int i, int j, double ec, double ew) {
   double v = F2(adx2d, i, j) + F2(advua, i, j) -
              F2(aru, i, j) * .25 *
                  (F2(cor, i, j) * d_(i, j) * (va_(i, j + 1) + va_(i, j)) +
                   F2(cor, i - 1, j) * d_(i - 1, j) * (va_(i - 1, j + 1) + va_(i - 1, j))) +
              .25 * P.grav * (dy_(i, j) + dy_(i - 1, j)) * (d_(i, j) + d_(i - 1, j)) *
-                 ((1. - 2. * P.alpha) * (F2(el, i, j) - F2(el, i - 1, j)) +
-                  P.alpha * (F2(elb, i, j) - F2(elb, i - 1, j) + F2(elf, i, j) - F2(elf, i - 1, j)) +
+                 ((1. - 2. * P.alpha) * (el_(i, j) - el_(i - 1, j)) +
+                  P.alpha * (elb_(i, j) - elb_(i - 1, j) + ec - ew) +
                   F2(e_atmos, i, j) - F2(e_atmos, i - 1, j)) +
              F2(drx2d, i, j) + F2(aru, i, j) * (F2(wusurf, i, j) - F2(wubot, i, j));          // :239-250
-  v = ((F2(h, i, j) + F2(elb, i, j) + F2(h, i - 1, j) + F2(elb, i - 1, j)) * F2(aru, i, j) * uab_(i, j) -
+  v = ((F2(h, i, j) + elb_(i, j) + F2(h, i - 1, j) + elb_(i - 1, j)) * F2(aru, i, j) * uab_(i, j) -
        4. * P.dte * v) /
-      ((F2(h, i, j) + F2(elf, i, j) + F2(h, i - 1, j) + F2(elf, i - 1, j)) * F2(aru, i, j));  // :256-260
+      ((F2(h, i, j) + ec + F2(h, i - 1, j) + ew) * F2(aru, i, j));                            // :256-260
   return v;
 }
-__device__ __forceinline__ double vaf_interior(const KP &P, int i, int j) {
+__device__ __forceinline__ double vaf_interior(const KP &P, int i, int j, double ec, double es) {
   double v = F2(ady2d, i, j) + F2(advva, i, j) +
              F2(arv, i, j) * .25 *
                  (F2(cor, i, j) * d_(i, j) * (ua_(i + 1, j) + ua_(i, j)) +
                   F2(cor, i, j - 1) * d_(i, j - 1) * (ua_(i + 1, j - 1) + ua_(i, j - 1))) +
              .25 * P.grav * (dx_(i, j) + dx_(i, j - 1)) * (d_(i, j) + d_(i, j - 1)) *
-                 ((1. - 2. * P.alpha) * (F2(el, i, j) - F2(el, i, j - 1)) +
-                  P.alpha * (F2(elb, i, j) - F2(elb, i, j - 1) + F2(elf, i, j) - F2(elf, i, j - 1)) +
+                 ((1. - 2. * P.alpha) * (el_(i, j) - el_(i, j - 1)) +
+                  P.alpha * (elb_(i, j) - elb_(i, j - 1) + ec - es) +
                   F2(e_atmos, i, j) - F2(e_atmos, i, j - 1)) +
              F2(dry2d, i, j) + F2(arv, i, j) * (F2(wvsurf, i, j) - F2(wvbot, i, j));          // :266-276
-  v = ((F2(h, i, j) + F2(elb, i, j) + F2(h, i, j - 1) + F2(elb, i, j - 1)) * F2(arv, i, j) * vab_(i, j) -
+  v = ((F2(h, i, j) + elb_(i, j) + F2(h, i, j - 1) + elb_(i, j - 1)) * F2(arv, i, j) * vab_(i, j) -
        4. * P.dte * v) /
-      ((F2(h, i, j) + F2(elf, i, j) + F2(h, i, j - 1) + F2(elf, i, j - 1)) * F2(arv, i, j));  // :282-286
+      ((F2(h, i, j) + ec + F2(h, i, j - 1) + es) * F2(arv, i, j));                            // :282-286
   return v;
 }
 // the open-boundary values of bcond(2); `interior` = 0 skips the advance.f formulas (bcond alone)
-__device__ __forceinline__ void uvaf_cell(const KP &P, int i, int j, int interior, double &uo, double &vo) {
+__device__ __forceinline__ void uvaf_cell(const KP &P, int i, int j, int interior, double ec, double ew, double es, double &uo, double &vo) {
   double u = F2(uaf, i, j), v = F2(vaf, i, j);
   const bool jin = (j >= 2 && j <= P.jmm1), iin = (i >= 2 && i <= P.imm1);
   if (interior) {
-    if (i >= 2 && i <= P.im && jin) u = uaf_interior(P, i, j);
-    if (iin && j >= 2 && j <= P.jm) v = vaf_interior(P, i, j);
+    if (i >= 2 && i <= P.im && jin) u = uaf_interior(P, i, j, ec, ew);
+    if (iin && j >= 2 && j <= P.jm) v = vaf_interior(P, i, j, ec, es);
   }
   if (P.W && jin && (i == 1 || i == 2)) {                                                 // :47-53
     if (i == 1) v = BD1(vabw, j);
-    u = BD1(uabw, j) - P.rfw * sqrt(P.grav / d_(2, j)) * (F2(el, 2, j) - BD1(elw, j));
+    u = BD1(uabw, j) - P.rfw * sqrt(P.grav / d_(2, j)) * (el_(2, j) - BD1(elw, j));
     u = P.ramp * u;
   }
   if (P.E && jin && i == P.im) {                                                          // :56-61
-    u = BD1(uabe, j) + P.rfe * sqrt(P.grav / d_(P.imm1, j)) * (F2(el, P.imm1, j) - BD1(ele, j));
+    u = BD1(uabe, j) + P.rfe * sqrt(P.grav / d_(P.imm1, j)) * (el_(P.imm1, j) - BD1(ele, j));
     u = P.ramp * u;
     v = BD1(vabe, j);
   }
   if (P.S && iin && (j == 1 || j == 2)) {                                                 // :64-70
     if (j == 1) u = BD1(uabs, i);
-    v = BD1(vabs, i) - P.rfs * sqrt(P.grav / d_(i, 2)) * (F2(el, i, 2) - BD1(els, i));
+    v = BD1(vabs, i) - P.rfs * sqrt(P.grav / d_(i, 2)) * (el_(i, 2) - BD1(els, i));
     v = P.ramp * v;
   }
   if (P.N && iin && j == P.jm) {                                                          // :73-78
-    v = BD1(vabn, i) + P.rfn * sqrt(P.grav / d_(i, P.jmm1)) * (F2(el, i, P.jmm1) - BD1(eln, i));
+    v = BD1(vabn, i) + P.rfn * sqrt(P.grav / d_(i, P.jmm1)) * (el_(i, P.jmm1) - BD1(eln, i));
     v = P.ramp * v;
     u = BD1(uabn, i);
   }
@@ -434,37 +448,80 @@ __global__ void k_ext_uvaf(KP P, int interior) {
   const int i = TID_I, j = TID_J;
   if (i > P.iml || j > P.jml) return;
   double u, v;
-  if (i <= P.im && j <= P.jm) uvaf_cell(P, i, j, interior, u, v);
-  else { u = F2(uaf, i, j); v = F2(vaf, i, j); }
+  if (i <= P.im && j <= P.jm) {
+    const double ec = F2(elf, i, j), ew = i >= 2 ? F2(elf, i - 1, j) : 0., es = j >= 2 ? F2(elf, i, j - 1) : 0.;
+    uvaf_cell(P, i, j, interior, ec, ew, es, u, v);
+  } else { u = F2(uaf, i, j); v = F2(vaf, i, j); }
   F2(uaf, i, j) = u * F2(dum, i, j);                                                      // :80-81
   F2(vaf, i, j) = v * F2(dvm, i, j);
 }
 
 // mode_external, etf weights + Asselin filter + time rotation + accumulation -- advance.f:295-350
-__global__ void k_ext_update(KP P) {
-  const int i = TID_I, j = TID_J;
-  if (i > P.iml || j > P.jml) return;
-  const bool act = (i <= P.im && j <= P.jm);
-  const double elf = F2(elf, i, j), uaf = F2(uaf, i, j), vaf = F2(vaf, i, j);
+// elf, uaf, vaf: the new values at (i,j); ew, es: elf at (i-1,j), (i,j-1).  Reads generation x2, writes y2.
+__device__ __forceinline__ void ext_update_cell(const KP &P, int i, int j, bool act, double elf, double uaf, double vaf, double ew, double es) {
   if (act) {                                                                              // :295-318
     if (P.iext == P.isplit - 2) F2(etf, i, j) = .25 * P.smoth * elf;
     else if (P.iext == P.isplit - 1) F2(etf, i, j) = F2(etf, i, j) + .5 * (1. - .5 * P.smoth) * elf;
     else if (P.iext == P.isplit) F2(etf, i, j) = (F2(etf, i, j) + .5 * elf) * F2(fsm, i, j);
   }
-  const double ua = ua_(i, j), va = va_(i, j), el = F2(el, i, j);
+  const double ua = ua_(i, j), va = va_(i, j), el = el_(i, j);
   F2(uab, i, j) = ua + .5 * P.smoth * (uab_(i, j) - 2. * ua + uaf);                       // :321,327
   F2(vab, i, j) = va + .5 * P.smoth * (vab_(i, j) - 2. * va + vaf);                       // :322,329
-  F2(elb, i, j) = el + .5 * P.smoth * (F2(elb, i, j) - 2. * el + elf);                    // :323-324
-  F2(el, i, j) = elf;                                                                     // :325
+  Y2(elb, i, j) = el + .5 * P.smoth * (elb_(i, j) - 2. * el + elf);                       // :323-324
+  Y2(el, i, j) = elf;                                                                     // :325
   const double dn = F2(h, i, j) + elf;
-  F2(d, i, j) = dn;                                                                       // :326
-  F2(ua, i, j) = uaf;                                                                     // :328
-  F2(va, i, j) = vaf;                                                                     // :330
+  Y2(d, i, j) = dn;                                                                       // :326
+  Y2(ua, i, j) = uaf;                                                                     // :328
+  Y2(va, i, j) = vaf;                                                                     // :330
   if (P.iext != P.isplit && act) {                                                        // :332-347
     F2(egf, i, j) = F2(egf, i, j) + elf * P.ispi;
-    if (i >= 2) F2(utf, i, j) = F2(utf, i, j) + uaf * (dn + (F2(h, i - 1, j) + F2(elf, i - 1, j))) * P.isp2i;
-    if (j >= 2) F2(vtf, i, j) = F2(vtf, i, j) + vaf * (dn + (F2(h, i, j - 1) + F2(elf, i, j - 1))) * P.isp2i;
+    if (i >= 2) F2(utf, i, j) = F2(utf, i, j) + uaf * (dn + (F2(h, i - 1, j) + ew)) * P.isp2i;
+    if (j >= 2) F2(vtf, i, j) = F2(vtf, i, j) + vaf * (dn + (F2(h, i, j - 1) + es)) * P.isp2i;
   }
+}
+__global__ void k_ext_update(KP P) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.iml || j > P.jml) return;
+  const bool act = (i <= P.im && j <= P.jm), acc = (act && P.iext != P.isplit);
+  ext_update_cell(P, i, j, act, F2(elf, i, j), F2(uaf, i, j), F2(vaf, i, j), (acc && i >= 2) ? F2(elf, i - 1, j) : 0.,
+                  (acc && j >= 2) ? F2(elf, i, j - 1) : 0.);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mode_external, single tile: ONE kernel per substep.  With nothing to exchange between the
+// continuity, momentum and filter phases (advance.f:233, :292-293) the three kernels above fuse: elf
+// at (i,j), (i-1,j), (i,j-1) is evaluated in registers, uaf/vaf follow, and the time rotation writes
+// the NEXT generation of ua, va, d, el, elb into the second buffer set (the neighbours of those five
+// are still being read by other threads).  elf, uaf, vaf reach memory only on the last substep
+// (nothing reads them in between).  Per substep 42 array passes instead of 70.
+// k_ext_step: cells 3..imm1 x 3..jmm1 (no clamp, no open-boundary formula);  k_ext_step_rim: the
+// three outermost lines on every side, with bcond(1) and bcond(2).  Array padding is not touched.
+__global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f) {
+  const int i = TID_I, j = TID_J;
+  if (i < 3 || i > P.imm1 || j < 3 || j > P.jmm1) return;
+  const double ec = elf_at(P, i, j), ew = elf_at(P, i - 1, j), es = elf_at(P, i, j - 1);
+  const double u = uaf_interior(P, i, j, ec, ew) * F2(dum, i, j);
+  const double v = vaf_interior(P, i, j, ec, es) * F2(dvm, i, j);
+  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
+  ext_update_cell(P, i, j, true, ec, u, v, ew, es);
+}
+__global__ void k_ext_step_rim(KP P, int store_f) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
+  int i, j;
+  if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
+  else {
+    const int q = t - 3 * im;
+    if (ncol <= 0 || q >= 3 * ncol) return;
+    const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
+  }
+  const double ec = elf_at(P, i, j), ew = i >= 2 ? elf_at(P, i - 1, j) : 0., es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
+  double u, v;
+  uvaf_cell(P, i, j, 1, ec, ew, es, u, v);
+  u = u * F2(dum, i, j);
+  v = v * F2(dvm, i, j);
+  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
+  ext_update_cell(P, i, j, true, ec, u, v, ew, es);
 }
 
 // mode_internal tail: rotate the 2-D time levels -- advance.f:525-531 (whole arrays)
@@ -487,7 +544,7 @@ void launch_advave_b(pomgpu_ctx *c) { LAUNCH(c, k_advave_b, grid2(c->P), blk2(),
 void launch_advave_c(pomgpu_ctx *c) { LAUNCH(c, k_advave_c, grid2(c->P), blk2(), c->P); }
 void launch_advave_fused(pomgpu_ctx *c) {
   const KP &P = c->P;
-  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) LAUNCHN(c, "k_advave_fused", k_advave_pair, dim3((P.iml / 2 + 61) / 62, (P.jml + 3) / 4, 1), blk2(), c->P);
+  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) LAUNCHN(c, "k_advave_pair", k_advave_pair, dim3((P.iml / 2 + 61) / 62, (P.jml + 3) / 4, 1), blk2(), c->P);
   else LAUNCH(c, k_advave_fused, grid2_halo(c->P), blk2(), c->P);
 }
 void launch_advave_m2a(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2a, grid2(c->P), blk2(), c->P); }
@@ -497,6 +554,13 @@ void launch_modeint_tail(pomgpu_ctx *c) { LAUNCH(c, k_modeint_tail, grid2(c->P),
 void launch_ext_elf(pomgpu_ctx *c) { LAUNCH(c, k_ext_elf, grid2(c->P), blk2(), c->P); }
 void launch_ext_uvaf(pomgpu_ctx *c, int interior) { LAUNCH(c, k_ext_uvaf, grid2(c->P), blk2(), c->P, interior); }
 void launch_ext_update(pomgpu_ctx *c) { LAUNCH(c, k_ext_update, grid2(c->P), blk2(), c->P); }
+// Q: c->P with y2 pointing at the next-generation buffers
+void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f) {
+  LAUNCH(c, k_ext_step, grid2(Q), blk2(), Q, store_f);
+  const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
+  LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
+}
+void launch_copy2(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy2, grid2(c->P), blk2(), c->P, dst, src); }
 void launch_int_tail(pomgpu_ctx *c) { LAUNCH(c, k_int_tail, grid2(c->P), blk2(), c->P); }
 void launch_bcond1(pomgpu_ctx *c) {
   LAUNCH(c, k_bcond1, grid2(c->P), blk2(), c->P);

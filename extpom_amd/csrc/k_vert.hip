@@ -702,8 +702,8 @@ void launch_profq(pomgpu_ctx *c, int fuse_prod) {
 }
 template <int KBT>
 static void launch_proft_reg(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
-  if (nbc == 2 || nbc == 4) LAUNCHN(c, "k_proft", (k_proft_reg<KBT, 1>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
-  else LAUNCHN(c, "k_proft", (k_proft_reg<KBT, 0>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  if (nbc == 2 || nbc == 4) LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 1>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  else LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 0>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
 }
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   const int kb = c->P.kb;

@@ -126,6 +126,24 @@ static void sync_scalars(pomgpu_ctx *c) {
 // ---- life cycle -------------------------------------------------------------------------------
 extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.1 (gfx950)"; }
 
+// ---- the two generations of ua, va, d, el, elb (fused external step, k_ext.hip) -------------------
+// ext_parity == 0: the current generation is in the blk2d arrays; == 1: in alt2.  KP.x2 (read) and
+// KP.y2 (write) both point at the current generation, so every kernel works in place; only
+// launch_ext_step gets a KP whose y2 is the other set.  ext_canonical() moves the current generation
+// back into blk2d; every entry point except pomgpu_mode_external calls it first (a no-op after an
+// even number of fused substeps).
+static const int X2_SLOT[5] = {P2_ua, P2_va, P2_d, P2_el, P2_elb};
+static void ext_buffers(pomgpu_ctx *c) {
+  KP &P = c->P;
+  for (int n = 0; n < 5; n++) P.x2[n] = P.y2[n] = c->ext_parity ? c->alt2[n] : P.b2 + (size_t)X2_SLOT[n] * P.n2;
+}
+static void ext_canonical(pomgpu_ctx *c) {
+  if (!c->ext_parity) return;
+  KP &P = c->P;
+  for (int n = 0; n < 5; n++) launch_copy2(c, P.b2 + (size_t)X2_SLOT[n] * P.n2, c->alt2[n]);
+  c->ext_parity = 0;
+  ext_buffers(c);
+}
 extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *stream) {
   if (!out || !d) return POMGPU_EINVAL;
   *out = NULL;
@@ -180,6 +198,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   for (int n = 0; n < POMGPU_NSCR3; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
+  for (int n = 0; n < 5; n++) alloc(&c->alt2[n], P.n2);
   alloc(&c->d_vel, 4);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
@@ -188,6 +207,8 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
     pomgpu_destroy(c);
     return POMGPU_ENOMEM;
   }
+  c->ext_parity = 0;
+  ext_buffers(c);
   (void)hipStreamSynchronize(c->stream);
   *out = c;
   return POMGPU_OK;
@@ -202,6 +223,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
   for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
+  for (int n = 0; n < 5; n++) (void)hipFree(c->alt2[n]);
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err);
   ProfState *ps = PS(c);
@@ -261,6 +283,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   if (!c) return POMGPU_EINVAL;
   KP &P = c->P;
   HIPCHK(c, hipSetDevice(c->device));
+  ext_canonical(c);
   if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
@@ -281,6 +304,7 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
   if (!c) return POMGPU_EINVAL;
   KP &P = c->P;
   HIPCHK(c, hipSetDevice(c->device));
+  ext_canonical(c);
   if (b1) HIPCHK(c, hipMemcpyAsync(b1, P.b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyDeviceToHost, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(b2, P.b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyDeviceToHost, c->stream));
   if (b3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
@@ -298,7 +322,7 @@ static void refresh_coefs(pomgpu_ctx *c) {
   launch_coef_dt(c);
   launch_coef_eta(c);
 }
-#define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL
+#define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL; ext_canonical(c)
 extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
@@ -324,7 +348,11 @@ extern "C" int pomgpu_download_3d(pomgpu_ctx *c, int s, double *h) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return POMGPU_OK;
 }
-extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) { return (c && s >= 0 && s < POM_NBLK2D) ? SLOT2(c, s) : NULL; }
+extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) {
+  if (!c || s < 0 || s >= POM_NBLK2D) return NULL;
+  ext_canonical(c);
+  return SLOT2(c, s);
+}
 extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) { return (c && s >= 0 && s < POM_NBLK3D) ? SLOT3(c, s) : NULL; }
 extern "C" int pomgpu_bind_host(pomgpu_ctx *c, const double *h2, const double *h3) {
   if (!c) return POMGPU_EINVAL;
@@ -510,7 +538,8 @@ static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.
   return POMGPU_OK;
 }
 
-#define NEED(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
+#define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
+#define NEED(c) NEED_RAW(c); ext_canonical(c)
 
 extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
   NEED(c);
@@ -544,10 +573,22 @@ extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) {       // advance.f:144-2
   xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);                    // :198-199
   return POMGPU_OK;
 }
-extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {          // advance.f:205-353
-  NEED(c);
+// store_f: write elf, uaf, vaf on every substep (the public entry point: the caller may look at them);
+// pomgpu_advance stores them on the last substep only -- nothing reads them in between
+static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-353
+  NEED_RAW(c);
   KP &P = c->P;
   P.iext = c->con.iext;
+  if (!c->exch && !getenv("POMGPU_EXT_SPLIT")) {              // one tile: one kernel per substep, two buffer generations
+    if (c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235 (reads ua, va, d of the current generation)
+    KP Q = P;
+    for (int n = 0; n < 5; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
+    launch_ext_step(c, Q, store_f || P.iext == P.isplit);     // :211-347
+    c->ext_parity ^= 1;
+    ext_buffers(c);
+    return POMGPU_OK;
+  }
+  ext_canonical(c);
   launch_ext_elf(c);                                          // :211-231
   xch(c, 1, D2(c, elf), 1);                                   // :233
   if (c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235
@@ -557,6 +598,7 @@ extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {          // advance.f:205-3
   if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
   return POMGPU_OK;
 }
+extern "C" int pomgpu_mode_external(pomgpu_ctx *c) { return mode_external(c, 1); }
 extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
   NEED(c);
   KP &P = c->P;
@@ -640,7 +682,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   if ((rc = pomgpu_mode_interaction(c))) return rc;
   for (int iext = 1; iext <= c->con.isplit; iext++) {
     c->con.iext = iext;
-    if ((rc = pomgpu_mode_external(c))) return rc;
+    if ((rc = mode_external(c, 0))) return rc;
   }
   c->con.iext = c->con.isplit + 1;
   if ((rc = pomgpu_mode_internal(c))) return rc;

@@ -33,7 +33,11 @@ struct KP {
   int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
+  // current (read) and next (written) generation of ua, va, d, el, elb for the external-mode kernels
+  // (k_ext.hip); identical and equal to the blk2d arrays except inside the fused external step
+  double *x2[5], *y2[5];
 };
+enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb };
 
 // ---- Fortran-style accessors (1-based), `P` is the KP in scope ------------------------------
 #define IX2(i, j) ((size_t)((j)-1) * (size_t)P.iml + (size_t)((i)-1))
@@ -151,6 +155,8 @@ struct pomgpu_ctx {
   const double *host2, *host3;   // host bases registered by pomgpu_bind_host
   void (*exch)(void *, double *const *, const int *, int);
   void *exch_user;
+  double *alt2[5];           // second buffer set of ua, va, d, el, elb (fused external step)
+  int ext_parity;            // 1 while the current generation of those five lives in alt2
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
   int *d_err;                // device error flag
   // profiling
@@ -221,6 +227,8 @@ void launch_modeint_tail(pomgpu_ctx *c);
 void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
+void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f);
+void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_int_tail(pomgpu_ctx *c);
 void launch_bcond1(pomgpu_ctx *c);
 // k_adv.hip

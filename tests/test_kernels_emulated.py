@@ -34,7 +34,7 @@ def diff(a, b, skip=SCRATCH):
     ("seamount", dict(), 8), ("island", dict(), 6), ("basin", dict(), 6),
     ("seamount", dict(nadv=1), 4), ("island", dict(nitera=2), 4), ("seamount", dict(nitera=3, sw=1.0), 3),
     ("seamount", dict(mode=4), 4), ("seamount", dict(mode=2), 4), ("seamount", dict(nbct=3, nbcs=3), 4),
-    ("basin", dict(isplit=10, alpha=0.225), 4)])
+    ("basin", dict(isplit=10, alpha=0.225), 4), ("seamount", dict(isplit=7), 3)])   # odd isplit: the buffer generations end swapped
 def test_steps_bit_identical(case, nml, steps):
     kw = dict(dte=6.0, isplit=30)
     kw.update(nml)
