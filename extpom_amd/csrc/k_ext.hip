@@ -496,14 +496,84 @@ __global__ void k_ext_update(KP P) {
 // (nothing reads them in between).  Per substep 42 array passes instead of 70.
 // k_ext_step: cells 3..imm1 x 3..jmm1 (no clamp, no open-boundary formula);  k_ext_step_rim: the
 // three outermost lines on every side, with bcond(1) and bcond(2).  Array padding is not touched.
+// Register-operand form: every array row is loaded once per cell (50 loads instead of ~95 through the
+// cell functions above), the (i-1) / (i+1) operands, the two x-fluxes of the east neighbour and the
+// west neighbour's new elevation come from the neighbour lane (halo-lane wavefronts).
 __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f) {
-  const int i = TID_I, j = TID_J;
-  if (i < 3 || i > P.imm1 || j < 3 || j > P.jmm1) return;
-  const double ec = elf_at(P, i, j), ew = elf_at(P, i - 1, j), es = elf_at(P, i, j - 1);
-  const double u = uaf_interior(P, i, j, ec, ew) * F2(dum, i, j);
-  const double v = vaf_interior(P, i, j, ec, es) * F2(dvm, i, j);
+  const int lane = HALO_LANE, i0 = HALO_COL, j = TID_J;
+  if (j < 3 || j > P.jmm1) return;                         // a whole wavefront (one row)
+  const bool out = (lane >= 1 && lane <= 62 && i0 >= 3 && i0 <= P.imm1);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);    // halo / padding lanes shadow a valid column
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+#define WS(x, expr) halo_w(x, [&] { return expr; })
+#define ES(x, expr) halo_e(x, [&] { return expr; })
+  // ---- operands: rows m2 = j-2, m1 = j-1, 0 = j, p1 = j+1 of this column
+  const double d_m2 = d_(i, j - 2), d_m1 = d_(i, j - 1), d_0 = d_(i, j), d_p1 = d_(i, j + 1);
+  const double ua_m1 = ua_(i, j - 1), ua_0 = ua_(i, j);
+  const double va_m1 = va_(i, j - 1), va_0 = va_(i, j), va_p1 = va_(i, j + 1);
+  const double dysx_m1 = K2(DYSX, i, j - 1), dysx_0 = K2(DYSX, i, j);                       // dy(i,q)+dy(i-1,q)
+  const double dxsy_m1 = K2(DXSY, i, j - 1), dxsy_0 = K2(DXSY, i, j), dxsy_p1 = K2(DXSY, i, j + 1);   // dx(i,q)+dx(i,q-1)
+  const double elb_m1 = elb_(i, j - 1), elb_0 = elb_(i, j), el_m1 = el_(i, j - 1), el_0 = el_(i, j);
+  const double art_m1 = F2(art, i, j - 1), art_0 = F2(art, i, j), vfl_m1 = F2(vfluxf, i, j - 1), vfl_0 = F2(vfluxf, i, j);
+  const double fsm_m1 = F2(fsm, i, j - 1), fsm_0 = F2(fsm, i, j);
+  const double ea_m1 = F2(e_atmos, i, j - 1), ea_0 = F2(e_atmos, i, j), h_m1 = F2(h, i, j - 1), h_0 = F2(h, i, j);
+  const double cor_m1 = F2(cor, i, j - 1), cor_0 = F2(cor, i, j);
+  const double adx2d = F2(adx2d, i, j), advua = F2(advua, i, j), aru = F2(aru, i, j), drx2d = F2(drx2d, i, j);
+  const double wusurf = F2(wusurf, i, j), wubot = F2(wubot, i, j), uab = uab_(i, j);
+  const double ady2d = F2(ady2d, i, j), advva = F2(advva, i, j), arv = F2(arv, i, j), dry2d = F2(dry2d, i, j);
+  const double wvsurf = F2(wvsurf, i, j), wvbot = F2(wvbot, i, j), vab = vab_(i, j);
+  // ---- neighbour-lane operands
+  // d(i-1) feeds this lane's own x-flux and through it ec, which the east neighbour takes as its ew:
+  // the west halo lane needs the true value too, so lane 0 loads it (lane_w) instead of shuffling
+  const double dW_0 = lane_w(d_0, [&] { return d_(iw, j); }), dW_m1 = lane_w(d_m1, [&] { return d_(iw, j - 1); });
+  const double corW_0 = WS(cor_0, F2(cor, iw, j)), vaW_0 = WS(va_0, va_(iw, j)), vaW_p1 = WS(va_p1, va_(iw, j + 1));
+  const double elW_0 = WS(el_0, el_(iw, j)), elbW_0 = WS(elb_0, elb_(iw, j)), eaW_0 = WS(ea_0, F2(e_atmos, iw, j)), hW_0 = WS(h_0, F2(h, iw, j));
+  const double uaE_0 = ES(ua_0, ua_(ie, j)), uaE_m1 = ES(ua_m1, ua_(ie, j - 1));
+  // ---- continuity (advance.f:211-231) at (i,j) and (i,j-1); the west value from the neighbour lane
+  const double fua_0 = .25 * (d_0 + dW_0) * dysx_0 * ua_0, fua_m1 = .25 * (d_m1 + dW_m1) * dysx_m1 * ua_m1;
+  const double fuaE_0 = ES(fua_0, flux_ua(P, ie, j)), fuaE_m1 = ES(fua_m1, flux_ua(P, ie, j - 1));
+  const double fva_m1 = .25 * (d_m1 + d_m2) * dxsy_m1 * va_m1, fva_0 = .25 * (d_0 + d_m1) * dxsy_0 * va_0,
+               fva_p1 = .25 * (d_p1 + d_0) * dxsy_p1 * va_p1;
+  const double ec = (elb_0 + P.dte2 * (-(fuaE_0 - fua_0 + fva_p1 - fva_0) / art_0 - vfl_0)) * fsm_0;
+  const double es = (elb_m1 + P.dte2 * (-(fuaE_m1 - fua_m1 + fva_0 - fva_m1) / art_m1 - vfl_m1)) * fsm_m1;
+  const double ew = WS(ec, elf_at(P, iw, j));
+#undef WS
+#undef ES
+  if (!out) return;
+  // ---- momentum (:237-290), as uaf_interior / vaf_interior
+  double u = adx2d + advua - aru * .25 * (cor_0 * d_0 * (va_p1 + va_0) + corW_0 * dW_0 * (vaW_p1 + vaW_0)) +
+             .25 * P.grav * dysx_0 * (d_0 + dW_0) *
+                 ((1. - 2. * P.alpha) * (el_0 - elW_0) + P.alpha * (elb_0 - elbW_0 + ec - ew) + ea_0 - eaW_0) +
+             drx2d + aru * (wusurf - wubot);
+  u = ((h_0 + elb_0 + hW_0 + elbW_0) * aru * uab - 4. * P.dte * u) / ((h_0 + ec + hW_0 + ew) * aru);
+  double v = ady2d + advva + arv * .25 * (cor_0 * d_0 * (uaE_0 + ua_0) + cor_m1 * d_m1 * (uaE_m1 + ua_m1)) +
+             .25 * P.grav * dxsy_0 * (d_0 + d_m1) *
+                 ((1. - 2. * P.alpha) * (el_0 - el_m1) + P.alpha * (elb_0 - elb_m1 + ec - es) + ea_0 - ea_m1) +
+             dry2d + arv * (wvsurf - wvbot);
+  v = ((h_0 + elb_0 + h_m1 + elb_m1) * arv * vab - 4. * P.dte * v) / ((h_0 + ec + h_m1 + es) * arv);
+  u = u * F2(dum, i, j);
+  v = v * F2(dvm, i, j);
   if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
-  ext_update_cell(P, i, j, true, ec, u, v, ew, es);
+  // ---- etf weights, Asselin filter, time rotation, accumulation (:295-347), as ext_update_cell
+  if (P.iext == P.isplit - 2) F2(etf, i, j) = .25 * P.smoth * ec;
+  else if (P.iext == P.isplit - 1) F2(etf, i, j) = F2(etf, i, j) + .5 * (1. - .5 * P.smoth) * ec;
+  else if (P.iext == P.isplit) F2(etf, i, j) = (F2(etf, i, j) + .5 * ec) * fsm_0;
+  F2(uab, i, j) = ua_0 + .5 * P.smoth * (uab - 2. * ua_0 + u);
+  F2(vab, i, j) = va_0 + .5 * P.smoth * (vab - 2. * va_0 + v);
+  Y2(elb, i, j) = el_0 + .5 * P.smoth * (elb_0 - 2. * el_0 + ec);
+  Y2(el, i, j) = ec;
+  const double dn = h_0 + ec;
+  Y2(d, i, j) = dn;
+  Y2(ua, i, j) = u;
+  Y2(va, i, j) = v;
+  if (P.iext != P.isplit) {
+    F2(egf, i, j) = F2(egf, i, j) + ec * P.ispi;
+    F2(utf, i, j) = F2(utf, i, j) + u * (dn + (hW_0 + ew)) * P.isp2i;
+    F2(vtf, i, j) = F2(vtf, i, j) + v * (dn + (h_m1 + es)) * P.isp2i;
+  }
 }
 __global__ void k_ext_step_rim(KP P, int store_f) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -556,7 +626,7 @@ void launch_ext_uvaf(pomgpu_ctx *c, int interior) { LAUNCH(c, k_ext_uvaf, grid2(
 void launch_ext_update(pomgpu_ctx *c) { LAUNCH(c, k_ext_update, grid2(c->P), blk2(), c->P); }
 // Q: c->P with y2 pointing at the next-generation buffers
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f) {
-  LAUNCH(c, k_ext_step, grid2(Q), blk2(), Q, store_f);
+  LAUNCH(c, k_ext_step, grid2_halo(Q), blk2(), Q, store_f);
   const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
   LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
 }
