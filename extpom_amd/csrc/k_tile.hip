@@ -472,6 +472,80 @@ __global__ void __launch_bounds__(256) k_advct_col(KP P) {
   if (out) { F3(advx, i, j, kb) = 0.; F3(advy, i, j, kb) = 0.; }
 }
 
+// ---- advu + advv in one pass -- solver.f:734-788, :791-845 --------------------------------------------
+// The two leapfrog steps share w, u, v: read together they cost 9 array reads + 2 writes instead of
+// 2 x (7 + 1) through the fused solve kernels of k_vert.hip, and the tridiagonal solves that follow
+// (k_profuv_reg) then need only their right-hand side and km.  Column-marching, halo-lane wavefronts:
+// the level loop carries the vertical fluxes, the (i-1) / (i+1) operands are neighbour-lane values.
+// Columns outside the interior get the reference's left-over vertical flux (:744-751, :801-808).
+struct LevUV { double w_c, w_s, u_c, v_c, u_s, v_n, ub, vb, advx, advy, drhox, drhoy; };   // w, u_c, v_c at level k+1; the rest at k
+__device__ __forceinline__ LevUV advuv_load(const KP &P, int i, int js, int j, int jn, int k) {
+  LevUV L;
+  L.w_c = F3(w, i, j, k + 1);  L.w_s = F3(w, i, js, k + 1); L.u_c = F3(u, i, j, k + 1); L.v_c = F3(v, i, j, k + 1);
+  L.u_s = F3(u, i, js, k);     L.v_n = F3(v, i, jn, k);
+  L.ub = F3(ub, i, j, k);      L.vb = F3(vb, i, j, k);
+  L.advx = F3(advx, i, j, k);  L.advy = F3(advy, i, j, k);  L.drhox = F3(drhox, i, j, k); L.drhoy = F3(drhoy, i, j, k);
+  return L;
+}
+__global__ void __launch_bounds__(256) k_advuv_col(KP P) {
+  HALO_XCD_DECODE
+  if (j > P.jm) return;                                     // whole wavefront (one row)
+  const bool out = (lane >= 1 && lane <= 62 && i0 <= P.im);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
+  const bool in = out && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  const int kb = P.kb, kbm1 = P.kbm1;
+  // column-resident coefficients
+  const double aru = F2(aru, i, j), arv = F2(arv, i, j);
+  const double dt_c = F2(dt, i, j), dt_w = F2(dt, iw, j), dt_s = F2(dt, i, js);
+  const double cd_c = F2(cor, i, j) * dt_c, cd_s = F2(cor, i, js) * dt_s;                  // cor*dt of this column and of (i,j-1)
+  const double hcu = P.grav * .125 * (dt_c + dt_w) *
+                     (F2(egf, i, j) - F2(egf, iw, j) + F2(egb, i, j) - F2(egb, iw, j) + (F2(e_atmos, i, j) - F2(e_atmos, iw, j)) * 2.) *
+                     (F2(dy, i, j) + F2(dy, iw, j));                                          // :765-770
+  const double hcv = P.grav * .125 * (dt_c + dt_s) *
+                     (F2(egf, i, j) - F2(egf, i, js) + F2(egb, i, j) - F2(egb, i, js) + (F2(e_atmos, i, j) - F2(e_atmos, i, js)) * 2.) *
+                     (F2(dx, i, j) + F2(dx, i, js));                                          // :822-827
+  const double hb = F2(h, i, j) + F2(etb, i, j), hf = F2(h, i, j) + F2(etf, i, j);
+  const double sau = (hb + F2(h, iw, j) + F2(etb, iw, j)) * aru, sdu = (hf + F2(h, iw, j) + F2(etf, iw, j)) * aru;   // :758, :781
+  const double sav = (hb + F2(h, i, js) + F2(etb, i, js)) * arv, sdv = (hf + F2(h, i, js) + F2(etf, i, js)) * arv;   // :815, :838
+  double u_k = F3(u, i, j, 1), v_k = F3(v, i, j, 1);       // u, v of this column at level k
+  double fu_k = 0., fv_k = 0.;                              // vertical fluxes at level k (0 at the surface)
+  LevUV c = advuv_load(P, i, js, j, jn, 1), nxt = c;
+  for (int k = 1; k <= kbm1; k++) {
+    if (k + 1 <= kbm1) nxt = advuv_load(P, i, js, j, jn, k + 1);
+    const double w_w = halo_w(c.w_c, [&] { return F3(w, iw, j, k + 1); });
+    const double tc = cd_c * (c.v_n + v_k);                                                 // cor*dt*(v(i,j+1,k)+v(i,j,k))
+    const double tw = halo_w(tc, [&] { return F2(cor, iw, j) * F2(dt, iw, j) * (F3(v, iw, jn, k) + F3(v, iw, j, k)); });
+    const double u_e = halo_e(u_k, [&] { return F3(u, ie, j, k); });
+    const double u_se = halo_e(c.u_s, [&] { return F3(u, ie, js, k); });
+    // vertical fluxes at level k+1 (:744-751, :801-808); zero below kbm1, and where the column has no west / south neighbour
+    double fu_n = 0., fv_n = 0.;
+    if (k + 1 <= kbm1) {
+      if (i >= 2) fu_n = .25 * (c.w_c + w_w) * (c.u_c + u_k);
+      if (j >= 2) fv_n = .25 * (c.w_c + c.w_s) * (c.v_c + v_k);
+    }
+    if (out) {
+      double ru = fu_k, rv = fv_k;                                                          // outside the interior: the flux itself
+      if (in) {
+        ru = (sau * c.ub - 2. * P.dti2 * (c.advx + (fu_k - fu_n) * aru / F1(dz, k) - aru * .25 * (tc + tw) + hcu + c.drhox)) / sdu;   // :758-782
+        rv = (sav * c.vb -
+              2. * P.dti2 * (c.advy + (fv_k - fv_n) * arv / F1(dz, k) + arv * .25 * (cd_c * (u_e + u_k) + cd_s * (u_se + c.u_s)) + hcv + c.drhoy)) /
+             sdv;                                                                           // :815-839
+      }
+      F3(uf, i, j, k) = ru;
+      F3(vf, i, j, k) = rv;
+    }
+    fu_k = fu_n; fv_k = fv_n;
+    u_k = c.u_c; v_k = c.v_c;
+    c = nxt;
+  }
+  if (out) { F3(uf, i, j, kb) = 0.; F3(vf, i, j, kb) = 0.; }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 void launch_coef_static(pomgpu_ctx *c) { LAUNCH(c, k_coef_static, grid2(c->P), blk2(), c->P); }
 void launch_coef_dt(pomgpu_ctx *c) { LAUNCH(c, k_coef_dt, grid2(c->P), blk2(), c->P); }
@@ -492,6 +566,7 @@ void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *q
 void launch_advct_col(pomgpu_ctx *c) {
   LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P);
 }
+void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk2(), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);
   else LAUNCH(c, k_advt2_col, grid1_halo(c->P), blk2(), c->P, fb, f, fc, ff);

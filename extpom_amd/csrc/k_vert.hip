@@ -657,6 +657,119 @@ __global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// profu / profv with the elimination vectors in registers (see k_proft_reg): the right-hand side is
+// uf / vf as left by k_advuv_col.  V = 0: profu, the km average runs over (i-1,j) and the west value
+// is the neighbour lane's (halo-lane wavefronts);  V = 1: profv, (i,j-1) needs a second load per level.
+// Phase A loads the whole column into the future ee/gg registers, phase B is the forward
+// elimination (solver.f:1712-1745 / :1810-1843), phase C the bottom value and back substitution.
+template <int KBT, int V>
+__global__ void __launch_bounds__(128) k_profuv_reg(KP P) {
+  const int j = TID_J;
+  if (j > P.jm) return;
+  int i0, lane = 1;
+  if (V) { i0 = TID_I; } else { lane = HALO_LANE; i0 = HALO_COL; }
+  const bool out = (lane >= 1 && lane <= 62 && i0 >= 2 && i0 <= P.imm1 && j >= 2 && j <= P.jmm1);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#else
+  if (V && !out) return;                                    // profv has no cross-lane traffic
+  if (j < 2 || j > P.jmm1) return;                          // wave-uniform
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
+  const int iw = i > 1 ? i - 1 : 1, js = j > 1 ? j - 1 : 1;
+  const int in_ = V ? i : iw, jn_ = V ? js : j;            // the second column of the averages
+  double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.n3;
+  // per-level accesses as (uniform plane pointer)[32-bit column offset]: the plane pointer is scalar, so
+  // the ~2*KBT loads of phase A share ONE offset register instead of holding a 64-bit address each
+  // (32-bit BYTE offsets: the form the compiler maps onto the scalar-base + vector-offset addressing mode)
+  const unsigned col = 8u * (unsigned)((j - 1) * P.iml + (i - 1)), col2 = 8u * (unsigned)((js - 1) * P.iml + (i - 1));
+  const double *kmp = P.b3 + (size_t)P3_km * P.n3;
+#define PLANE(ptr, k, off) (*(double *)((char *)((ptr) + (size_t)((k)-1) * P.n2) + (off)))
+  const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
+  double ee[KBT], gg[KBT];
+#define KC(k) ((k) < kbm1 ? (k) : kbm1)
+#define KCB(k) ((k) < kb ? (k) : kb)
+  // ---- phase A: all loads.  km(k) -> ee[k-1]; its partner column -> the neighbour lane (V = 0) or,
+  // for V = 1, gg[k-1] for a moment; then ee[k-1] = averaged km (:1705-1710 / :1803-1808) and
+  // rhs(k) -> gg[k-1].  Two register arrays in total.
+#pragma unroll
+  for (int k = 1; k <= KBT; k++) ee[k - 1] = PLANE(kmp, KCB(k), col);
+  if (V) {
+#pragma unroll
+    for (int k = 1; k <= KBT; k++) gg[k - 1] = PLANE(kmp, KCB(k), col2);
+  } else {
+#pragma unroll
+    for (int k = 1; k <= KBT - 1; k++) gg[k - 1] = PLANE(f, KC(k), col);
+  }
+  const double rhs_b = G3(f, i, j, kbm1);
+  const double dh = V ? .5 * (F2(h, i, j) + F2(etf, i, j) + F2(h, i, js) + F2(etf, i, js))
+                      : (F2(h, i, j) + F2(etf, i, j) + F2(h, iw, j) + F2(etf, iw, j)) * .5;
+  const double wsurf = V ? F2(wvsurf, i, j) : F2(wusurf, i, j);
+  const double m = V ? F2(dvm, i, j) : F2(dum, i, j);
+  const double cb2 = F2(cbc, i, j) + F2(cbc, in_, jn_);
+  double tps;
+  if (V) tps = 0.5 * cb2 * sqrt(sq(.25 * (F3(ub, i, j, kbm1) + F3(ub, i + 1, j, kbm1) + F3(ub, i, js, kbm1) + F3(ub, i + 1, js, kbm1))) +
+                                sq(F3(vb, i, j, kbm1)));
+  else tps = 0.5 * cb2 * sqrt(sq(F3(ub, i, j, kbm1)) +
+                              sq(.25 * (F3(vb, i, j, kbm1) + F3(vb, i, j + 1, kbm1) + F3(vb, iw, j, kbm1) + F3(vb, iw, j + 1, kbm1))));
+  SCHED_FENCE();
+#pragma unroll
+  for (int k = 1; k <= KBT; k++) {
+    ee[k - 1] = (ee[k - 1] + (V ? gg[k - 1] : halo_w(ee[k - 1], [&] { return F3(km, iw, j, KCB(k)); }))) * .5;
+    if (!V && (k & 3) == 0) SCHED_FENCE();                  // or the scheduler forms all lane shifts first: +KBT live doubles
+  }
+  if (V) {
+    SCHED_FENCE();
+#pragma unroll
+    for (int k = 1; k <= KBT - 1; k++) gg[k - 1] = PLANE(f, KC(k), col);
+  }
+  SCHED_FENCE();
+  // ---- phase B: forward elimination; ee[k-1] holds the averaged km of level k until level k overwrites it
+#define KMA(k) ee[(k)-1]
+  double km_c = KMA(1), km_n = KMA(2);
+  double e_prev, g_prev;
+  {
+    const double a = -P.dti2 * (km_n + P.umol) / (F1(dz, 1) * F1(dzz, 1) * dh * dh);
+    e_prev = a / (a - 1.);
+    g_prev = (-P.dti2 * wsurf / (-F1(dz, 1) * dh) - gg[0]) / (a - 1.);
+    ee[0] = e_prev; gg[0] = g_prev;
+  }
+  double e_last = e_prev, g_last = g_prev, km_last = km_n;   // ee, gg of level kbm2 and the averaged km of level kbm1
+#pragma unroll
+  for (int k = 2; k <= KBT - 2; k++) {
+    km_c = km_n;
+    km_n = KMA(k + 1);
+    const double a = -P.dti2 * (km_n + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC(k)) * dh * dh);
+    const double c = -P.dti2 * (km_c + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC(k - 1)) * dh * dh);
+    const double g = 1. / (a + c * (1. - e_prev) - 1.);
+    e_prev = a * g;
+    g_prev = (c * g_prev - gg[k - 1]) * g;
+    ee[k - 1] = e_prev; gg[k - 1] = g_prev;
+    const bool fin = (k == kbm2);
+    e_last = fin ? e_prev : e_last;
+    g_last = fin ? g_prev : g_last;
+    km_last = fin ? km_n : km_last;
+  }
+#undef KMA
+  if (!out) return;
+  // ---- phase C -- :1747-1777 / :1845-1874
+  const double c = -P.dti2 * (km_last + P.umol) / (F1(dz, kbm1) * F1(dzz, kbm2) * dh * dh);
+  double x = (c * g_last - rhs_b) / (tps * P.dti2 / (-F1(dz, kbm1) * dh) - 1. - (e_last - 1.) * c);
+  x = x * m;
+  G3(f, i, j, kbm1) = x;
+  if (V) F2(wvbot, i, j) = -tps * x; else F2(wubot, i, j) = -tps * x;
+#pragma unroll
+  for (int ki = KBT - 2; ki >= 1; ki--) {
+    const double xn = (ee[ki - 1] * x + gg[ki - 1]) * m;
+    if (ki <= kbm2) { x = xn; PLANE(f, ki, col) = x; }
+  }
+  F2(tps, i, j) = tps;
+#undef KC
+#undef KCB
+#undef PLANE
+}
+
+// ---------------------------------------------------------------------------------------------
 // column-mean-free Asselin filter of u,v and time rotation -- advance.f:469-514
 __global__ void k_uv_filter(KP P) {
   COL2
@@ -718,4 +831,21 @@ void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *
 }
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advu_profu, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advv_profv, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
+template <int KBT> static void launch_profuv_reg_t(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  LAUNCHN(c, "k_profu_reg", (k_profuv_reg<KBT, 0>), dim3((P.iml + 61) / 62, (P.jml + 1) / 2, 1), colblk(), c->P);
+  LAUNCHN(c, "k_profv_reg", (k_profuv_reg<KBT, 1>), colgrid(P), colblk(), c->P);
+}
+int launch_profuv_reg(pomgpu_ctx *c) {
+  const int kb = c->P.kb;
+  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) return 0;
+  if (kb <= 24) launch_profuv_reg_t<24>(c);
+  else if (kb <= 32) launch_profuv_reg_t<32>(c);
+  else if (kb <= 40) launch_profuv_reg_t<40>(c);
+  else if (kb <= 44) launch_profuv_reg_t<44>(c);
+  else if (kb <= 50) launch_profuv_reg_t<50>(c);
+  else if (kb <= 56) launch_profuv_reg_t<56>(c);
+  else launch_profuv_reg_t<64>(c);
+  return 1;
+}
 void launch_uv_filter(pomgpu_ctx *c) { LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P); }

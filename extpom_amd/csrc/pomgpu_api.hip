@@ -643,8 +643,13 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       if (rc) return rc;
       launch_ts_update(c, fold, fnew, k.nadv == 2);           // :444-454 in one pass
     }
-    launch_advu_profu(c, 1, 1);                               // :459-462
-    launch_advv_profv(c, 1, 1);
+    if (c->P.kb >= 6 && c->P.kb <= 64 && !getenv("POMGPU_THOMAS_SCRATCH")) {
+      launch_advuv_col(c);                                    // :459-460 advu, advv in one pass
+      launch_profuv_reg(c);                                   // :461-462 profu, profv with register-resident elimination vectors
+    } else {
+      launch_advu_profu(c, 1, 1);                             // :459-462
+      launch_advv_profv(c, 1, 1);
+    }
     xch(c, 2, D2(c, wubot), 1, D2(c, wvbot), 1);              // solver.f:1777, :1874
     launch_bcondorl3(c);                                      // :464
     xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);          // :466-467

@@ -85,12 +85,33 @@ static_assert(C2__count <= POMGPU_NCOEF2, "raise POMGPU_NCOEF2");
 // value its western / eastern neighbour lane holds replaces a second global load of the same word.
 // The two edge lanes of the wavefront have no such neighbour and evaluate `fb` (a load or a
 // recomputation) instead.  Every lane of the wavefront must reach the call.
+// Whole-wavefront shift by one lane as two DPP moves (wave_shr:1 / wave_shl:1, GFX9 encodings 0x138 /
+// 0x130): a plain VALU operation, no trip through the LDS crossbar as with __shfl_up/__shfl_down
+// (ds_bpermute), so no lgkmcnt wait and no batch of live results.  Edge lanes keep their own value,
+// exactly as the shuffles do (tools/micro/dpp_shift.hip checks both on the device).
+#ifndef POMGPU_EMU
+__device__ __forceinline__ double wave_up1(double x) {      // lane n <- lane n-1
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_dn1(double x) {      // lane n <- lane n+1
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#else
+static inline double wave_up1(double x) { return x; }
+static inline double wave_dn1(double x) { return x; }
+#endif
 template <class F> __device__ __forceinline__ double lane_w(double x, F fb) {
-  const double t = __shfl_up(x, 1, 64);
+  const double t = wave_up1(x);
   return (threadIdx.x == 0) ? fb() : t;
 }
 template <class F> __device__ __forceinline__ double lane_e(double x, F fb) {
-  const double t = __shfl_down(x, 1, 64);
+  const double t = wave_dn1(x);
   return (threadIdx.x == blockDim.x - 1) ? fb() : t;
 }
 
@@ -102,8 +123,8 @@ template <class F> __device__ __forceinline__ double lane_e(double x, F fb) {
 template <class F> __device__ __forceinline__ double halo_w(double, F fb) { return fb(); }
 template <class F> __device__ __forceinline__ double halo_e(double, F fb) { return fb(); }
 #else
-template <class F> __device__ __forceinline__ double halo_w(double x, F) { return __shfl_up(x, 1, 64); }
-template <class F> __device__ __forceinline__ double halo_e(double x, F) { return __shfl_down(x, 1, 64); }
+template <class F> __device__ __forceinline__ double halo_w(double x, F) { return wave_up1(x); }
+template <class F> __device__ __forceinline__ double halo_e(double x, F) { return wave_dn1(x); }
 #endif
 // nothing may be scheduled across this point (keeps a block of prefetch loads together and early)
 #ifdef POMGPU_EMU
@@ -220,6 +241,8 @@ void launch_advave_b(pomgpu_ctx *c);
 void launch_advave_c(pomgpu_ctx *c);
 void launch_advave_fused(pomgpu_ctx *c);
 void launch_advct_col(pomgpu_ctx *c);
+void launch_advuv_col(pomgpu_ctx *c);
+int launch_profuv_reg(pomgpu_ctx *c);   // 0 when kb is outside the instantiated range
 void launch_advave_m2a(pomgpu_ctx *c);
 void launch_advave_m2b(pomgpu_ctx *c);
 void launch_vint(pomgpu_ctx *c);
