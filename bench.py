@@ -44,7 +44,7 @@ KERNEL_PASSES = {
     "k_advct_col": 7,        # a2, one tile: R u,v,ub,vb,aam W advx,advy
     "k_advq_col": 7,         # a9, one tile: R q,qb,u,v,w,aam W qf
     "k_advt2_col": 7,        # a13: R fb,fclim,u,v,w,aam W ff
-    "k_ts_update": 22,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,6 restore fields W t,tb,s,sb,rho,3 restore fields
+    "k_ts_update": 19,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,6 restore fields W t,tb,s,sb,rho
     "k_profq_prod": 9,       # R km,kh,t,s,rho,u,v (+1 k-shifted reuse counted once) W prod  -> 7R+1W (+1)
     "k_advq_flux": 7,        # a9 first half: R q,qb,u,v,aam W xflux,yflux
     "k_advq_step": 6,        # a9 second half: R q,qb,w,xflux,yflux W qf
@@ -56,6 +56,9 @@ KERNEL_PASSES = {
     "k_uv_filter": 10,       # a19: R uf,ub,u,vf,vb,v W ub,u,vb,v
     "k_proft": 3,            # a14: R f,kh W f
     "k_proft_reg": 3,
+    "k_profu_reg": 3,        # a18: R uf,km W uf
+    "k_profv_reg": 3,
+    "k_advuv_col": 11,       # a17: R w,u,v,ub,vb,advx,advy,drhox,drhoy W uf,vf
     "k_aam_pair": 3,
     "k_realvertvl_col": 4,
     "k_ts_filter": 10,       # a15: R uf,vf,t,tb,s,sb W tb,t,sb,s (+uf,vf masks)

@@ -208,10 +208,15 @@ __device__ __forceinline__ void c_q_filter(const KP &P, const int i, const int j
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
   if (mask && i <= P.im && j <= P.jm) {
     const double m = F2(fsm, i, j);
-    uf = uf * m + 1.e-10;
+    uf = uf * m + 1.e-10;                                  // bcond(6)
     vf = vf * m + 1.e-10;
-    F3(uf, i, j, k) = uf;
-    F3(vf, i, j, k) = vf;
+    // stored only where somebody still reads them: advt1/advt2 write the interior of levels 1..kbm1
+    // and leave the rim columns and level kb of uf, vf as they are (solver.f:577-731) -- those
+    // left-overs flow on into t, s.  Everywhere else the next writer replaces the value unread.
+    if (k == P.kb || i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) {
+      F3(uf, i, j, k) = uf;
+      F3(vf, i, j, k) = vf;
+    }
   }
   const double q = F3(q2, i, j, k), ql = F3(q2l, i, j, k);
   F3(q2b, i, j, k) = q + .5 * P.smoth * (uf + F3(q2b, i, j, k) - 2. * q);
@@ -459,14 +464,14 @@ __device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int 
 // mode_internal, tracer tail in ONE pass (nadv=2 path): the in-place round trips of advt2 on tb/sb
 // (solver.f:691,715), bcond(4)'s mask (bounds_forcing.f:233-240), the Asselin filter and rotation of
 // t,s (advance.f:444-449), restore_interior's interpolation, relaxation and mask
-// (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 8 writes per cell instead
+// (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 5 writes per cell instead
 // of the 38 array passes of the five separate kernels.
 __device__ __forceinline__ double dens_point(const KP &P, double si, double ti, int i, int j, int k);
-__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt);
-__global__ void k_ts_update(KP P, double fold, double fnew, int rt) {
-  MARCH3(c_ts_update(P, i, j, k, fold, fnew, rt))
+__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst);
+__global__ void k_ts_update(KP P, double fold, double fnew, int rt, int store_rst) {
+  MARCH3(c_ts_update(P, i, j, k, fold, fnew, rt, store_rst))
 }
-__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt) {
+__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst) {
   const bool act = (i <= P.im && j <= P.jm), lev = (k <= P.kbm1);
   const double m = F2(fsm, i, j);
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
@@ -489,9 +494,11 @@ __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int 
       const double tr = fold * F3(trstrb, i, j, k) + fnew * F3(trstrf, i, j, k);
       const double sr = fold * F3(srstrb, i, j, k) + fnew * F3(srstrf, i, j, k);
       const double ta = fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
-      F3(trstr, i, j, k) = tr;
-      F3(srstr, i, j, k) = sr;
-      F3(taurstr, i, j, k) = ta;
+      if (store_rst) {                                                 // else left to k_restore_fields (on demand)
+        F3(trstr, i, j, k) = tr;
+        F3(srstr, i, j, k) = sr;
+        F3(taurstr, i, j, k) = ta;
+      }
       const double c = 2. * P.dti / 86400.;
       tn = tn + c * ta * (tr - tn);
       tbn = tbn + c * ta * (tr - tbn);
@@ -560,6 +567,19 @@ __device__ __forceinline__ void c_restore(const KP &P, const int i, const int j,
   F3(tb, i, j, k) = tb * m;
   F3(s, i, j, k) = s * m;
   F3(sb, i, j, k) = sb * m;
+}
+// the interpolated restoring fields alone (bounds_forcing.f:1090-1098).  Inside pomgpu_advance nothing
+// reads trstr, srstr, taurstr, so k_ts_update does not write them; this kernel materialises them from
+// the last step's weights before anybody can look (downloads, stand-alone entry points).
+__device__ __forceinline__ void c_restore_fields(const KP &P, const int i, const int j, const int k, double fold, double fnew);
+__global__ void k_restore_fields(KP P, double fold, double fnew) {
+  MARCH3(c_restore_fields(P, i, j, k, fold, fnew))
+}
+__device__ __forceinline__ void c_restore_fields(const KP &P, const int i, const int j, const int k, double fold, double fnew) {
+  if (k > P.kbm1 || i > P.im || j > P.jm) return;
+  F3(trstr, i, j, k) = fold * F3(trstrb, i, j, k) + fnew * F3(trstrf, i, j, k);
+  F3(srstr, i, j, k) = fold * F3(srstrb, i, j, k) + fnew * F3(srstrf, i, j, k);
+  F3(taurstr, i, j, k) = fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
 }
 // trstrb = trstrf etc. for k <= kbm1 (bounds_forcing.f:1056-1064)
 __device__ __forceinline__ void c_restore_shift(const KP &P, const int i, const int j, const int k);
@@ -849,7 +869,10 @@ void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double
 void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   LAUNCH(c, k_advt2_fused, gridm(c->P), blk2(), c->P, fb, f, fc, ff);
 }
-void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt) { LAUNCH(c, k_ts_update, gridm(c->P), blk2(), c->P, fold, fnew, rt); }
+void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst) {
+  LAUNCH(c, k_ts_update, gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst);
+}
+void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore_fields, gridm(c->P), blk2(), c->P, fold, fnew); }
 void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, gridm(c->P), blk2(), c->P, mask); }
 void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, gridm(c->P), blk2(), c->P); }
 void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, gridm(c->P), blk2(), c->P); }

@@ -137,6 +137,12 @@ static void ext_buffers(pomgpu_ctx *c) {
   KP &P = c->P;
   for (int n = 0; n < 5; n++) P.x2[n] = P.y2[n] = c->ext_parity ? c->alt2[n] : P.b2 + (size_t)X2_SLOT[n] * P.n2;
 }
+// trstr, srstr, taurstr of the last internal step, if k_ts_update skipped them
+static void restore_materialize(pomgpu_ctx *c) {
+  if (!c->rst_pending) return;
+  c->rst_pending = 0;
+  launch_restore_fields(c, c->rst_fold, c->rst_fnew);
+}
 static void ext_canonical(pomgpu_ctx *c) {
   if (!c->ext_parity) return;
   KP &P = c->P;
@@ -208,6 +214,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
     return POMGPU_ENOMEM;
   }
   c->ext_parity = 0;
+  c->rst_pending = 0;
   ext_buffers(c);
   (void)hipStreamSynchronize(c->stream);
   *out = c;
@@ -284,6 +291,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   KP &P = c->P;
   HIPCHK(c, hipSetDevice(c->device));
   ext_canonical(c);
+  restore_materialize(c);
   if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
@@ -305,6 +313,7 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
   KP &P = c->P;
   HIPCHK(c, hipSetDevice(c->device));
   ext_canonical(c);
+  restore_materialize(c);
   if (b1) HIPCHK(c, hipMemcpyAsync(b1, P.b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyDeviceToHost, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(b2, P.b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyDeviceToHost, c->stream));
   if (b3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
@@ -322,7 +331,7 @@ static void refresh_coefs(pomgpu_ctx *c) {
   launch_coef_dt(c);
   launch_coef_eta(c);
 }
-#define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL; ext_canonical(c)
+#define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL; ext_canonical(c); restore_materialize(c)
 extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
@@ -353,7 +362,11 @@ extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) {
   ext_canonical(c);
   return SLOT2(c, s);
 }
-extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) { return (c && s >= 0 && s < POM_NBLK3D) ? SLOT3(c, s) : NULL; }
+extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) {
+  if (!c || s < 0 || s >= POM_NBLK3D) return NULL;
+  restore_materialize(c);
+  return SLOT3(c, s);
+}
 extern "C" int pomgpu_bind_host(pomgpu_ctx *c, const double *h2, const double *h3) {
   if (!c) return POMGPU_EINVAL;
   c->host2 = h2;
@@ -539,10 +552,11 @@ static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.
 }
 
 #define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
-#define NEED(c) NEED_RAW(c); ext_canonical(c)
+#define NEED_HOT(c) NEED_RAW(c); ext_canonical(c)            /* the entry points pomgpu_advance strings together */
+#define NEED(c) NEED_HOT(c); restore_materialize(c)
 
 extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
-  NEED(c);
+  NEED_HOT(c);
   pom_blkcon &k = c->con;
   k.time = k.dti * (double)(float)k.iint / 86400. + k.time0;
   if (k.iint >= k.iswtch) k.iprint = (int)lround(k.prtd2 * 24. * 3600. / k.dti);
@@ -552,7 +566,7 @@ extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
   return POMGPU_OK;
 }
 extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {      // advance.f:96-141
-  NEED(c);
+  NEED_HOT(c);
   KP &P = c->P;
   if (P.mode != 2) {
     seq_advct(c);
@@ -564,7 +578,7 @@ extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {      // advance.f:96-14
   return POMGPU_OK;
 }
 extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) {       // advance.f:144-202
-  NEED(c);
+  NEED_HOT(c);
   if (c->P.mode != 2) {
     launch_vint(c);
     seq_advave(c);
@@ -600,7 +614,7 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
 }
 extern "C" int pomgpu_mode_external(pomgpu_ctx *c) { return mode_external(c, 1); }
 extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
-  NEED(c);
+  NEED_HOT(c);
   KP &P = c->P;
   const pom_blkcon &k = c->con;
   if ((k.iint != 1 || k.time0 != 0.) && k.mode != 2) {
@@ -641,7 +655,8 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       double fold, fnew;
       int rc = restore_prepare(c, &fold, &fnew);              // :452 (record handling)
       if (rc) return rc;
-      launch_ts_update(c, fold, fnew, k.nadv == 2);           // :444-454 in one pass
+      launch_ts_update(c, fold, fnew, k.nadv == 2, 0);        // :444-454 in one pass; trstr/srstr/taurstr on demand
+      c->rst_pending = 1; c->rst_fold = fold; c->rst_fnew = fnew;
     }
     if (c->P.kb >= 6 && c->P.kb <= 64 && !getenv("POMGPU_THOMAS_SCRATCH")) {
       launch_advuv_col(c);                                    // :459-460 advu, advv in one pass
@@ -680,7 +695,7 @@ extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, in
   return POMGPU_OK;
 }
 extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
-  NEED(c);
+  NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
   if ((rc = pomgpu_lateral_viscosity(c))) return rc;
@@ -695,7 +710,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   return POMGPU_OK;
 }
 extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
-  NEED(c);
+  NEED_HOT(c);
   for (int n = 0; n < nsteps; n++) {
     c->con.iint += 1;
     int rc = pomgpu_advance(c);

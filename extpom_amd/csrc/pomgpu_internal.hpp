@@ -178,6 +178,8 @@ struct pomgpu_ctx {
   void *exch_user;
   double *alt2[5];           // second buffer set of ua, va, d, el, elb (fused external step)
   int ext_parity;            // 1 while the current generation of those five lives in alt2
+  int rst_pending;           // trstr/srstr/taurstr of the last step exist only as (rst_fold, rst_fnew) weights
+  double rst_fold, rst_fnew;
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
   int *d_err;                // device error flag
   // profiling
@@ -274,7 +276,8 @@ void launch_copy3(pomgpu_ctx *c, double *dst, const double *src);
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff);
 void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
 void launch_ts_filter(pomgpu_ctx *c, int mask);
-void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt);
+void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst);
+void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew);
 void launch_mask_ts(pomgpu_ctx *c);
 void launch_mask_uv(pomgpu_ctx *c);
 void launch_mask_w(pomgpu_ctx *c);
