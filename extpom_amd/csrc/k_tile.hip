@@ -370,7 +370,8 @@ __device__ double advct_xg_mem(const KP &P, int i, int j, int k) {              
   xg = xg - dtaam * ((F3(ub, i, j, k) - F3(ub, i, j - 1, k)) / dy4 + (F3(vb, i, j, k) - F3(vb, i - 1, j, k)) / K2(DX4, i, j));
   return .25 * dy4 * xg;
 }
-__global__ void __launch_bounds__(256) k_advct_col(KP P) {
+// sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
+__global__ void __launch_bounds__(256) k_advct_col(KP P, int sum2d) {
   HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
   if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
@@ -385,10 +386,13 @@ __global__ void __launch_bounds__(256) k_advct_col(KP P) {
   const bool in = out && iin && jrow;
   const int kb = P.kb, kbm1 = P.kbm1;
   if (!jrow) {                                              // rim rows: advx = advy = 0 (solver.f:211,:317)
-    if (out)
+    if (out) {
       for (int k = 1; k <= kb; k++) { F3(advx, i, j, k) = 0.; F3(advy, i, j, k) = 0.; }
+      if (sum2d) { F2(adx2d, i, j) = 0.; F2(ady2d, i, j) = 0.; }
+    }
     return;
   }
+  double ax2 = 0., ay2 = 0.;
   // column-resident coefficients
   const double dtsx_c = K2(DTSX, i, j), dtsx_s = K2(DTSX, i, js);
   const double dtsx_e = halo_e(dtsx_c, [&] { return K2(DTSX, ie, j); });
@@ -466,10 +470,16 @@ __global__ void __launch_bounds__(256) k_advct_col(KP P) {
       }
       F3(advx, i, j, k) = ax;
       F3(advy, i, j, k) = ay;
+      const double dzk = F1(dz, k);
+      ax2 = ax2 + ax * dzk;
+      ay2 = ay2 + ay * dzk;
     }
     c = nxt;
   }
-  if (out) { F3(advx, i, j, kb) = 0.; F3(advy, i, j, kb) = 0.; }
+  if (out) {
+    F3(advx, i, j, kb) = 0.; F3(advy, i, j, kb) = 0.;
+    if (sum2d) { F2(adx2d, i, j) = ax2; F2(ady2d, i, j) = ay2; }
+  }
 }
 
 // ---- advu + advv in one pass -- solver.f:734-788, :791-845 --------------------------------------------
@@ -563,8 +573,8 @@ static dim3 grid_rows(const KP &P) {
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
   LAUNCH(c, k_advq_col, grid1_halo(c->P), blk2(), c->P, q, qb, qf, zero_else);
 }
-void launch_advct_col(pomgpu_ctx *c) {
-  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P);
+void launch_advct_col(pomgpu_ctx *c, int sum2d) {
+  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P, sum2d);
 }
 void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk2(), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {

@@ -20,9 +20,23 @@
 // ---------------------------------------------------------------------------------------------
 // baropg -- solver.f:848-940.  The running vertical sum lives in a register; density anomalies
 // rho-rmean are formed on the fly (the reference subtracts rmean in place first, :854).
-__global__ void k_baropg(KP P) {
+// sum2d: also leave the vertical integrals drx2d, dry2d of advance.f:152-168 (k_vint)
+__global__ void k_baropg(KP P, int sum2d) {
   COL2
-  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) {
+    if (sum2d) {                                             // rim and padding columns: whatever drhox, drhoy hold there
+      double rx = 0., ry = 0.;
+      if (i <= P.im && j <= P.jm)
+        for (int k = 1; k <= P.kbm1; k++) {
+          const double dzk = F1(dz, k);
+          rx = rx + F3(drhox, i, j, k) * dzk;
+          ry = ry + F3(drhoy, i, j, k) * dzk;
+        }
+      F2(drx2d, i, j) = rx;
+      F2(dry2d, i, j) = ry;
+    }
+    return;
+  }
   const double dtc = dt_(i, j), dtw = dt_(i - 1, j), dts = dt_(i, j - 1);
   const double sx = .25 * (dtc + dtw), sy = .25 * (dtc + dts);
   const double mx = F2(dum, i, j), my = F2(dvm, i, j);
@@ -32,8 +46,12 @@ __global__ void k_baropg(KP P) {
   double rs0 = F3(rho, i, j - 1, 1) - F3(rmean, i, j - 1, 1);
   double ax = .5 * P.grav * (-F1(zz, 1)) * (dtc + dtw) * (rc0 - rw0);                       // :859-860
   double ay = .5 * P.grav * (-F1(zz, 1)) * (dtc + dts) * (rc0 - rs0);                       // :895-896
-  F3(drhox, i, j, 1) = P.ramp * (sx * ax * mx * ex);                                        // :883-885,931
-  F3(drhoy, i, j, 1) = P.ramp * (sy * ay * my * ey);
+  double ox = P.ramp * (sx * ax * mx * ex), oy = P.ramp * (sy * ay * my * ey);
+  F3(drhox, i, j, 1) = ox;                                                                  // :883-885,931
+  F3(drhoy, i, j, 1) = oy;
+  double rx = 0., ry = 0.;
+  rx = rx + ox * F1(dz, 1);
+  ry = ry + oy * F1(dz, 1);
   for (int k = 2; k <= P.kbm1; k++) {
     const double rc = F3(rho, i, j, k) - F3(rmean, i, j, k);
     const double rw = F3(rho, i - 1, j, k) - F3(rmean, i - 1, j, k);
@@ -43,10 +61,14 @@ __global__ void k_baropg(KP P) {
          P.grav * .25 * zp * (dtc - dtw) * (rc + rw - rc0 - rw0);                           // :867-875
     ay = ay + P.grav * .25 * zm * (dtc + dts) * (rc - rs + rc0 - rs0) +
          P.grav * .25 * zp * (dtc - dts) * (rc + rs - rc0 - rs0);                           // :903-911
-    F3(drhox, i, j, k) = P.ramp * (sx * ax * mx * ex);
-    F3(drhoy, i, j, k) = P.ramp * (sy * ay * my * ey);
+    ox = P.ramp * (sx * ax * mx * ex); oy = P.ramp * (sy * ay * my * ey);
+    F3(drhox, i, j, k) = ox;
+    F3(drhoy, i, j, k) = oy;
+    rx = rx + ox * F1(dz, k);
+    ry = ry + oy * F1(dz, k);
     rc0 = rc; rw0 = rw; rs0 = rs;
   }
+  if (sum2d) { F2(drx2d, i, j) = rx; F2(dry2d, i, j) = ry; }
   F3(drhox, i, j, P.kb) = P.ramp * F3(drhox, i, j, P.kb);                                   // :928-935, k=kb
   F3(drhoy, i, j, P.kb) = P.ramp * F3(drhoy, i, j, P.kb);
 }
@@ -800,7 +822,7 @@ __global__ void k_uv_filter(KP P) {
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 colblk() { return dim3(64, 2, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
-void launch_baropg(pomgpu_ctx *c) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P); }
+void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P, sum2d); }
 void launch_int_uvmean(pomgpu_ctx *c) { LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P); }
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }

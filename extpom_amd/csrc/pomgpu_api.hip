@@ -444,9 +444,9 @@ static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
     launch_advave_m2b(c);
   }
 }
-static void seq_advct(pomgpu_ctx *c) {                        // solver.f:201-408
+static void seq_advct(pomgpu_ctx *c, int sum2d = 0) {         // solver.f:201-408
   KP &P = c->P;
-  if (!c->exch) { launch_advct_col(c); return; }              // one tile: nothing to exchange, fluxes stay in registers
+  if (!c->exch) { launch_advct_col(c, sum2d); return; }       // one tile: nothing to exchange, fluxes stay in registers
   launch_advct_a(c);
   xch(c, 2, P.s3[0], P.kbm1, P.s3[1], P.kbm1);                // :229, :279
   launch_advct_b(c);
@@ -454,8 +454,8 @@ static void seq_advct(pomgpu_ctx *c) {                        // solver.f:201-40
   launch_advct_c(c);
   xch(c, 1, D3(c, advy), P.kb);                               // :405
 }
-static void seq_baropg(pomgpu_ctx *c) {                       // solver.f:848-940
-  launch_baropg(c);
+static void seq_baropg(pomgpu_ctx *c, int sum2d = 0) {        // solver.f:848-940
+  launch_baropg(c, sum2d);
   launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :854 + :937
 }
 static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair, int zero_else) {   // solver.f:411-477
@@ -565,22 +565,25 @@ extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
   sync_scalars(c);
   return POMGPU_OK;
 }
-extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {      // advance.f:96-141
+// sum2d (pomgpu_advance on one tile): advct and baropg leave the vertical integrals that mode_interaction
+// would otherwise gather by reading advx, advy, drhox, drhoy again (advance.f:152-168)
+static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-141
   NEED_HOT(c);
   KP &P = c->P;
   if (P.mode != 2) {
-    seq_advct(c);
-    if (P.npg == 1) seq_baropg(c);
+    seq_advct(c, sum2d);
+    if (P.npg == 1) seq_baropg(c, sum2d);
     else return fail(c, POMGPU_EINVAL, "Error: invalid value for npg (only npg=1 is built; baropg_mcc is a 'next' row)");
     launch_aam(c);
     xch(c, 1, D3(c, aam), P.kbm1);                            // :137
   }
   return POMGPU_OK;
 }
-extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) {       // advance.f:144-202
+extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) { return lateral_viscosity(c, 0); }
+static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-202
   NEED_HOT(c);
   if (c->P.mode != 2) {
-    launch_vint(c);
+    launch_vint(c, sums_done);
     seq_advave(c);
   }
   launch_modeint_tail(c);
@@ -612,6 +615,7 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
   return POMGPU_OK;
 }
+extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) { return mode_interaction(c, 0); }
 extern "C" int pomgpu_mode_external(pomgpu_ctx *c) { return mode_external(c, 1); }
 extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
   NEED_HOT(c);
@@ -698,8 +702,9 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
-  if ((rc = pomgpu_lateral_viscosity(c))) return rc;
-  if ((rc = pomgpu_mode_interaction(c))) return rc;
+  const int sum2d = (!c->exch && c->P.mode != 2 && c->P.npg == 1);
+  if ((rc = lateral_viscosity(c, sum2d))) return rc;
+  if ((rc = mode_interaction(c, sum2d))) return rc;
   for (int iext = 1; iext <= c->con.isplit; iext++) {
     c->con.iext = iext;
     if ((rc = mode_external(c, 0))) return rc;

@@ -242,12 +242,12 @@ void launch_advave_a(pomgpu_ctx *c);
 void launch_advave_b(pomgpu_ctx *c);
 void launch_advave_c(pomgpu_ctx *c);
 void launch_advave_fused(pomgpu_ctx *c);
-void launch_advct_col(pomgpu_ctx *c);
+void launch_advct_col(pomgpu_ctx *c, int sum2d);
 void launch_advuv_col(pomgpu_ctx *c);
 int launch_profuv_reg(pomgpu_ctx *c);   // 0 when kb is outside the instantiated range
 void launch_advave_m2a(pomgpu_ctx *c);
 void launch_advave_m2b(pomgpu_ctx *c);
-void launch_vint(pomgpu_ctx *c);
+void launch_vint(pomgpu_ctx *c, int only_aam);
 void launch_modeint_tail(pomgpu_ctx *c);
 void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
@@ -288,7 +288,7 @@ void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo
 void launch_realvertvl(pomgpu_ctx *c);
 void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v);
 // k_vert.hip
-void launch_baropg(pomgpu_ctx *c);
+void launch_baropg(pomgpu_ctx *c, int sum2d);
 void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
