@@ -251,11 +251,17 @@ __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const
 // neighbour-lane operands.  The reference exchanges xflux/yflux between the flux and the step
 // loops (:458-459); with all neighbours -1 that exchange is a no-op and the two halves fuse: the
 // fluxes never reach memory.  Used only when the context has no exchange hook (one tile).
-struct LevQ { double q_c, q_s, q_n, qb_c, qb_s, qb_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
-__device__ __forceinline__ LevQ advq_load(const KP &P, const double *q, const double *qb, int i, int js, int j, int jn, int k) {
-  LevQ L;
-  L.q_c = G3(q, i, j, k);    L.q_s = G3(q, i, js, k);    L.q_n = G3(q, i, jn, k);
-  L.qb_c = G3(qb, i, j, k);  L.qb_s = G3(qb, i, js, k);  L.qb_n = G3(qb, i, jn, k);
+// NF = 2 advances q2 and q2l in ONE pass (advance.f:407-408 calls advq twice): u, v, w, aam and every
+// face coefficient are read once for both -- 12.5 array passes instead of 2 x 9.5.
+struct QFields { const double *q[2], *qb[2]; double *qf[2]; };
+template <int NF> struct LevQ { double q_c[NF], q_s[NF], q_n[NF], qb_c[NF], qb_s[NF], qb_n[NF], am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
+template <int NF> __device__ __forceinline__ LevQ<NF> advq_load(const KP &P, const QFields &A, int i, int js, int j, int jn, int k) {
+  LevQ<NF> L;
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    L.q_c[f] = G3(A.q[f], i, j, k);    L.q_s[f] = G3(A.q[f], i, js, k);    L.q_n[f] = G3(A.q[f], i, jn, k);
+    L.qb_c[f] = G3(A.qb[f], i, j, k);  L.qb_s[f] = G3(A.qb[f], i, js, k);  L.qb_n[f] = G3(A.qb[f], i, jn, k);
+  }
   L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
   L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
   L.w_c = F3(w, i, j, k);
@@ -275,7 +281,8 @@ __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double 
   x = x - .25 * (am_hi_k + am_lo_k + am_hi_m + am_lo_m) * c.hs * (qb_hi - qb_lo) * c.msk / c.ds_den;
   return .5 * c.ds_num * x;
 }
-__global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const double *qb, double *qf, int zero_else) {
+template <int NF>
+__global__ void __launch_bounds__(256) k_advq_col(KP P, QFields A, int zero_else) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;
@@ -290,43 +297,53 @@ __global__ void __launch_bounds__(256) k_advq_col(KP P, const double *q, const d
   const CoefQ cw = coefq_x(P, i, j), cs = coefq_y(P, i, j), cn = coefq_y(P, i, jn);
   const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
   const int kb = P.kb, kbm1 = P.kbm1;
-  LevQ cur = advq_load(P, q, qb, i, js, j, jn, 1), nxt = cur, prv = cur;
+  LevQ<NF> cur = advq_load<NF>(P, A, i, js, j, jn, 1), nxt = cur;
+  double u_m = 0., v_m = 0., vn_m = 0., am_m = 0., ams_m = 0., amn_m = 0.;   // u, v, v(j+1), aam (c, s, n) of level L-1
   double am_w_prv = 0.;                       // aam(i-1,j,L-1) as seen by this lane
-  double wq_pp = 0., wq_p = 0.;               // w*q of levels L-2 and L-1
-  double xe_p = 0., xw_p = 0., yn_p = 0., ys_p = 0., qb_p = 0.;   // faces and qb of level L-1, waiting for w(L)*q(L)
+  double wq_pp[NF], wq_p[NF];                 // w*q of levels L-2 and L-1
+  double xe_p[NF], xw_p[NF], yn_p[NF], ys_p[NF], qb_p[NF];   // faces and qb of level L-1, waiting for w(L)*q(L)
+#pragma unroll
+  for (int f = 0; f < NF; f++) wq_pp[f] = wq_p[f] = xe_p[f] = xw_p[f] = yn_p[f] = ys_p[f] = qb_p[f] = 0.;
   for (int L = 1; L <= kb; L++) {
-    if (L + 1 <= kb) nxt = advq_load(P, q, qb, i, js, j, jn, L + 1);
+    if (L + 1 <= kb) nxt = advq_load<NF>(P, A, i, js, j, jn, L + 1);
     const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
-    double xe_c = 0., xw_c = 0., yn_c = 0., ys_c = 0.;
-    if (L >= 2 && L <= kbm1) {
-      const double q_w = halo_w(cur.q_c, [&] { return G3(q, iw, j, L); });
-      const double qb_w = halo_w(cur.qb_c, [&] { return G3(qb, iw, j, L); });
-      const double xw = advq_face(cw, cur.q_c, q_w, cur.u_c, prv.u_c, cur.am_c, am_w, prv.am_c, am_w_prv, cur.qb_c, qb_w);
-      xw_c = xw;
-      xe_c = halo_e(xw, [&] {                               // emulation only: the east face from memory
-        return advq_face(coefq_x(P, ie, j), G3(q, ie, j, L), cur.q_c, F3(u, ie, j, L), F3(u, ie, j, L - 1), F3(aam, ie, j, L), cur.am_c,
-                         F3(aam, ie, j, L - 1), prv.am_c, G3(qb, ie, j, L), cur.qb_c);
-      });
-      ys_c = advq_face(cs, cur.q_c, cur.q_s, cur.v_c, prv.v_c, cur.am_c, cur.am_s, prv.am_c, prv.am_s, cur.qb_c, cur.qb_s);
-      yn_c = advq_face(cn, cur.q_n, cur.q_c, cur.v_n, prv.v_n, cur.am_n, cur.am_c, prv.am_n, prv.am_c, cur.qb_n, cur.qb_c);
-    }
-    const double wq_c = cur.w_c * cur.q_c;
-    if (icol) {
-      const int k = L - 1;                                   // level completed in this iteration
-      if (in && k >= 2 && k <= kbm1) {
-        double r = (wq_pp - wq_c) * art / (F1(dz, k) + F1(dz, k - 1)) + xe_p - xw_p + yn_p - ys_p;   // :465-468
-        r = (hea * qb_p - P.dti2 * r) / hfa;                                                    // :469-471
-        G3(qf, i, j, k) = r;
-      } else if (zero_else && k >= 1) {
-        G3(qf, i, j, k) = 0.;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      double xe_c = 0., xw_c = 0., yn_c = 0., ys_c = 0.;
+      if (L >= 2 && L <= kbm1) {
+        const double q_w = halo_w(cur.q_c[f], [&] { return G3(A.q[f], iw, j, L); });
+        const double qb_w = halo_w(cur.qb_c[f], [&] { return G3(A.qb[f], iw, j, L); });
+        const double xw = advq_face(cw, cur.q_c[f], q_w, cur.u_c, u_m, cur.am_c, am_w, am_m, am_w_prv, cur.qb_c[f], qb_w);
+        xw_c = xw;
+        xe_c = halo_e(xw, [&] {                             // emulation only: the east face from memory
+          return advq_face(coefq_x(P, ie, j), G3(A.q[f], ie, j, L), cur.q_c[f], F3(u, ie, j, L), F3(u, ie, j, L - 1), F3(aam, ie, j, L), cur.am_c,
+                           F3(aam, ie, j, L - 1), am_m, G3(A.qb[f], ie, j, L), cur.qb_c[f]);
+        });
+        ys_c = advq_face(cs, cur.q_c[f], cur.q_s[f], cur.v_c, v_m, cur.am_c, cur.am_s, am_m, ams_m, cur.qb_c[f], cur.qb_s[f]);
+        yn_c = advq_face(cn, cur.q_n[f], cur.q_c[f], cur.v_n, vn_m, cur.am_n, cur.am_c, amn_m, am_m, cur.qb_n[f], cur.qb_c[f]);
       }
+      const double wq_c = cur.w_c * cur.q_c[f];
+      if (icol) {
+        const int k = L - 1;                                 // level completed in this iteration
+        if (in && k >= 2 && k <= kbm1) {
+          double r = (wq_pp[f] - wq_c) * art / (F1(dz, k) + F1(dz, k - 1)) + xe_p[f] - xw_p[f] + yn_p[f] - ys_p[f];   // :465-468
+          r = (hea * qb_p[f] - P.dti2 * r) / hfa;                                               // :469-471
+          G3(A.qf[f], i, j, k) = r;
+        } else if (zero_else && k >= 1) {
+          G3(A.qf[f], i, j, k) = 0.;
+        }
+      }
+      wq_pp[f] = wq_p[f]; wq_p[f] = wq_c; qb_p[f] = cur.qb_c[f];
+      xe_p[f] = xe_c; xw_p[f] = xw_c; yn_p[f] = yn_c; ys_p[f] = ys_c;
     }
-    wq_pp = wq_p; wq_p = wq_c; qb_p = cur.qb_c;
-    xe_p = xe_c; xw_p = xw_c; yn_p = yn_c; ys_p = ys_c;
     am_w_prv = am_w;
-    prv = cur; cur = nxt;
+    u_m = cur.u_c; v_m = cur.v_c; vn_m = cur.v_n; am_m = cur.am_c; ams_m = cur.am_s; amn_m = cur.am_n;
+    cur = nxt;
   }
-  if (icol && zero_else) G3(qf, i, j, kb) = 0.;
+  if (icol && zero_else) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) G3(A.qf[f], i, j, kb) = 0.;
+  }
 }
 
 // ---- advct, all three phases fused (single tile) -- solver.f:201-408 ------------------------------------
@@ -571,7 +588,12 @@ static dim3 grid_rows(const KP &P) {
   return dim3((P.iml + 63) / 64, (unsigned)(strips / 4), (unsigned)(nbands * P.kb));
 }
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
-  LAUNCH(c, k_advq_col, grid1_halo(c->P), blk2(), c->P, q, qb, qf, zero_else);
+  QFields A; A.q[0] = A.q[1] = q; A.qb[0] = A.qb[1] = qb; A.qf[0] = A.qf[1] = qf;
+  LAUNCHN(c, "k_advq_col", (k_advq_col<1>), grid1_halo(c->P), blk2(), c->P, A, zero_else);
+}
+void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *ql, const double *qlb, double *qlf, int zero_else) {
+  QFields A; A.q[0] = q; A.qb[0] = qb; A.qf[0] = qf; A.q[1] = ql; A.qb[1] = qlb; A.qf[1] = qlf;
+  LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo(c->P), blk2(), c->P, A, zero_else);
 }
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
   LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P, sum2d);

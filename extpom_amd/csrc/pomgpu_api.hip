@@ -628,8 +628,12 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     // :403-409 (uf = vf = 0 is folded into the advq step kernels)
     launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
     if (!c->exch) {                                           // one tile: flux and step halves fuse (no exchange between them)
-      launch_advq_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), 1);
-      launch_advq_col(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);
+      if (getenv("POMGPU_ADVQ_SINGLE")) {
+        launch_advq_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), 1);
+        launch_advq_col(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);
+      } else {
+        launch_advq2_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);   // q2 and q2l in one pass
+      }
     } else {
       double *x0 = P.s3[0], *y0 = P.s3[1], *x1 = P.s3[2], *y1 = P.s3[3];
       launch_advq_flux(c, D3(c, q2), D3(c, q2b), x0, y0);
