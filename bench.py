@@ -42,6 +42,8 @@ KERNEL_PASSES = {
     "k_profq": 22,           # a10, one tile (production term formed in the kernel): R kq,km,kh,t,s,rho,q2b,q2lb,q2,uf,vf,u,v W q2b,q2lb,l,dtef,uf,vf,kq,km,kh
     "k_profq/tiles": 21,     # several tiles: prod comes from k_profq_prod (exchanged): R ...,prod instead of u,v
     "k_advct_col": 7,        # a2, one tile: R u,v,ub,vb,aam W advx,advy
+    "k_advq2_col": 10,       # a9 for q2 and q2l together: R q2,q2b,q2l,q2lb,u,v,w,aam W uf,vf
+    "k_advt2x2_col": 10,     # a13 for T and S together: R tb,tclim,sb,sclim,u,v,w,aam W uf,vf
     "k_advq_col": 7,         # a9, one tile: R q,qb,u,v,w,aam W qf
     "k_advt2_col": 7,        # a13: R fb,fclim,u,v,w,aam W ff
     "k_ts_update": 19,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,6 restore fields W t,tb,s,sb,rho

@@ -154,14 +154,20 @@ __global__ void __launch_bounds__(256) k_advt2_rows(KP P, const double *fb, cons
 //     order, so such a load would wait for the whole prefetch batch of the next level.
 // Per cell: 13 512-byte wavefront loads (was 56 in the cell kernel), 3 face evaluations
 // in x/y (was 4) and 1 in z (was 2).
-struct LevT { double fb_c, fb_s, fb_n, fc_c, fc_s, fc_n, am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
+// NF = 2 advances T and S in ONE pass (advance.f:431-432 calls advt2 twice): u, v, w, aam and the face
+// coefficients are read once for both fields.
+struct TFields { const double *fb[2], *f[2], *fcl[2]; double *ff[2]; };
+template <int NF> struct LevT { double fb_c[NF], fb_s[NF], fb_n[NF], fc_c[NF], fc_s[NF], fc_n[NF], am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
 // every load of a level is issued here, in one batch, BEFORE the level that is being computed
 // needs anything: vmcnt counts in order, so a load issued in the middle of the arithmetic would
 // make the wave wait for the whole prefetch batch of the next level
-__device__ __forceinline__ LevT advt2_load(const KP &P, const double *fb, const double *fcl, int i, int js, int j, int jn, int k) {
-  LevT L;
-  L.fb_c = G3(fb, i, j, k);  L.fb_s = G3(fb, i, js, k);  L.fb_n = G3(fb, i, jn, k);
-  L.fc_c = G3(fcl, i, j, k); L.fc_s = G3(fcl, i, js, k); L.fc_n = G3(fcl, i, jn, k);
+template <int NF> __device__ __forceinline__ LevT<NF> advt2_load(const KP &P, const TFields &A, int i, int js, int j, int jn, int k) {
+  LevT<NF> L;
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    L.fb_c[f] = G3(A.fb[f], i, j, k);  L.fb_s[f] = G3(A.fb[f], i, js, k);  L.fb_n[f] = G3(A.fb[f], i, jn, k);
+    L.fc_c[f] = G3(A.fcl[f], i, j, k); L.fc_s[f] = G3(A.fcl[f], i, js, k); L.fc_n[f] = G3(A.fcl[f], i, jn, k);
+  }
   L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
   L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
   L.w_c = F3(w, i, j, k);
@@ -183,7 +189,8 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   f.dif = -am * c.hs * P.tprni * ((fb_hi - fc_hi) - (fb_lo - fc_lo)) * c.msk * c.ds_num * 0.5 / c.ds_den;
   return f;
 }
-__global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
+template <int NF>
+__global__ void __launch_bounds__(256) k_advt2_col(KP P, TFields A) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
@@ -199,51 +206,61 @@ __global__ void __launch_bounds__(256) k_advt2_col(KP P, const double *fb, const
   // column-resident coefficients of the west, south and north faces and of the cell
   const CoefT cw = coef_x(P, i, j), cs = coef_y(P, i, j), cn = coef_y(P, i, jn);
   const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
-  const double f1 = G3(f, i, j, 1);
+  double f1[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) f1[f] = G3(A.f[f], i, j, 1);
   const int kbm1 = P.kbm1;
-  LevT cur = advt2_load(P, fb, fcl, i, js, j, jn, 1), nxt = cur;
+  LevT<NF> cur = advt2_load<NF>(P, A, i, js, j, jn, 1), nxt = cur;
   // carried from level L-1 to its completion in iteration L
-  double p_adv = 0., p_dif = 0., p_fb = 0., p_zu = 0.;
+  double p_adv[NF], p_dif[NF], p_fb[NF], p_zu[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) p_adv[f] = p_dif[f] = p_fb[f] = p_zu[f] = 0.;
   for (int L = 1; L <= kbm1 + 1; L++) {
-    if (L + 1 <= kbm1) nxt = advt2_load(P, fb, fcl, i, js, j, jn, L + 1);          // in flight during this iteration
-    const double ffk = (L >= 2 && !in && icol) ? G3(ff, i, j, L - 1) : 0.;
-    double zu = 0.;                                                                // top face of level L (0 below kbm1)
-    double s_adv = 0., s_dif = 0.;
-    if (L <= kbm1) {
-      const double fb_w = halo_w(cur.fb_c, [&] { return G3(fb, iw, j, L); });
-      const double fc_w = halo_w(cur.fc_c, [&] { return G3(fcl, iw, j, L); });
-      const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
-      const FaceT xw = advt2_face(P, cw, cur.u_c, cur.fb_c, fb_w, cur.fc_c, fc_w, cur.am_c, am_w);
-      auto east = [&] {                                     // emulation only: the east face from memory
-        return advt2_face(P, coef_x(P, ie, j), F3(u, ie, j, L), G3(fb, ie, j, L), cur.fb_c, G3(fcl, ie, j, L), cur.fc_c,
-                          F3(aam, ie, j, L), cur.am_c);
-      };
-      FaceT xe;
-      xe.adv = halo_e(xw.adv, [&] { return east().adv; });
-      xe.dif = halo_e(xw.dif, [&] { return east().dif; });
-      const FaceT ys = advt2_face(P, cs, cur.v_c, cur.fb_c, cur.fb_s, cur.fc_c, cur.fc_s, cur.am_c, cur.am_s);
-      const FaceT yn = advt2_face(P, cn, cur.v_n, cur.fb_n, cur.fb_c, cur.fc_n, cur.fc_c, cur.am_n, cur.am_c);
-      s_adv = xe.adv - xw.adv + yn.adv - ys.adv;                                              // solver.f:670-671
-      s_dif = xe.dif - xw.dif + yn.dif - ys.dif;                                              // :721-722
-      zu = (L == 1) ? cur.w_c * f1 * art : upw_(cur.w_c, cur.fb_c, p_fb) * art;               // :646-662
-    }
-    if (L >= 2 && icol) {                                   // finish level L-1: its bottom face is this level's top face
-      const int k = L - 1;
-      double r;
-      if (in) {
-        r = p_adv + (p_zu - zu) / F1(dz, k);                                                  // :670-672
-        r = (p_fb * hea - P.dti2 * r) / hfa;                                                  // :673-674
-        r = r * fsm;                                                                          // :1899
-        r = r - P.dti2 * p_dif / hfa;                                                         // :721-723
-      } else {
-        r = ffk * fsm;                                                                        // :1899 (rim cells)
+    if (L + 1 <= kbm1) nxt = advt2_load<NF>(P, A, i, js, j, jn, L + 1);            // in flight during this iteration
+    const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      const double ffk = (L >= 2 && !in && icol) ? G3(A.ff[f], i, j, L - 1) : 0.;
+      double zu = 0.;                                                              // top face of level L (0 below kbm1)
+      double s_adv = 0., s_dif = 0.;
+      if (L <= kbm1) {
+        const double fb_w = halo_w(cur.fb_c[f], [&] { return G3(A.fb[f], iw, j, L); });
+        const double fc_w = halo_w(cur.fc_c[f], [&] { return G3(A.fcl[f], iw, j, L); });
+        const FaceT xw = advt2_face(P, cw, cur.u_c, cur.fb_c[f], fb_w, cur.fc_c[f], fc_w, cur.am_c, am_w);
+        auto east = [&] {                                   // emulation only: the east face from memory
+          return advt2_face(P, coef_x(P, ie, j), F3(u, ie, j, L), G3(A.fb[f], ie, j, L), cur.fb_c[f], G3(A.fcl[f], ie, j, L), cur.fc_c[f],
+                            F3(aam, ie, j, L), cur.am_c);
+        };
+        FaceT xe;
+        xe.adv = halo_e(xw.adv, [&] { return east().adv; });
+        xe.dif = halo_e(xw.dif, [&] { return east().dif; });
+        const FaceT ys = advt2_face(P, cs, cur.v_c, cur.fb_c[f], cur.fb_s[f], cur.fc_c[f], cur.fc_s[f], cur.am_c, cur.am_s);
+        const FaceT yn = advt2_face(P, cn, cur.v_n, cur.fb_n[f], cur.fb_c[f], cur.fc_n[f], cur.fc_c[f], cur.am_n, cur.am_c);
+        s_adv = xe.adv - xw.adv + yn.adv - ys.adv;                                            // solver.f:670-671
+        s_dif = xe.dif - xw.dif + yn.dif - ys.dif;                                            // :721-722
+        zu = (L == 1) ? cur.w_c * f1[f] * art : upw_(cur.w_c, cur.fb_c[f], p_fb[f]) * art;    // :646-662
       }
-      G3(ff, i, j, k) = r;
+      if (L >= 2 && icol) {                                 // finish level L-1: its bottom face is this level's top face
+        const int k = L - 1;
+        double r;
+        if (in) {
+          r = p_adv[f] + (p_zu[f] - zu) / F1(dz, k);                                          // :670-672
+          r = (p_fb[f] * hea - P.dti2 * r) / hfa;                                             // :673-674
+          r = r * fsm;                                                                        // :1899
+          r = r - P.dti2 * p_dif[f] / hfa;                                                    // :721-723
+        } else {
+          r = ffk * fsm;                                                                      // :1899 (rim cells)
+        }
+        G3(A.ff[f], i, j, k) = r;
+      }
+      p_adv[f] = s_adv; p_dif[f] = s_dif; p_fb[f] = cur.fb_c[f]; p_zu[f] = zu;
     }
-    p_adv = s_adv; p_dif = s_dif; p_fb = cur.fb_c; p_zu = zu;
     cur = nxt;
   }
-  if (icol) G3(ff, i, j, P.kb) = G3(ff, i, j, P.kb) * fsm;                                    // :1899, level kb
+  if (icol) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) G3(A.ff[f], i, j, P.kb) = G3(A.ff[f], i, j, P.kb) * fsm;     // :1899, level kb
+  }
 }
 
 // ---- advq, flux + step fused (single tile) -- solver.f:411-477 -----------------------------------------
@@ -601,5 +618,13 @@ void launch_advct_col(pomgpu_ctx *c, int sum2d) {
 void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk2(), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);
-  else LAUNCH(c, k_advt2_col, grid1_halo(c->P), blk2(), c->P, fb, f, fc, ff);
+  else {
+    TFields A; A.fb[0] = A.fb[1] = fb; A.f[0] = A.f[1] = f; A.fcl[0] = A.fcl[1] = fc; A.ff[0] = A.ff[1] = ff;
+    LAUNCHN(c, "k_advt2_col", (k_advt2_col<1>), grid1_halo(c->P), blk2(), c->P, A);
+  }
+}
+void launch_advt2x2_col(pomgpu_ctx *c, const double *tb, const double *t, const double *tc, double *tf, const double *sb, const double *s_,
+                        const double *sc, double *sf) {
+  TFields A; A.fb[0] = tb; A.f[0] = t; A.fcl[0] = tc; A.ff[0] = tf; A.fb[1] = sb; A.f[1] = s_; A.fcl[1] = sc; A.ff[1] = sf;
+  LAUNCHN(c, "k_advt2x2_col", (k_advt2_col<2>), grid1_halo(c->P), blk2(), c->P, A);
 }

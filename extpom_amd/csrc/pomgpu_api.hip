@@ -651,8 +651,17 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
         seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
       } else if (k.nadv == 2) {
-        seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), true);
-        seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf), true);
+        if (P.nitera == 1 && !getenv("POMGPU_ADVT2_SINGLE") && !getenv("POMGPU_ADVT2_ROWS")) {   // T and S in one pass
+          launch_coef_eta(c);
+          launch_advt2x2_col(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
+          xch(c, 1, D3(c, uf), P.kbm1);                         // solver.f:728 (T)
+          launch_copy_kb(c, D3(c, tb));                         // :618
+          xch(c, 1, D3(c, vf), P.kbm1);                         // :728 (S)
+          launch_copy_kb(c, D3(c, sb));
+        } else {
+          seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), true);
+          seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf), true);
+        }
       } else {
         return fail(c, POMGPU_EINVAL, "Error: invalid value for nadv");
       }

@@ -243,6 +243,8 @@ void launch_advave_b(pomgpu_ctx *c);
 void launch_advave_c(pomgpu_ctx *c);
 void launch_advave_fused(pomgpu_ctx *c);
 void launch_advct_col(pomgpu_ctx *c, int sum2d);
+void launch_advt2x2_col(pomgpu_ctx *c, const double *tb, const double *t, const double *tc, double *tf, const double *sb, const double *s_,
+                        const double *sc, double *sf);
 void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *ql, const double *qlb, double *qlf, int zero_else);
 void launch_advuv_col(pomgpu_ctx *c);
 int launch_profuv_reg(pomgpu_ctx *c);   // 0 when kb is outside the instantiated range
