@@ -819,6 +819,62 @@ __global__ void k_uv_filter(KP P) {
   F2(tps, i, j) = sv;
 }
 
+// uv_filter with the column in registers (one component per launch: V = 0 u, V = 1 v).  The scratch-free
+// kernel above sweeps the column twice and re-reads uf, ub, u for the second sweep (16 array passes for
+// both components).  Here the first sweep leaves d(k) = uf+ub-2u and the old u(k) in registers
+// (compile-time indices, loops unrolled for a template bound >= kb), stores u = uf at once, and the
+// second sweep needs no memory: 3 reads + 2 writes per component.  u and ub of the whole column are
+// requested up front into their final registers; uf streams through two small chunk buffers.
+template <int KBT, int V>
+__global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
+  COL2
+  if (i > P.im || j > P.jm) return;
+  const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.n3;
+  double *b = P.b3 + (size_t)(V ? P3_vb : P3_ub) * P.n3, *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.n3;
+  const int kb = P.kb, kbm1 = P.kbm1;
+  constexpr int CH = 8, NL = KBT - 1, NCH = (NL + CH - 1) / CH;
+  double dk[NL], uo[NL], t0[CH], t1[CH];
+#define KC(k) ((k) < kbm1 ? (k) : kbm1)
+#pragma unroll
+  for (int k = 1; k <= NL; k++) { uo[k - 1] = G3(c, i, j, KC(k)); dk[k - 1] = G3(b, i, j, KC(k)); }
+#pragma unroll
+  for (int q = 0; q < CH; q++) t0[q] = G3(f, i, j, KC(q + 1));
+  const double c_kb = G3(c, i, j, kb), f_kb = G3(f, i, j, kb);
+  double su = 0.;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    if (ch + 1 < NCH) {
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        const double x = G3(f, i, j, KC((ch + 1) * CH + q + 1));
+        if (ch & 1) t0[q] = x; else t1[q] = x;
+      }
+    }
+    SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const int k = ch * CH + q + 1;
+      if (k <= NL) {
+        const double uf = (ch & 1) ? t1[q] : t0[q];
+        const double d = uf + dk[k - 1] - 2. * uo[k - 1];                                   // advance.f:473-474 / :495-496
+        dk[k - 1] = d;
+        if (k <= kbm1) {
+          su = su + d * F1(dz, k);
+          G3(c, i, j, k) = uf;                                                              // :489 / :511
+        }
+      }
+    }
+    SCHED_FENCE();
+  }
+#pragma unroll
+  for (int k = 1; k <= NL; k++)
+    if (k <= kbm1) G3(b, i, j, k) = uo[k - 1] + .5 * P.smoth * (dk[k - 1] - su);            // :484-488 / :506-510
+  G3(b, i, j, kb) = c_kb;
+  G3(c, i, j, kb) = f_kb;
+  if (V) F2(tps, i, j) = su;
+#undef KC
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 colblk() { return dim3(64, 2, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
@@ -870,4 +926,21 @@ int launch_profuv_reg(pomgpu_ctx *c) {
   else launch_profuv_reg_t<64>(c);
   return 1;
 }
-void launch_uv_filter(pomgpu_ctx *c) { LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P); }
+template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c) {
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), colgrid(c->P), colblk(), c->P);
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), colgrid(c->P), colblk(), c->P);
+}
+static int launch_uv_filter_reg(pomgpu_ctx *c) {
+  const int kb = c->P.kb;
+  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) return 0;
+  if (kb <= 24) launch_uv_filter_reg_t<24>(c);
+  else if (kb <= 32) launch_uv_filter_reg_t<32>(c);
+  else if (kb <= 40) launch_uv_filter_reg_t<40>(c);
+  else if (kb <= 44) launch_uv_filter_reg_t<44>(c);
+  else if (kb <= 50) launch_uv_filter_reg_t<50>(c);
+  else if (kb <= 56) launch_uv_filter_reg_t<56>(c);
+  else launch_uv_filter_reg_t<64>(c);
+  return 1;
+}
+void launch_uv_filter(pomgpu_ctx *c) {
+  if (launch_uv_filter_reg(c)) return; LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P); }
