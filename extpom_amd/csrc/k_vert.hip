@@ -819,6 +819,35 @@ __global__ void k_uv_filter(KP P) {
   F2(tps, i, j) = sv;
 }
 
+// int_uvmean with the column in registers (V = 0: u, V = 1: v): the scratch-free kernel above reads the
+// column once for the depth mean and again to correct it (4 reads + 2 writes for both components);
+// with the level loop unrolled for a template bound >= kb the column waits in registers: 1 read + 1 write.
+template <int KBT, int V>
+__global__ void __launch_bounds__(128) k_int_uvmean_reg(KP P) {
+  COL2
+  double *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.n3;
+  const int kbm1 = P.kbm1;
+  double x[KBT - 1];
+#define KC(k) ((k) < kbm1 ? (k) : kbm1)
+#pragma unroll
+  for (int k = 1; k <= KBT - 1; k++) x[k - 1] = G3(c, i, j, KC(k));
+  const bool upd = V ? (i <= P.im && j >= 2 && j <= P.jm) : (j <= P.jm && i >= 2 && i <= P.im);
+  double mean = 0.;
+  if (upd) mean = V ? (F2(vtb, i, j) + F2(vtf, i, j)) / (dt_(i, j) + dt_(i, j - 1)) : (F2(utb, i, j) + F2(utf, i, j)) / (dt_(i, j) + dt_(i - 1, j));
+  SCHED_FENCE();
+  double s_ = 0.;
+#pragma unroll
+  for (int k = 1; k <= KBT - 1; k++)
+    if (k <= kbm1) s_ = s_ + x[k - 1] * F1(dz, k);                                           // advance.f:365-372
+  if (upd) {
+#pragma unroll
+    for (int k = 1; k <= KBT - 1; k++)
+      if (k <= kbm1) G3(c, i, j, k) = (x[k - 1] - s_) + mean;                                // :375-392
+  }
+  if (V) F2(tps, i, j) = s_;
+#undef KC
+}
+
 // uv_filter with the column in registers (one component per launch: V = 0 u, V = 1 v).  The scratch-free
 // kernel above sweeps the column twice and re-reads uf, ub, u for the second sweep (16 array passes for
 // both components).  Here the first sweep leaves d(k) = uf+ub-2u and the old u(k) in registers
@@ -879,7 +908,21 @@ __global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
 static inline dim3 colblk() { return dim3(64, 2, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
 void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P, sum2d); }
-void launch_int_uvmean(pomgpu_ctx *c) { LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P); }
+template <int KBT> static void launch_int_uvmean_reg_t(pomgpu_ctx *c) {
+  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 0>), colgrid(c->P), colblk(), c->P);
+  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 1>), colgrid(c->P), colblk(), c->P);
+}
+void launch_int_uvmean(pomgpu_ctx *c) {
+  const int kb = c->P.kb;
+  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P);
+  else if (kb <= 24) launch_int_uvmean_reg_t<24>(c);
+  else if (kb <= 32) launch_int_uvmean_reg_t<32>(c);
+  else if (kb <= 40) launch_int_uvmean_reg_t<40>(c);
+  else if (kb <= 44) launch_int_uvmean_reg_t<44>(c);
+  else if (kb <= 50) launch_int_uvmean_reg_t<50>(c);
+  else if (kb <= 56) launch_int_uvmean_reg_t<56>(c);
+  else launch_int_uvmean_reg_t<64>(c);
+}
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
 void launch_profq_prod(pomgpu_ctx *c) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); }
