@@ -174,6 +174,39 @@ def test_config2_seamount_256x256x30_matches_oracle():
     assert not diff(a, b), diff(a, b)
 
 
+def test_general_kernels_behind_the_fast_paths(monkeypatch):
+    """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
+    multi-tile runs, selected through the library's developer switches, on an even and an odd grid"""
+    OracleTile, oracle_finish_initial = _oracle()
+    for v in ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
+              "POMGPU_REALVERTVL_CELLS"):
+        monkeypatch.setenv(v, "1")
+    for im, jm in ((65, 49), (128, 96)):
+        a = make_case("seamount", im, jm, 21, dte=6.0, isplit=30)
+        oracle_finish_initial(a)
+        b = a.copy()
+        OracleTile(a).run(3)
+        g = _gpu(b)
+        g.run(3)
+        g.download()
+        g.close()
+        assert not diff(a, b), (im, jm, diff(a, b))
+
+
+def test_kb_above_the_register_kernels_bound():
+    """kb = 70 > 64: the column kernels with private work vectors take over from the unrolled ones"""
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("basin", 64, 48, 70, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(2)
+    g = _gpu(b)
+    g.run(2)
+    g.download()
+    g.close()
+    assert not diff(a, b), diff(a, b)
+
+
 def test_restart_and_determinism_properties_1024x1024x40():
     """config 3's grid on one GPU, size-independent properties: (i) two runs give identical bits,
     (ii) run(2n) == run(n) + download/upload + run(n) (the restart property), (iii) land stays

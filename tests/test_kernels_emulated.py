@@ -67,6 +67,41 @@ def test_even_leading_dimension_steps(case, im, jm):
         assert not diff(a, b), f"step {n}: {diff(a, b)}"
 
 
+def test_kb_above_the_register_kernels_bound():
+    """kb = 70 > 64: the column kernels with private work vectors take over from the unrolled ones"""
+    a = make_case("basin", 64, 48, 70, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, 3):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
+FALLBACK_ENV = ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
+                "POMGPU_REALVERTVL_CELLS")
+
+
+def test_general_kernels_behind_the_fast_paths(monkeypatch):
+    """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
+    multi-tile runs stay bit-identical too (selected here through the library's developer switches)"""
+    for v in FALLBACK_ENV:
+        monkeypatch.setenv(v, "1")
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, 4):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
 def warm_state(case="island"):
     a = make_case(case, 65, 49, 21, dte=6.0, isplit=30)
     oracle_finish_initial(a)
