@@ -39,8 +39,8 @@ NML = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
 # SURVEY 8(a)/(d).  bytes per launch = passes * 8 B * im*jm*kb of the tile.
 KERNEL_PASSES = {
     "k_advt2_fused": 7,      # a13: R fb,fclim,u,v,w,aam  W ff
-    "k_profq": 22,           # a10, one tile (production term formed in the kernel): R kq,km,kh,t,s,rho,q2b,q2lb,q2,uf,vf,u,v W q2b,q2lb,l,dtef,uf,vf,kq,km,kh
-    "k_profq/tiles": 21,     # several tiles: prod comes from k_profq_prod (exchanged): R ...,prod instead of u,v
+    "k_profq": 23,           # a10 + a11, one tile (production term and the q2/q2l Asselin filter inside): R kq,km,kh,t,s,rho,q2b,q2lb,q2,q2l,uf,vf,u,v W q2b,q2lb,q2,q2l,l,dtef,kq,km,kh
+    "k_profq/tiles": 22,     # several tiles: prod comes from k_profq_prod (exchanged): R ...,prod instead of u,v
     "k_advct_col": 7,        # a2, one tile: R u,v,ub,vb,aam W advx,advy
     "k_advq2_col": 10,       # a9 for q2 and q2l together: R q2,q2b,q2l,q2lb,u,v,w,aam W uf,vf
     "k_advt2x2_col": 10,     # a13 for T and S together: R tb,tclim,sb,sclim,u,v,w,aam W uf,vf

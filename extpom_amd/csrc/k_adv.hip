@@ -224,6 +224,21 @@ __device__ __forceinline__ void c_q_filter(const KP &P, const int i, const int j
   F3(q2lb, i, j, k) = ql + .5 * P.smoth * (vf + F3(q2lb, i, j, k) - 2. * ql);
   F3(q2l, i, j, k) = vf;
 }
+__global__ void k_q_filter_rim(KP P) {
+  const int t = TID_I, line = (int)blockIdx.y, k = TID_K;
+  if (k > P.kb) return;
+  int i, j;
+  if (line < 4) {                                          // columns 1, 2, imm1, im over all rows
+    if (t > P.jm) return;
+    i = line == 0 ? 1 : (line == 1 ? 2 : (line == 2 ? P.imm1 : P.im)); j = t;
+    if (line == 2 && P.imm1 <= 2) return;                  // (tiny tiles: no line twice)
+  } else {                                                 // rows 1, 2, jmm1, jm between them
+    if (t < 3 || t > P.imm1 - 1) return;
+    j = line == 4 ? 1 : (line == 5 ? 2 : (line == 6 ? P.jmm1 : P.jm)); i = t;
+    if (line == 6 && P.jmm1 <= 2) return;
+  }
+  c_q_filter(P, i, j, k, 1);
+}
 __device__ __forceinline__ void c_mask_q(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_q(KP P) {   // the mask of bcond(6) alone
   MARCH3(c_mask_q(P, i, j, k))
@@ -852,6 +867,12 @@ void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *
   LAUNCH(c, k_advq_step, gridm(c->P), blk2(), c->P, q, qb, qf, xf, yf, zero_else);
 }
 void launch_q_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_q_filter, gridm(c->P), blk2(), c->P, mask); }
+// the filter of the two outermost lines on every side alone (the interior rode on k_profq's back substitution)
+void launch_q_filter_rim(pomgpu_ctx *c) {
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_q_filter_rim, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P);
+}
 void launch_mask_q(pomgpu_ctx *c) { LAUNCH(c, k_mask_q, gridm(c->P), blk2(), c->P); }
 void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {
   LAUNCH(c, k_advt1, gridm(c->P), blk2(), c->P, (const double *)fb, (const double *)f, fclim, ff);

@@ -182,7 +182,12 @@ __global__ void k_profq_prod(KP P) {
 //     private per-thread arrays.  (The first cut re-read l three times and dtef twice and kept gh
 //     and two generations of ee/gg: 53 GB of HBM traffic per launch at 2048x1536x50 against 26 GB
 //     algorithmic, rocprofv3 FETCH_SIZE/WRITE_SIZE.)
-__global__ void k_profq(KP P, int fuse_prod) {
+// fuse_filter (inside pomgpu_advance): the Asselin filter and time rotation of q2, q2l (advance.f:416-421,
+// with bcond(6)'s mask) ride on the back substitution of the interior columns -- uf, vf never reach
+// memory there (only their level-kb left-overs do, see k_q_filter); the two outermost lines of columns
+// keep the plain path (bcond(6), which also reads their old q2/q2l, and on several tiles the exchange
+// come between the solve and their filter).
+__global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
@@ -217,6 +222,8 @@ __global__ void k_profq(KP P, int fuse_prod) {
   // is formed here from the same sound speed / density / km / kh this walk reads anyway, instead of
   // being written by a kernel of its own and read back
   const bool pin = fuse_prod && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  // not the two outermost lines: bcond(6) reads the OLD q2, q2l of columns 2 / imm1 / jmm1 (bounds_forcing.f:262-318)
+  const bool ffil = fuse_filter && (i >= 3 && i <= P.imm1 - 1 && j >= 3 && j <= P.jmm1 - 1);
   const int ie = i < P.iml ? i + 1 : i, jn = j < P.jml ? j + 1 : j;
   double ucm = 0., uem = 0., vcm = 0., vnm = 0.;                   // u(i), u(i+1), v(j), v(j+1) of level k-1
   for (int k = 1; k <= kb; k++) {
@@ -231,8 +238,10 @@ __global__ void k_profq(KP P, int fuse_prod) {
     if (mid) {
       q2b = fabs(q2b);                                                                      // :1325-1326
       const double q2lb = fabs(F3(q2lb, i, j, k));
-      F3(q2b, i, j, k) = q2b;
-      F3(q2lb, i, j, k) = q2lb;
+      if (!ffil) {                                           // with the fused filter q2b, q2lb are rewritten on the way up
+        F3(q2b, i, j, k) = q2b;
+        F3(q2lb, i, j, k) = q2lb;
+      }
       bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * h_(i, j)) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
       l = fabs(q2lb / q2b);                                                                 // :1338-1344
       if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
@@ -310,7 +319,7 @@ __global__ void k_profq(KP P, int fuse_prod) {
     if (k + 2 <= kb) kqp = F3(kq, i, j, k + 2);
   }
   // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468
-  {
+  if (!ffil) {
     double x = ufbot, y = 0.;
     for (int ki = kbm1; ki >= 1; ki--) {
       x = ee1[ki - 1] * x + gg1[ki - 1];
@@ -322,6 +331,36 @@ __global__ void k_profq(KP P, int fuse_prod) {
     }
     F3(vf, i, j, 1) = 0.;
     F3(vf, i, j, kb) = 0.;
+  } else {
+    const double hs = .5 * P.smoth;
+    // one level of k_q_filter: bcond(6)'s mask, Asselin filter, rotation; q2b, q2lb as k_profq leaves them
+    // (|.| at 2..kbm1).  The four operands of the level above are requested one iteration ahead.
+    struct QL { double qb, qlb, q, ql; };
+    auto qload = [&](int k) { QL L; L.qb = F3(q2b, i, j, k); L.qlb = F3(q2lb, i, j, k); L.q = F3(q2, i, j, k); L.ql = F3(q2l, i, j, k); return L; };
+    auto filt = [&](int k, const QL &L, double ufv, double vfv) {
+      const double ufm = ufv * fsm_c + 1.e-10, vfm = vfv * fsm_c + 1.e-10;
+      double qb = L.qb, qlb = L.qlb;
+      if (k >= 2 && k <= kbm1) { qb = fabs(qb); qlb = fabs(qlb); }
+      F3(q2b, i, j, k) = L.q + hs * (ufm + qb - 2. * L.q);
+      F3(q2, i, j, k) = ufm;
+      F3(q2lb, i, j, k) = L.ql + hs * (vfm + qlb - 2. * L.ql);
+      F3(q2l, i, j, k) = vfm;
+      if (k == kb) { F3(uf, i, j, k) = ufm; F3(vf, i, j, k) = vfm; }   // advt leaves level kb of uf, vf as it finds it
+    };
+    QL cur = qload(kb), nxt = qload(kbm1);
+    filt(kb, cur, ufbot, 0.);
+    double x = ufbot, y = 0.;
+    for (int ki = kbm1; ki >= 1; ki--) {
+      cur = nxt;
+      if (ki >= 2) nxt = qload(ki - 1);
+      x = ee1[ki - 1] * x + gg1[ki - 1];
+      double yv = 0.;
+      if (ki >= 2) {
+        y = ee2[ki - 1] * y + gg2[ki - 1];
+        yv = fabs(y);
+      }
+      filt(ki, cur, (ki >= 2) ? fabs(x) : x, yv);
+    }
   }
 }
 
@@ -926,8 +965,8 @@ void launch_int_uvmean(pomgpu_ctx *c) {
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
 void launch_profq_prod(pomgpu_ctx *c) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); }
-void launch_profq(pomgpu_ctx *c, int fuse_prod) {
-  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod);
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter) {
+  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod, fuse_filter);
   const KP &P = c->P;
   if (P.W || P.E || P.S || P.N) {
     const int len = P.im > P.jm ? P.im : P.jm;

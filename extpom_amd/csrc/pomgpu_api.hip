@@ -466,14 +466,14 @@ static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair,
   xch(c, 2, xf, P.kbm1, yf, P.kbm1);                          // :458-459
   launch_advq_step(c, q, qb, qf, xf, yf, zero_else);
 }
-static void seq_profq(pomgpu_ctx *c) {                        // solver.f:1212-1538
+static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0) {   // solver.f:1212-1538
   KP &P = c->P;
   launch_profq_bc(c);
   xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
-  if (!c->exch) { launch_profq(c, 1); return; }               // one tile: prod is formed inside the solve kernel
+  if (!c->exch) { launch_profq(c, 1, fuse_filter); return; }  // one tile: prod is formed inside the solve kernel
   launch_profq_prod(c);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
-  launch_profq(c, 0);
+  launch_profq(c, 0, fuse_filter);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
   launch_copy_kb(c, fb);                                      // solver.f:496 / :618
@@ -642,10 +642,12 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       launch_advq_step(c, D3(c, q2), D3(c, q2b), D3(c, uf), x0, y0, 1);
       launch_advq_step(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), x1, y1, 1);
     }
-    seq_profq(c);
+    const int qfuse = !getenv("POMGPU_QFILTER_SPLIT");
+    seq_profq(c, qfuse);                                      // with the interior's Asselin filter (:416-421) on its way up
     xch(c, 2, D3(c, uf) + P.n2, P.kbm2, D3(c, vf) + P.n2, P.kbm2);   // :411-412
     launch_bcond6_edges(c);                                   // :414
-    launch_q_filter(c, 1);                                    // :416-421
+    if (qfuse) launch_q_filter_rim(c);                        // :416-421, edge lines
+    else launch_q_filter(c, 1);
     if (k.mode != 4) {
       if (k.nadv == 1) {
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));

@@ -268,6 +268,7 @@ void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb);
 void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf);
 void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *xf, const double *yf, int zero_else);
 void launch_q_filter(pomgpu_ctx *c, int mask);
+void launch_q_filter_rim(pomgpu_ctx *c);
 void launch_mask_q(pomgpu_ctx *c);
 void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff);
 void launch_copy_kb(pomgpu_ctx *c, double *f);
@@ -296,7 +297,7 @@ void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
 void launch_profq_prod(pomgpu_ctx *c);
-void launch_profq(pomgpu_ctx *c, int fuse_prod);
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter);
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
