@@ -139,7 +139,12 @@ def main():
 
     import torch
     from extpom_amd import decomp, dist as pdist
-    rank, world, local = pdist.init()
+    # POM_BENCH_REHEARSE=1: developer rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on GPU 0,
+    # gloo with host-staged halos instead of RCCL (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearse = os.environ.get("POM_BENCH_REHEARSE") == "1"
+    rank, world, local = pdist.init("gloo" if rehearse else None)
+    if rehearse:
+        local = 0
     if world != args.gpus:
         if rank == 0:
             print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -161,7 +166,7 @@ def main():
     g = gpu_initialise(st, local, stream)
     if world > 1:
         from extpom_amd.halo import DeviceHalo
-        halo = DeviceHalo(g, tile, torch.device("cuda", local))
+        halo = DeviceHalo(g, tile, torch.device("cuda", local), staged=rehearse)
 
     def barrier():
         g.sync()
@@ -190,7 +195,7 @@ def main():
     dt = time.perf_counter() - t0
     timed = g.prof_end()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     g.get_con()
