@@ -501,6 +501,130 @@ void pomo_baropg(pomo_tile *T) {
 }
 
 /* ===================================================================================== */
+/* baropg_mcc -- solver.f:943-1159: baroclinic pressure gradient with McCalpin's 4th-order
+ * correction (npg = 2).  The (0:im_local,0:jm_local) work arrays rho4th, d4th differ from rho, d
+ * only in their extra west column / south row, which order2d_mpi / order3d_mpi fill from the
+ * neighbour (column nx-2 / row ny-2 of ITS array); they are read only where i-2 = 0 or j-2 = 0.
+ * (1./24.), (1./24), (1./16.) are REAL(4) constants. */
+void pomo_baropg_mcc(pomo_tile *T) {
+  int i, j, k; size_t n;
+  const double c24 = (double)(1.f/24.f), c16 = (double)(1.f/16.f);
+  double *prho = A3_(rho), *prm = A3_(rmean);
+  double *d4 = T->scr[0], *ddx = T->scr[1], *drho = T->scr[2], *rhou = T->scr[3];
+  double *gw3 = T->scr[4], *gs3 = T->scr[5], *gw2 = T->scr[6], *gs2 = T->scr[7];   /* rho4th(0,j,k), rho4th(i,0,k), d4th(0,j), d4th(i,0) */
+#define RHO4W(j,k) gw3[(size_t)((k)-1)*jm_local+(size_t)((j)-1)]
+#define RHO4S(i,k) gs3[(size_t)((k)-1)*im_local+(size_t)((i)-1)]
+  for (n = 0; n < T->n3; n++) prho[n] = prho[n]-prm[n];                                 /* :954 */
+  memset(gw3, 0, sizeof(double)*(size_t)jm_local*kb); memset(gs3, 0, sizeof(double)*(size_t)im_local*kb);
+  memset(gw2, 0, sizeof(double)*(size_t)jm_local);    memset(gs2, 0, sizeof(double)*(size_t)im_local);
+  if (T->order) {                                                                       /* :958-959 */
+    T->order(T->user, A2_(d), im_local, jm_local, 1, gw2, gs2);
+    T->order(T->user, prho, im_local, jm_local, kb, gw3, gs3);
+  }
+  /* ---- x component */
+  memset(ddx, 0, sizeof(double)*(size_t)im*jm); memset(d4, 0, sizeof(double)*(size_t)im*jm);   /* :962-965 */
+  zero3(T, 2); zero3(T, 3);
+  for (j = 1; j <= jm; j++) for (i = 2; i <= im; i++) {                                 /* :968-978 */
+    for (k = 1; k <= kbm1; k++) {
+      L3_(drho,i,j,k) = (rho(i,j,k)-rho(i-1,j,k))*dum(i,j);
+      L3_(rhou,i,j,k) = 0.5*(rho(i,j,k)+rho(i-1,j,k))*dum(i,j);
+    }
+    L2_(ddx,i,j) = (d(i,j)-d(i-1,j))*dum(i,j);
+    L2_(d4,i,j) = .5*(d(i,j)+d(i-1,j))*dum(i,j);
+  }
+  {
+    const int i0 = (n_west == -1) ? 3 : 2;                                              /* :980-1024 */
+    for (j = 1; j <= jm; j++) for (i = i0; i <= imm1; i++) {
+#define RW2(k) ((i) >= 3 ? rho(i-2,j,k) : RHO4W(j,k))
+      const double dw2 = (i >= 3) ? d(i-2,j) : gw2[j-1];
+      for (k = 1; k <= kbm1; k++) {
+        L3_(drho,i,j,k) = L3_(drho,i,j,k) - c24*
+                          (dum(i+1,j)*(rho(i+1,j,k)-rho(i,j,k))-
+                           2*(rho(i,j,k)-rho(i-1,j,k))+
+                           dum(i-1,j)*(rho(i-1,j,k)-RW2(k)));
+        L3_(rhou,i,j,k) = L3_(rhou,i,j,k) + c16*
+                          (dum(i+1,j)*(rho(i,j,k)-rho(i+1,j,k))+
+                           dum(i-1,j)*(rho(i-1,j,k)-RW2(k)));
+      }
+      L2_(ddx,i,j) = L2_(ddx,i,j)-c24*
+                     (dum(i+1,j)*(d(i+1,j)-d(i,j))-
+                      2*(d(i,j)-d(i-1,j))+
+                      dum(i-1,j)*(d(i-1,j)-dw2));
+      L2_(d4,i,j) = L2_(d4,i,j)+c16*
+                    (dum(i+1,j)*(d(i,j)-d(i+1,j))+
+                     dum(i-1,j)*(d(i-1,j)-dw2));
+#undef RW2
+    }
+  }
+  for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)                               /* :1027-1031 */
+    drhox(i,j,1) = grav*(-zz(1))*L2_(d4,i,j)*L3_(drho,i,j,1);
+  for (k = 2; k <= kbm1; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)   /* :1033-1044 */
+    drhox(i,j,k) = drhox(i,j,k-1)
+                   +grav*0.5*dzz(k-1)*L2_(d4,i,j)
+                    *(L3_(drho,i,j,k-1)+L3_(drho,i,j,k))
+                   +grav*0.5*(zz(k-1)+zz(k))*L2_(ddx,i,j)
+                    *(L3_(rhou,i,j,k)-L3_(rhou,i,j,k-1));
+  for (k = 1; k <= kbm1; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)   /* :1046-1054 */
+    drhox(i,j,k) = .25*(dt(i,j)+dt(i-1,j))
+                      *drhox(i,j,k)*dum(i,j)
+                      *(dy(i,j)+dy(i-1,j));
+  /* ---- y component */
+  memset(ddx, 0, sizeof(double)*(size_t)im*jm); memset(d4, 0, sizeof(double)*(size_t)im*jm);   /* :1059-1062 */
+  zero3(T, 2); zero3(T, 3);
+  for (j = 2; j <= jm; j++) for (i = 1; i <= im; i++) {                                 /* :1065-1075 */
+    for (k = 1; k <= kbm1; k++) {
+      L3_(drho,i,j,k) = (rho(i,j,k)-rho(i,j-1,k))*dvm(i,j);
+      L3_(rhou,i,j,k) = .5*(rho(i,j,k)+rho(i,j-1,k))*dvm(i,j);
+    }
+    L2_(ddx,i,j) = (d(i,j)-d(i,j-1))*dvm(i,j);
+    L2_(d4,i,j) = .5*(d(i,j)+d(i,j-1))*dvm(i,j);
+  }
+  {
+    const int j0 = (n_south == -1) ? 3 : 2;                                             /* :1077-1121 */
+    for (j = j0; j <= jmm1; j++) for (i = 1; i <= im; i++) {
+#define RS2(k) ((j) >= 3 ? rho(i,j-2,k) : RHO4S(i,k))
+      const double ds2 = (j >= 3) ? d(i,j-2) : gs2[i-1];
+      for (k = 1; k <= kbm1; k++) {
+        L3_(drho,i,j,k) = L3_(drho,i,j,k)-c24*
+                          (dvm(i,j+1)*(rho(i,j+1,k)-rho(i,j,k))-
+                           2*(rho(i,j,k)-rho(i,j-1,k))+
+                           dvm(i,j-1)*(rho(i,j-1,k)-RS2(k)));
+        L3_(rhou,i,j,k) = L3_(rhou,i,j,k)+c16*
+                          (dvm(i,j+1)*(rho(i,j,k)-rho(i,j+1,k))+
+                           dvm(i,j-1)*(rho(i,j-1,k)-RS2(k)));
+      }
+      L2_(ddx,i,j) = L2_(ddx,i,j)-c24*
+                     (dvm(i,j+1)*(d(i,j+1)-d(i,j))-
+                      2*(d(i,j)-d(i,j-1))+
+                      dvm(i,j-1)*(d(i,j-1)-ds2));
+      L2_(d4,i,j) = L2_(d4,i,j)+c16*
+                    (dvm(i,j+1)*(d(i,j)-d(i,j+1))+
+                     dvm(i,j-1)*(d(i,j-1)-ds2));
+#undef RS2
+    }
+  }
+  for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)                               /* :1124-1128 */
+    drhoy(i,j,1) = grav*(-zz(1))*L2_(d4,i,j)*L3_(drho,i,j,1);
+  for (k = 2; k <= kbm1; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)   /* :1130-1141 */
+    drhoy(i,j,k) = drhoy(i,j,k-1)
+                   +grav*0.5*dzz(k-1)*L2_(d4,i,j)
+                    *(L3_(drho,i,j,k-1)+L3_(drho,i,j,k))
+                   +grav*0.5*(zz(k-1)+zz(k))*L2_(ddx,i,j)
+                    *(L3_(rhou,i,j,k)-L3_(rhou,i,j,k-1));
+  for (k = 1; k <= kbm1; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++)   /* :1143-1151 */
+    drhoy(i,j,k) = .25*(dt(i,j)+dt(i,j-1))
+                      *drhoy(i,j,k)*dvm(i,j)
+                      *(dx(i,j)+dx(i,j-1));
+  for (k = 1; k <= kb; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++) {   /* :1155-1162 */
+    drhox(i,j,k) = ramp*drhox(i,j,k);
+    drhoy(i,j,k) = ramp*drhoy(i,j,k);
+  }
+  for (n = 0; n < T->n3; n++) prho[n] = prho[n]+prm[n];                                 /* :1164 */
+#undef RHO4W
+#undef RHO4S
+}
+
+/* ===================================================================================== */
 /* dens(si,ti,rhoo) -- solver.f:1162-1209 */
 void pomo_dens(pomo_tile *T, double *si, double *ti, double *rhoo) {
   int i, j, k;
@@ -1148,8 +1272,9 @@ void pomo_lateral_viscosity(pomo_tile *T) {
     pomo_advct(T);
     if (npg == 1) {
       pomo_baropg(T);
+    } else if (npg == 2) {
+      pomo_baropg_mcc(T);                                                               /* :115-116 */
     } else {
-      /* npg=2 (baropg_mcc) is outside this round's scope; the reference flags other values */
       error_status = 1;
       fprintf(stderr, "Error: invalid value for npg\n");
     }

@@ -37,6 +37,10 @@ typedef struct pomo_tile {
   double vamax; int imax, jmax;
   /* scratch for the reference's automatic arrays */
   double *scr[POMO_NSCR];
+  /* order2d_mpi / order3d_mpi (parallel_mpi.f:353-480): hand the caller column nx-2 and row ny-2 of a
+   * (nx,ny[,nz]) array and take the west / south neighbour's into ghost_w (ny*nz values, j fastest) and
+   * ghost_s (nx*nz values, i fastest); either ghost stays untouched on a physical edge.  NULL = one tile. */
+  void (*order)(void *user, const double *a, int nx, int ny, int nz, double *ghost_w, double *ghost_s);
 } pomo_tile;
 
 /* bind storage; returns 0 or -1 on allocation failure */

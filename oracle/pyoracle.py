@@ -128,6 +128,6 @@ def oracle_finish_initial(st):
         ot.call("dens", ot.a3(si), ot.a3(ti), ot.a3(rho))
 
     def baropg(s):
-        ot.call("baropg")
+        ot.call("baropg_mcc" if int(s.npg) == 2 else "baropg")
 
     return finish_initial(st, dens, baropg)

@@ -145,7 +145,7 @@ def ref_finish_initial(st):
 
     def baropg(s):
         lib.put(s)
-        lib.call("baropg")
+        lib.call("baropg_mcc" if int(s.npg) == 2 else "baropg")
         lib.get(s)
 
     return finish_initial(st, dens, baropg)

@@ -34,6 +34,8 @@ CONFIGS = {
     "island_default": ("island", dict(dte=6.0, isplit=30), [3, 40]),
     "basin_default": ("basin", dict(dte=6.0, isplit=30), [3, 40]),
     "basin_alpha": ("basin", dict(dte=6.0, isplit=10, alpha=0.225), [3, 20]),
+    "seamount_npg2": ("seamount", dict(dte=6.0, isplit=30, npg=2), [3, 20]),      # baropg_mcc
+    "island_npg2": ("island", dict(dte=6.0, isplit=30, npg=2), [3, 20]),
 }
 PLANES = {"seamount_default": [10, 100], "island_default": [40], "basin_default": [40]}
 PLANE_FIELDS = ["el", "et", "ua", "va", "u", "v", "t", "s", "q2", "km", "rho", "w"]

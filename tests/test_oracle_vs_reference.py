@@ -24,7 +24,8 @@ def _diff(a, b):
 
 @pytest.mark.parametrize("case,nml", [("seamount", dict(dte=6.0, isplit=30)),
                                       ("island", dict(dte=6.0, isplit=30, nadv=1)),
-                                      ("basin", dict(dte=6.0, isplit=10, nitera=2))])
+                                      ("basin", dict(dte=6.0, isplit=10, nitera=2)),
+                                      ("island", dict(dte=6.0, isplit=30, npg=2))])
 def test_full_state_bit_identical(case, nml):
     a = make_case(case, 65, 49, 21, **nml)
     ref_finish_initial(a)
@@ -63,7 +64,7 @@ def test_each_routine_bit_identical():
         assert not _diff(x, y), f"{name}: {_diff(x, y)}"
 
     i = lambda v: ctypes.byref(ctypes.c_int(v))
-    for name in ("advave", "advct", "advu", "advv", "baropg", "profq", "profu", "profv", "vertvl", "realvertvl",
+    for name in ("advave", "advct", "advu", "advv", "baropg", "baropg_mcc", "profq", "profu", "profv", "vertvl", "realvertvl",
                  "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "check_velocity"):
         both(name)
     both("advq", lambda l: (l.f3("q2b"), l.f3("q2"), l.f3("uf")), lambda o: (o.a3("q2b"), o.a3("q2"), o.a3("uf")))
