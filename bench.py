@@ -98,7 +98,7 @@ def gpu_initialise(st, device, stream):
         g._chk(g.L.pomgpu_download_3d(g.h, P3[rho], P(s.field(rho))), "download")
 
     def baropg(s):
-        g.call("baropg")
+        g.call("baropg_mcc" if int(s.npg) == 2 else "baropg")
         for f in ("drhox", "drhoy", "rho"):
             g._chk(g.L.pomgpu_download_3d(g.h, P3[f], P(s.field(f))), "download")
 
@@ -167,6 +167,8 @@ def main():
     if world > 1:
         from extpom_amd.halo import DeviceHalo
         halo = DeviceHalo(g, tile, torch.device("cuda", local), staged=rehearse)
+        from extpom_amd.halo import Halo
+        g.set_order_exchange(Halo(tile, staged=rehearse).device_order_hook(torch.device("cuda", local)))   # npg = 2 only
 
     def barrier():
         g.sync()

@@ -74,6 +74,94 @@ __global__ void k_baropg(KP P, int sum2d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// baropg_mcc -- solver.f:943-1159 (npg = 2): McCalpin's 4th-order pressure gradient.  Same shape as
+// k_baropg: the anomaly rho-rmean is formed on the fly, drho / rhou of the level above ride in
+// registers, the reference's four automatic 3-D arrays are gone.  The one extra ghost column / row
+// (rho4th(0,j,k), d4th(0,j), ...(i,0,...)) that order2d_mpi / order3d_mpi deliver on several tiles sits
+// in the small buffers KP.g4[] (filled by k_order_pack + the order hook); on a physical edge the
+// correction starts one cell further in, exactly as the reference's two branches (:980-1024).
+// (1./24.), (1./24), (1./16.) are REAL(4) constants in the reference.
+#define RA(ii, jj, kk) (F3(rho, ii, jj, kk) - F3(rmean, ii, jj, kk))
+__global__ void k_order_pack(KP P, double *send_e, double *send_n) {     // what order2d/3d_mpi send: column iml-2, row jml-2
+  const int t = TID_I, k = (int)blockIdx.y;                              // k = 0: d, k >= 1: rho-rmean at level k
+  if (t <= P.jml && send_e) send_e[(size_t)k * P.jml + (t - 1)] = k == 0 ? F2(d, P.iml - 2, t) : RA(P.iml - 2, t, k);
+  if (t <= P.iml && send_n) send_n[(size_t)k * P.iml + (t - 1)] = k == 0 ? F2(d, t, P.jml - 2) : RA(t, P.jml - 2, k);
+}
+__global__ void k_baropg_mcc(KP P, int sum2d) {
+  COL2
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) {
+    if (sum2d) {                                             // rim and padding columns: whatever drhox, drhoy hold there
+      double rx = 0., ry = 0.;
+      if (i <= P.im && j <= P.jm)
+        for (int k = 1; k <= P.kbm1; k++) {
+          const double dzk = F1(dz, k);
+          rx = rx + F3(drhox, i, j, k) * dzk;
+          ry = ry + F3(drhoy, i, j, k) * dzk;
+        }
+      F2(drx2d, i, j) = rx;
+      F2(dry2d, i, j) = ry;
+    }
+    return;
+  }
+  const double c24 = (double)(1.f / 24.f), c16 = (double)(1.f / 16.f);
+  const bool cx = (i >= (P.W ? 3 : 2)), cy = (j >= (P.S ? 3 : 2));      // 4th-order correction applies
+  const bool gx = (i == 2), gy = (j == 2);                               // its outermost operand is the extra ghost
+  const double *gw3 = P.g4[0], *gs3 = P.g4[1], *gw2 = P.g4[2], *gs2 = P.g4[3];
+  const int iww = gx ? 1 : i - 2, jss = gy ? 1 : j - 2;                  // (in-range dummy when the ghost is used)
+  const double mxc = F2(dum, i, j), mxe = F2(dum, i + 1, j), mxw = F2(dum, i - 1, j);
+  const double myc = F2(dvm, i, j), myn = F2(dvm, i, j + 1), mys = F2(dvm, i, j - 1);
+  const double dc = F2(d, i, j), de = F2(d, i + 1, j), dw = F2(d, i - 1, j), dn = F2(d, i, j + 1), ds = F2(d, i, j - 1);
+  const double dww = gx ? gw2[j - 1] : F2(d, iww, j), dss = gy ? gs2[i - 1] : F2(d, i, jss);
+  double ddxx = (dc - dw) * mxc, d4x = .5 * (dc + dw) * mxc;                                  // :976-977
+  if (cx) {
+    ddxx = ddxx - c24 * (mxe * (de - dc) - 2 * (dc - dw) + mxw * (dw - dww));                 // :993-996
+    d4x = d4x + c16 * (mxe * (dc - de) + mxw * (dw - dww));                                   // :997-999
+  }
+  double ddxy = (dc - ds) * myc, d4y = .5 * (dc + ds) * myc;                                  // :1073-1074
+  if (cy) {
+    ddxy = ddxy - c24 * (myn * (dn - dc) - 2 * (dc - ds) + mys * (ds - dss));                 // :1090-1093
+    d4y = d4y + c16 * (myn * (dc - dn) + mys * (ds - dss));                                   // :1094-1096
+  }
+  const double sx = .25 * (dt_(i, j) + dt_(i - 1, j)), ex = dy_(i, j) + dy_(i - 1, j);
+  const double sy = .25 * (dt_(i, j) + dt_(i, j - 1)), ey = dx_(i, j) + dx_(i, j - 1);
+  double ax = 0., ay = 0., drx_m = 0., rux_m = 0., dry_m = 0., ruy_m = 0., rx = 0., ry = 0.;
+  for (int k = 1; k <= P.kbm1; k++) {
+    const double rc = RA(i, j, k), re = RA(i + 1, j, k), rw = RA(i - 1, j, k), rn = RA(i, j + 1, k), rs = RA(i, j - 1, k);
+    const double rww = gx ? gw3[(size_t)(k - 1) * P.jml + (j - 1)] : RA(iww, j, k);
+    const double rss = gy ? gs3[(size_t)(k - 1) * P.iml + (i - 1)] : RA(i, jss, k);
+    double drx = (rc - rw) * mxc, rux = 0.5 * (rc + rw) * mxc;                                // :971-974
+    if (cx) {
+      drx = drx - c24 * (mxe * (re - rc) - 2 * (rc - rw) + mxw * (rw - rww));                 // :984-987
+      rux = rux + c16 * (mxe * (rc - re) + mxw * (rw - rww));                                 // :988-990
+    }
+    double dry = (rc - rs) * myc, ruy = .5 * (rc + rs) * myc;                                 // :1068-1071
+    if (cy) {
+      dry = dry - c24 * (myn * (rn - rc) - 2 * (rc - rs) + mys * (rs - rss));                 // :1081-1084
+      ruy = ruy + c16 * (myn * (rc - rn) + mys * (rs - rss));                                 // :1085-1087
+    }
+    if (k == 1) {
+      ax = P.grav * (-F1(zz, 1)) * d4x * drx;                                                 // :1029
+      ay = P.grav * (-F1(zz, 1)) * d4y * dry;                                                 // :1126
+    } else {
+      ax = ax + P.grav * 0.5 * F1(dzz, k - 1) * d4x * (drx_m + drx) +
+           P.grav * 0.5 * (F1(zz, k - 1) + F1(zz, k)) * ddxx * (rux - rux_m);                 // :1036-1041
+      ay = ay + P.grav * 0.5 * F1(dzz, k - 1) * d4y * (dry_m + dry) +
+           P.grav * 0.5 * (F1(zz, k - 1) + F1(zz, k)) * ddxy * (ruy - ruy_m);                 // :1133-1138
+    }
+    const double ox = P.ramp * (sx * ax * mxc * ex), oy = P.ramp * (sy * ay * myc * ey);      // :1049-1051, :1146-1148, :1157-1158
+    F3(drhox, i, j, k) = ox;
+    F3(drhoy, i, j, k) = oy;
+    rx = rx + ox * F1(dz, k);
+    ry = ry + oy * F1(dz, k);
+    drx_m = drx; rux_m = rux; dry_m = dry; ruy_m = ruy;
+  }
+  F3(drhox, i, j, P.kb) = P.ramp * F3(drhox, i, j, P.kb);                                     // :1155-1160, k = kb
+  F3(drhoy, i, j, P.kb) = P.ramp * F3(drhoy, i, j, P.kb);
+  if (sum2d) { F2(drx2d, i, j) = rx; F2(dry2d, i, j) = ry; }
+}
+#undef RA
+
+// ---------------------------------------------------------------------------------------------
 // mode_internal: make the depth mean of (u,v) equal (ua,va) -- advance.f:365-393
 __global__ void k_int_uvmean(KP P) {
   COL2
@@ -947,6 +1035,12 @@ __global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
 static inline dim3 colblk() { return dim3(64, 2, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
 void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P, sum2d); }
+void launch_baropg_mcc(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg_mcc, colgrid(c->P), colblk(), c->P, sum2d); }
+void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n) {
+  const KP &P = c->P;
+  const int len = P.iml > P.jml ? P.iml : P.jml;
+  LAUNCH(c, k_order_pack, dim3((len + 63) / 64, P.kb + 1, 1), dim3(64, 1, 1), c->P, send_e, send_n);
+}
 template <int KBT> static void launch_int_uvmean_reg_t(pomgpu_ctx *c) {
   LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 0>), colgrid(c->P), colblk(), c->P);
   LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 1>), colgrid(c->P), colblk(), c->P);

@@ -205,6 +205,12 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
   for (int n = 0; n < 5; n++) alloc(&c->alt2[n], P.n2);
+  for (int n = 0; n < 2; n++) {
+    const size_t len = (size_t)(P.kb + 1) * (n == 0 ? P.jml : P.iml);
+    alloc(&c->ord_send[n], len);
+    alloc(&c->ord_recv[n], len);
+  }
+  if (ok) { P.g4[2] = c->ord_recv[0]; P.g4[0] = c->ord_recv[0] + P.jml; P.g4[3] = c->ord_recv[1]; P.g4[1] = c->ord_recv[1] + P.iml; }
   alloc(&c->d_vel, 4);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
@@ -231,6 +237,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
   for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
   for (int n = 0; n < 5; n++) (void)hipFree(c->alt2[n]);
+  for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err);
   ProfState *ps = PS(c);
@@ -391,6 +398,12 @@ extern "C" int pomgpu_set_exchange(pomgpu_ctx *c, pomgpu_exchange_fn fn, void *u
   c->exch_user = user;
   return POMGPU_OK;
 }
+extern "C" int pomgpu_set_order_exchange(pomgpu_ctx *c, pomgpu_order_fn fn, void *user) {
+  if (!c) return POMGPU_EINVAL;
+  c->order = fn;
+  c->order_user = user;
+  return POMGPU_OK;
+}
 
 extern "C" int pomgpu_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi) {
   if (!c || !dev || !nz || (dir != 0 && dir != 1)) return POMGPU_EINVAL;
@@ -457,6 +470,15 @@ static void seq_advct(pomgpu_ctx *c, int sum2d = 0) {         // solver.f:201-40
 static void seq_baropg(pomgpu_ctx *c, int sum2d = 0) {        // solver.f:848-940
   launch_baropg(c, sum2d);
   launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :854 + :937
+}
+static void seq_baropg_mcc(pomgpu_ctx *c, int sum2d = 0) {    // solver.f:943-1159
+  KP &P = c->P;
+  if (c->order) {                                             // :958-959 order2d_mpi(d), order3d_mpi(rho - rmean), one message per neighbour
+    launch_order_pack(c, c->ord_send[0], c->ord_send[1]);
+    c->order(c->order_user, c->ord_send[0], (P.kb + 1) * P.jml, c->ord_send[1], (P.kb + 1) * P.iml, c->ord_recv[0], c->ord_recv[1]);
+  }
+  launch_baropg_mcc(c, sum2d);
+  launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :954 + :1164
 }
 static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair, int zero_else) {   // solver.f:411-477
   KP &P = c->P;
@@ -573,7 +595,11 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-14
   if (P.mode != 2) {
     seq_advct(c, sum2d);
     if (P.npg == 1) seq_baropg(c, sum2d);
-    else return fail(c, POMGPU_EINVAL, "Error: invalid value for npg (only npg=1 is built; baropg_mcc is a 'next' row)");
+    else if (P.npg == 2) seq_baropg_mcc(c, sum2d);
+    else {                                                    // advance.f:117-120
+      fprintf(stderr, "\nError: invalid value for npg\n");
+      c->con.error_status = 1;
+    }
     launch_aam(c);
     xch(c, 1, D3(c, aam), P.kbm1);                            // :137
   }
@@ -717,7 +743,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
-  const int sum2d = (!c->exch && c->P.mode != 2 && c->P.npg == 1);
+  const int sum2d = (!c->exch && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   if ((rc = lateral_viscosity(c, sum2d))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;
   for (int iext = 1; iext <= c->con.isplit; iext++) {
@@ -743,6 +769,7 @@ extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
 extern "C" int pomgpu_advave(pomgpu_ctx *c) { NEED(c); seq_advave(c); return POMGPU_OK; }
 extern "C" int pomgpu_advct(pomgpu_ctx *c) { NEED(c); seq_advct(c); return POMGPU_OK; }
 extern "C" int pomgpu_baropg(pomgpu_ctx *c) { NEED(c); seq_baropg(c); return POMGPU_OK; }
+extern "C" int pomgpu_baropg_mcc(pomgpu_ctx *c) { NEED(c); seq_baropg_mcc(c); return POMGPU_OK; }
 extern "C" int pomgpu_advq(pomgpu_ctx *c, const double *qb, const double *q, const double *qf) {
   NEED(c);
   double *a = dev3(c, qb), *b = dev3(c, q), *d = dev3(c, qf);

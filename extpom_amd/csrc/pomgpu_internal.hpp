@@ -36,6 +36,8 @@ struct KP {
   // current (read) and next (written) generation of ua, va, d, el, elb for the external-mode kernels
   // (k_ext.hip); identical and equal to the blk2d arrays except inside the fused external step
   double *x2[5], *y2[5];
+  // baropg_mcc's extra ghosts: rho4th(0,j,k) [kb x jml], rho4th(i,0,k) [kb x iml], d4th(0,j) [jml], d4th(i,0) [iml]
+  double *g4[4];
 };
 enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb };
 
@@ -176,6 +178,9 @@ struct pomgpu_ctx {
   const double *host2, *host3;   // host bases registered by pomgpu_bind_host
   void (*exch)(void *, double *const *, const int *, int);
   void *exch_user;
+  void (*order)(void *, const double *, int, const double *, int, double *, double *);   // pomgpu_order_fn
+  void *order_user;
+  double *ord_send[2], *ord_recv[2];   // [0] east/west: (kb+1) x jml, [1] north/south: (kb+1) x iml
   double *alt2[5];           // second buffer set of ua, va, d, el, elb (fused external step)
   int ext_parity;            // 1 while the current generation of those five lives in alt2
   int rst_pending;           // trstr/srstr/taurstr of the last step exist only as (rst_fold, rst_fnew) weights
@@ -293,6 +298,8 @@ void launch_realvertvl(pomgpu_ctx *c);
 void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v);
 // k_vert.hip
 void launch_baropg(pomgpu_ctx *c, int sum2d);
+void launch_baropg_mcc(pomgpu_ctx *c, int sum2d);
+void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n);
 void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);

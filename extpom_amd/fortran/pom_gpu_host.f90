@@ -153,6 +153,13 @@ subroutine baropg
   call pomgpu_push_con            ! ramp
   if (pomgpu_baropg(pom_ctx) /= 0) error_status = 1
 end subroutine
+subroutine baropg_mcc
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  call pomgpu_push_con            ! ramp
+  if (pomgpu_baropg_mcc(pom_ctx) /= 0) error_status = 1
+end subroutine
 subroutine dens(si, ti, rhoo)
   use pomgpu_iface
   implicit none

@@ -76,6 +76,7 @@ module pomgpu_iface
   procedure(pomgpu_noarg), bind(C, name='pomgpu_advu') :: pomgpu_advu
   procedure(pomgpu_noarg), bind(C, name='pomgpu_advv') :: pomgpu_advv
   procedure(pomgpu_noarg), bind(C, name='pomgpu_baropg') :: pomgpu_baropg
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_baropg_mcc') :: pomgpu_baropg_mcc
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profq') :: pomgpu_profq
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profu') :: pomgpu_profu
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profv') :: pomgpu_profv

@@ -96,6 +96,44 @@ class Halo:
         self._phase(arrays, t.n_west, t.n_east, take_x, put_x)
         self._phase(arrays, t.n_south, t.n_north, take_y, put_y)
 
+    def order(self, send_e, send_n, recv_w, recv_s):
+        """order2d_mpi / order3d_mpi (parallel_mpi.f:353-480): one-way, eastward and northward.
+        send_e / send_n go to the eastern / northern neighbour, recv_w / recv_s come from the western /
+        southern one (flat tensors; a missing neighbour skips that transfer)."""
+        t = self.t
+        ops, staged = [], []
+        for buf, nb, fn in ((send_e, t.n_east, dist.isend), (recv_w, t.n_west, dist.irecv),
+                            (send_n, t.n_north, dist.isend), (recv_s, t.n_south, dist.irecv)):
+            if nb < 0:
+                continue
+            x = buf
+            if self.staged:
+                x = buf.cpu() if fn is dist.isend else torch.empty(buf.shape, dtype=buf.dtype)
+                if fn is dist.irecv:
+                    staged.append((x, buf))
+            ops.append(dist.P2POp(fn, x, nb, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for host, dev in staged:
+            dev.copy_(host)
+
+    def numpy_order_hook(self):
+        """for OracleTile(order=...): a (nz,ny,nx), ghost_w (nz,ny), ghost_s (nz,nx) numpy views"""
+        def fn(a, ghost_w, ghost_s):
+            nz, ny, nx = a.shape
+            ta = torch.from_numpy(a)
+            self.order(ta[:, :, nx - 3].contiguous().reshape(-1), ta[:, ny - 3, :].contiguous().reshape(-1),
+                       torch.from_numpy(ghost_w).reshape(-1), torch.from_numpy(ghost_s).reshape(-1))
+        return fn
+
+    def device_order_hook(self, device):
+        """for PomGpu.set_order_exchange: raw device addresses of the packed buffers"""
+        def fn(send_e, n_e, send_n, n_n, recv_w, recv_s):
+            w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=device)
+            self.order(w(send_e, n_e), w(send_n, n_n), w(recv_w, n_e), w(recv_s, n_n))
+        return fn
+
     # ---- hooks ----------------------------------------------------------------------------
     def gpu_hook(self, device):
         """callback for PomGpu.set_exchange: device addresses + level counts"""

@@ -23,6 +23,9 @@ class Dims(ctypes.Structure):
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                ctypes.c_int)
+# pomgpu_order_fn: (user, send_east, n_east, send_north, n_north, recv_west, recv_south) -- device addresses
+ORDER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                            ctypes.c_void_p, ctypes.c_void_p)
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -45,6 +48,7 @@ _SIGS = {
     "pomgpu_device_2d": (_P, [_P, _I]),
     "pomgpu_device_3d": (_P, [_P, _I]),
     "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
+    "pomgpu_set_order_exchange": (_I, [_P, ORDER_FN, _P]),
     "pomgpu_halo_pack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
@@ -66,7 +70,7 @@ _SIGS = {
 }
 # argument-less hot-path entry points, same names as the reference subroutines
 NOARG = ["get_time", "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "advance", "advave",
-         "advct", "advu", "advv", "baropg", "profq", "profu", "profv", "vertvl", "realvertvl", "restore_interior"]
+         "advct", "advu", "advv", "baropg", "baropg_mcc", "profq", "profu", "profv", "vertvl", "realvertvl", "restore_interior"]
 for _n in NOARG:
     _SIGS["pomgpu_" + _n] = (_I, [_P])
 

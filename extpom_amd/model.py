@@ -93,6 +93,14 @@ class PomGpu:
         self._exch_cb = _lib.EXCHANGE_FN(cb)
         self._chk(self.L.pomgpu_set_exchange(self.h, self._exch_cb, None), "set_exchange")
 
+    def set_order_exchange(self, fn):
+        """fn(send_east, n_east, send_north, n_north, recv_west, recv_south): device addresses (baropg_mcc's
+        order2d_mpi / order3d_mpi, packed by the library) -- see extpom_amd.halo.Halo.device_order_hook"""
+        def cb(user, se, ne, sn, nn, rw, rs):
+            fn(se, ne, sn, nn, rw, rs)
+        self._order_cb = _lib.ORDER_FN(cb)
+        self._chk(self.L.pomgpu_set_order_exchange(self.h, self._order_cb, None), "set_order_exchange")
+
     # ---- hot path, reference names -------------------------------------------------------
     def _a(self, name):
         return self._p(self.st.field(name))
@@ -144,7 +152,7 @@ def gpu_finish_initial(st: PomState, **kw) -> PomState:
 
     def baropg(s):
         g.upload(s)
-        g.call("baropg")
+        g.call("baropg_mcc" if int(s.npg) == 2 else "baropg")
         g.download(s)
 
     finish_initial(st, dens, baropg)

@@ -88,6 +88,17 @@ double *pomgpu_device_3d(pomgpu_ctx *ctx, int slot3d);
 typedef void (*pomgpu_exchange_fn)(void *user, double *const *dev, const int *nz, int count);
 int pomgpu_set_exchange(pomgpu_ctx *ctx, pomgpu_exchange_fn fn, void *user);
 
+/* order2d_mpi / order3d_mpi of baropg_mcc (parallel_mpi.f:353-480, called at solver.f:958-959): the
+ * 4th-order pressure gradient needs ONE more ghost column to the west and ghost row to the south.  The
+ * library packs what the reference sends -- column im_local-2 / row jm_local-2 of d and of rho-rmean --
+ * into device buffers and asks the hook to move them: `send_east` (n_east doubles) goes to the eastern
+ * neighbour, which receives it as `recv_west`; `send_north` (n_north) to the northern one, received as
+ * `recv_south`.  A tile without the respective neighbour skips that transfer (its recv buffer is not
+ * read).  NULL hook = single tile. */
+typedef void (*pomgpu_order_fn)(void *user, const double *send_east, int n_east, const double *send_north, int n_north,
+                                double *recv_west, double *recv_south);
+int pomgpu_set_order_exchange(pomgpu_ctx *ctx, pomgpu_order_fn fn, void *user);
+
 /* Pack / unpack helpers for the hook (one kernel launch per direction instead of one copy per
  * array and edge).  dir 0 = east/west phase, 1 = north/south phase.  pack: the edge the western
  * (southern) neighbour needs -- column 2 (row 2) of every array -- goes to `to_lo`, column im-1
@@ -122,6 +133,7 @@ int pomgpu_advt2(pomgpu_ctx *ctx, const double *fb, const double *f, const doubl
 int pomgpu_advu(pomgpu_ctx *ctx);                /* solver.f:734-788 */
 int pomgpu_advv(pomgpu_ctx *ctx);                /* solver.f:791-845 */
 int pomgpu_baropg(pomgpu_ctx *ctx);              /* solver.f:848-940 */
+int pomgpu_baropg_mcc(pomgpu_ctx *ctx);          /* solver.f:943-1159 (npg = 2) */
 int pomgpu_dens(pomgpu_ctx *ctx, const double *si, const double *ti, const double *rhoo); /* :1162-1209 */
 int pomgpu_profq(pomgpu_ctx *ctx);               /* solver.f:1212-1538 */
 int pomgpu_proft(pomgpu_ctx *ctx, const double *f, const double *wfsurf, const double *fsurf, int nbc); /* :1541-1683 */

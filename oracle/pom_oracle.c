@@ -113,6 +113,7 @@ int pomo_bind(pomo_tile *T, int aim, int ajm, int akb, int iml_, int jml_, pom_b
   }
   return 0;
 }
+void pomo_set_order(pomo_tile *T, pomo_order_fn fn) { T->order = fn; }
 void pomo_release(pomo_tile *T) { for (int n = 0; n < POMO_NSCR; n++) { free(T->scr[n]); T->scr[n] = NULL; } }
 
 /* ===================================================================================== */

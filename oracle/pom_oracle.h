@@ -58,6 +58,9 @@ void pomo_advt2(pomo_tile *t, double *fb, double *f, double *fclim, double *ff);
 void pomo_advu(pomo_tile *t);
 void pomo_advv(pomo_tile *t);
 void pomo_baropg(pomo_tile *t);
+void pomo_baropg_mcc(pomo_tile *t);   /* solver.f:943-1159 (npg = 2) */
+typedef void (*pomo_order_fn)(void *user, const double *a, int nx, int ny, int nz, double *ghost_w, double *ghost_s);
+void pomo_set_order(pomo_tile *t, pomo_order_fn fn);
 void pomo_dens(pomo_tile *t, double *si, double *ti, double *rhoo);
 void pomo_profq(pomo_tile *t);
 void pomo_proft(pomo_tile *t, double *f, double *wfsurf, double *fsurf, int nbc);

@@ -34,12 +34,14 @@ def lib():
 _EXCH2 = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int)
 _EXCH3 = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                           ctypes.c_int)
+_ORDER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
 
 
 class OracleTile:
     """Binds a PomState to the C oracle; every pomo_* entry point is reachable through call()."""
 
-    def __init__(self, st, exch2d=None, exch3d=None):
+    def __init__(self, st, exch2d=None, exch3d=None, order=None):
         self.st = st
         L = self.L = lib()
         self._buf = ctypes.create_string_buffer(L.pomo_tile_size())
@@ -84,6 +86,15 @@ class OracleTile:
             cb = _EXCH3(lambda user, a, nx, ny, nz: exch3d(np.ctypeslib.as_array(a, shape=(nz, ny, nx))))
             self._cb.append(cb)
             self._poke(self._off_ex3, ctypes.cast(cb, ctypes.c_void_p).value)
+
+        if order is not None:       # order(a[nz,ny,nx], ghost_w[nz,ny], ghost_s[nz,nx]) -- parallel_mpi.f:353-480
+            as_ = np.ctypeslib.as_array
+            cb = _ORDER(lambda user, a, nx, ny, nz, gw, gs: order(as_(a, shape=(nz, ny, nx)), as_(gw, shape=(nz, ny)),
+                                                                   as_(gs, shape=(nz, nx))))
+            self._cb.append(cb)
+            L.pomo_set_order.argtypes = [ctypes.c_void_p, _ORDER]
+            L.pomo_set_order.restype = None
+            L.pomo_set_order(self.t, cb)
 
     def _poke(self, off, value):
         ctypes.c_void_p.from_buffer(self._buf, off).value = value

@@ -13,14 +13,14 @@ import torch.multiprocessing as mp
 
 from extpom_amd import decomp
 from extpom_amd.cases import finish_initial, make_case
-from extpom_amd.halo import DeviceHalo
+from extpom_amd.halo import DeviceHalo, Halo
 from extpom_amd.layout import BLK2D, BLK3D
 
 IM, JM, KB, STEPS = 97, 61, 16, 3
 SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
 
 
-def worker(rank, world, split, port, out):
+def worker(rank, world, split, port, out, nml):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,19 +29,20 @@ def worker(rank, world, split, port, out):
     nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
-    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10)
+    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10, **nml)
     # kernels and torch's pack/unpack must share ONE stream; torch's default stream has handle 0, which
     # the C ABI reads as "create your own", so make a real stream current and hand that over
     ts = torch.cuda.Stream()
     torch.cuda.set_stream(ts)
     g = PomGpu(st, device=0, stream=ts.cuda_stream)
     halo = DeviceHalo(g, tile, torch.device("cuda", 0), staged=True)
+    g.set_order_exchange(Halo(tile, staged=True).device_order_hook(torch.device("cuda", 0)))   # baropg_mcc (npg = 2)
 
     def dens(s, a, b, c):
         g.upload(s); g.call("dens", a, b, c); g.download(s)
 
     def baropg(s):
-        g.upload(s); g.call("baropg"); g.download(s)
+        g.upload(s); g.call("baropg_mcc" if int(s.npg) == 2 else "baropg"); g.download(s)
 
     finish_initial(st, dens, baropg)
     g.upload(st)
@@ -54,14 +55,14 @@ def worker(rank, world, split, port, out):
     dist.destroy_process_group()
 
 
-def main(split):
+def main(split, nml):
     import tempfile
     from oracle.pyoracle import OracleTile, oracle_finish_initial
     out = tempfile.mkdtemp()
     port = 29700 + (os.getpid() % 200)
     world = 4 if split == "xy" else 2
-    mp.spawn(worker, args=(world, split, port, out), nprocs=world, join=True)
-    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10)
+    mp.spawn(worker, args=(world, split, port, out, nml), nprocs=world, join=True)
+    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
     bad = []
@@ -85,4 +86,4 @@ def main(split):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "x")
+    main(sys.argv[1] if len(sys.argv) > 1 else "x", dict(npg=2) if "npg2" in sys.argv[2:] else {})

@@ -20,18 +20,19 @@ IM, JM, KB, STEPS = 41, 35, 11, 4
 SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
 
 
-def worker(rank, world, split, port, out):
+def worker(rank, world, split, port, out, nml):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
-    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10)
+    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10, **nml)
     halo = Halo(tile)
-    ot = OracleTile(st, exch2d=halo.numpy_hook2d(), exch3d=halo.numpy_hook3d())
+    ot = OracleTile(st, exch2d=halo.numpy_hook2d(), exch3d=halo.numpy_hook3d(), order=halo.numpy_order_hook())
     from extpom_amd.cases import finish_initial
-    finish_initial(st, lambda s, a, b, c: ot.call("dens", ot.a3(a), ot.a3(b), ot.a3(c)), lambda s: ot.call("baropg"))
+    finish_initial(st, lambda s, a, b, c: ot.call("dens", ot.a3(a), ot.a3(b), ot.a3(c)),
+                   lambda s: ot.call("baropg_mcc" if int(s.npg) == 2 else "baropg"))
     ot.run(STEPS)
     np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
              n=halo.count, **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
@@ -39,13 +40,13 @@ def worker(rank, world, split, port, out):
     dist.destroy_process_group()
 
 
-def main(split):
+def main(split, nml):
     import tempfile
     out = tempfile.mkdtemp()
     port = 29600 + (os.getpid() % 200)
     world = 4 if split == "xy" else 2
-    mp.spawn(worker, args=(world, split, port, out), nprocs=world, join=True)
-    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10)
+    mp.spawn(worker, args=(world, split, port, out, nml), nprocs=world, join=True)
+    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
     bad = []
@@ -71,4 +72,4 @@ def main(split):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "x")
+    main(sys.argv[1] if len(sys.argv) > 1 else "x", dict(npg=2) if "npg2" in sys.argv[2:] else {})

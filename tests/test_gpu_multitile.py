@@ -18,3 +18,11 @@ def test_two_tiles_on_one_gpu_match_single_tile_oracle(split):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py"), split], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_four_tiles_with_the_4th_order_pressure_gradient():
+    """npg = 2 on a 2x2 split: baropg_mcc's extra ghost column / row travel through the order hook"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py"), "xy", "npg2"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -48,7 +48,8 @@ def test_native_library_is_the_one_running():
 
 
 @pytest.mark.parametrize("name", ["seamount_default", "seamount_nadv1", "seamount_nitera2", "seamount_mode2",
-                                  "seamount_mode4", "seamount_nbc3", "island_default", "basin_default", "basin_alpha"])
+                                  "seamount_mode4", "seamount_nbc3", "island_default", "basin_default", "basin_alpha",
+                                  "seamount_npg2", "island_npg2"])
 def test_gpu_reproduces_reference_digests(golden, name):
     """every restart-list field after every checkpoint hashes to what the REFERENCE produced"""
     OracleTile, oracle_finish_initial = _oracle()
@@ -95,7 +96,7 @@ def test_short_wave_penetration_within_tolerance(golden_planes):
 
 
 ROUTINES = [
-    ("advave", (), ()), ("advct", (), ()), ("advu", (), ()), ("advv", (), ()), ("baropg", (), ()), ("profq", (), ()),
+    ("advave", (), ()), ("advct", (), ()), ("advu", (), ()), ("advv", (), ()), ("baropg", (), ()), ("baropg_mcc", (), ()), ("profq", (), ()),
     ("profu", (), ()), ("profv", (), ()), ("vertvl", (), ()), ("realvertvl", (), ()), ("lateral_viscosity", (), ()),
     ("mode_interaction", (), ()), ("mode_external", (), ()), ("mode_internal", (), ()),
     ("advq", ("q2b", "q2", "uf"), ()), ("advt1", ("tb", "t", "tclim", "uf"), ()), ("advt2", ("sb", "s", "sclim", "vf"), ()),

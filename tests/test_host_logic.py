@@ -97,3 +97,11 @@ def test_two_rank_halo_exchange_is_decomposition_invariant():
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "HALO-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_order_exchange_of_baropg_mcc_is_decomposition_invariant():
+    """npg = 2: the 4th-order pressure gradient needs one more ghost column / row (order2d_mpi,
+    order3d_mpi); 2x2 split over gloo against the single-tile run"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "halo_worker.py"), "xy", "npg2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HALO-OK" in r.stdout, r.stdout + r.stderr

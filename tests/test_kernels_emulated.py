@@ -34,7 +34,8 @@ def diff(a, b, skip=SCRATCH):
     ("seamount", dict(), 8), ("island", dict(), 6), ("basin", dict(), 6),
     ("seamount", dict(nadv=1), 4), ("island", dict(nitera=2), 4), ("seamount", dict(nitera=3, sw=1.0), 3),
     ("seamount", dict(mode=4), 4), ("seamount", dict(mode=2), 4), ("seamount", dict(nbct=3, nbcs=3), 4),
-    ("basin", dict(isplit=10, alpha=0.225), 4), ("seamount", dict(isplit=7), 3)])   # odd isplit: the buffer generations end swapped
+    ("basin", dict(isplit=10, alpha=0.225), 4), ("seamount", dict(isplit=7), 3),
+    ("island", dict(npg=2), 4), ("seamount", dict(npg=2, nadv=1), 3)])   # odd isplit: the buffer generations end swapped
 def test_steps_bit_identical(case, nml, steps):
     kw = dict(dte=6.0, isplit=30)
     kw.update(nml)
@@ -112,7 +113,7 @@ def warm_state(case="island"):
 
 
 ROUTINES = [
-    ("advave", (), ()), ("advct", (), ()), ("advu", (), ()), ("advv", (), ()), ("baropg", (), ()), ("profq", (), ()),
+    ("advave", (), ()), ("advct", (), ()), ("advu", (), ()), ("advv", (), ()), ("baropg", (), ()), ("baropg_mcc", (), ()), ("profq", (), ()),
     ("profu", (), ()), ("profv", (), ()), ("vertvl", (), ()), ("realvertvl", (), ()), ("lateral_viscosity", (), ()),
     ("mode_interaction", (), ()), ("mode_external", (), ()), ("mode_internal", (), ()),
     ("advq", ("q2b", "q2", "uf"), ()), ("advt1", ("tb", "t", "tclim", "uf"), ()), ("advt2", ("sb", "s", "sclim", "vf"), ()),
