@@ -212,6 +212,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   }
   if (ok) { P.g4[2] = c->ord_recv[0]; P.g4[0] = c->ord_recv[0] + P.jml; P.g4[3] = c->ord_recv[1]; P.g4[1] = c->ord_recv[1] + P.iml; }
   alloc(&c->d_vel, 4);
+  alloc(&c->d_stats, 8);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
   if (!ok) {
@@ -239,7 +240,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < 5; n++) (void)hipFree(c->alt2[n]);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
-  (void)hipFree(c->d_vel); (void)hipFree(c->d_err);
+  (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
   ProfState *ps = PS(c);
   if (ps) {
     for (auto &p : ps->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -737,6 +738,21 @@ extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, in
             (int)out[1], (int)out[2]);
     c->con.error_status = 1;
   }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_domain_stats(pomgpu_ctx *c, double *out, int sums_only) {   // advance.f:644-756
+  NEED(c);
+  if (!out) return POMGPU_EINVAL;
+  launch_domain_stats(c, c->d_stats);
+  double s[7];                                                // vtot atot mtot stot sum(tb*dvol) sum(et*darea) ekin
+  HIPCHK(c, hipMemcpyAsync(s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double tavg = s[4], savg = 0., eavg = s[5];
+  if (!sums_only) {                                           // what my_task 0 does after sum0d_mpi (:680-686, :728-736)
+    eavg = (s[1] != 0) ? s[5] / s[1] : 0.;
+    if (s[0] != 0) { tavg = s[4] / s[0]; savg = s[3] / s[0]; } else { tavg = 0.; savg = 0.; }
+  }
+  out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; out[3] = s[3]; out[4] = tavg; out[5] = savg; out[6] = eavg; out[7] = s[6];
   return POMGPU_OK;
 }
 extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59

@@ -187,6 +187,7 @@ struct pomgpu_ctx {
   double rst_fold, rst_fnew;
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
   int *d_err;                // device error flag
+  double *d_stats;           // device: the seven sums of domain_stats
   // profiling
   bool prof_on;
   ProfEntry prof[96];
@@ -323,3 +324,4 @@ int launch_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count
 int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo, const double *from_hi);
 // k_reduce.hip
 void launch_check_velocity(pomgpu_ctx *c);
+void launch_domain_stats(pomgpu_ctx *c, double *out_dev);

@@ -98,6 +98,47 @@ subroutine check_velocity
   rc = pomgpu_get_con(pom_ctx, c_loc(alpha))     ! brings error_status back
 end subroutine
 
+! domain_stats (advance.f:644-756): the tile's sums come from the device; the reduction over ranks and
+! the averages are the reference's own lines (sum0d_mpi / bcast0d_mpi stay the host's, parallel_mpi.f:125-151)
+subroutine domain_stats(vtot, atot, mtot, stot, tavg, savg, eavg, ekin)
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  double precision, intent(out) :: vtot, atot, mtot, stot, tavg, savg, eavg, ekin
+  real(c_double) :: o(8)
+  if (pomgpu_domain_stats(pom_ctx, o, 1_c_int) /= 0) error_status = 1
+  vtot = o(1); atot = o(2); mtot = o(3); stot = o(4); tavg = o(5); savg = 0.d0; eavg = o(7); ekin = o(8)
+  call sum0d_mpi(atot, 0)
+  call sum0d_mpi(eavg, 0)
+  call sum0d_mpi(vtot, 0)
+  call sum0d_mpi(mtot, 0)
+  call sum0d_mpi(stot, 0)
+  call sum0d_mpi(tavg, 0)
+  call sum0d_mpi(ekin, 0)
+  if (my_task == 0) then
+    if (atot /= 0) then
+      eavg = eavg/atot
+    else
+      eavg = 0.
+    end if
+    if (vtot /= 0) then
+      tavg = tavg/vtot
+      savg = stot/vtot
+    else
+      tavg = 0.
+      savg = 0.
+    end if
+  end if
+  call bcast0d_mpi(atot, 0)
+  call bcast0d_mpi(vtot, 0)
+  call bcast0d_mpi(mtot, 0)
+  call bcast0d_mpi(stot, 0)
+  call bcast0d_mpi(tavg, 0)
+  call bcast0d_mpi(savg, 0)
+  call bcast0d_mpi(eavg, 0)
+  call bcast0d_mpi(ekin, 0)
+end subroutine
+
 ! ---- kernels (solver.f), reference signatures -----------------------------------------------
 subroutine advave
   use pomgpu_iface

@@ -15,6 +15,7 @@ program pom_gpu_main
   namelist/pom_nml/ title,wrk_pth,netcdf_file,mode,nadv,nitera,sw,npg,dte,isplit,time_start,nread_rst, &
                     read_rst_file,cont_bry,write_rst,write_rst_file,days,prtd1,prtd2,swtch,ntp,nbct,nbcs
   integer :: nsteps, nrec, n, rc, n2, n3, nbd
+  double precision :: vtot, atot, mtot, stot, tavg, savg, eavg, ekin
   double precision, allocatable, target :: tr(:,:,:,:), sr(:,:,:,:)
   character(len=256) :: fin, fout
 
@@ -53,6 +54,9 @@ program pom_gpu_main
     iint = iint + 1
     call advance_hot
   end do
+  my_task = 0; master_task = 0
+  call domain_stats(vtot, atot, mtot, stot, tavg, savg, eavg, ekin)   ! print_section's sums, no state download needed
+  write(6,'(a,8es25.16e3)') 'domain_stats:', vtot, atot, mtot, stot, tavg, savg, eavg, ekin
   call pomgpu_download_state
   open(72, file=trim(fout), form='unformatted', access='stream', status='replace')
   call blk_write(72, aam2d, 73*n2)
@@ -82,4 +86,16 @@ subroutine advance_hot
   end do
   call mode_internal
   call check_velocity
+end subroutine
+
+! this driver runs ONE task: the rank reductions of the reference's parallel_mpi.f:125-151 are identities
+subroutine sum0d_mpi(work, to)
+  implicit none
+  double precision work
+  integer to
+end subroutine
+subroutine bcast0d_mpi(work, from)
+  implicit none
+  double precision work
+  integer from
 end subroutine

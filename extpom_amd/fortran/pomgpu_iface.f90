@@ -39,6 +39,9 @@ module pomgpu_iface
     integer(c_int) function pomgpu_check_velocity(ctx, vamax, imax, jmax) bind(C, name='pomgpu_check_velocity')
       import; type(c_ptr), value :: ctx; real(c_double) :: vamax; integer(c_int) :: imax, jmax
     end function
+    integer(c_int) function pomgpu_domain_stats(ctx, out, sums_only) bind(C, name='pomgpu_domain_stats')
+      import; type(c_ptr), value :: ctx; real(c_double) :: out(8); integer(c_int), value :: sums_only
+    end function
     integer(c_int) function pomgpu_advq(ctx, qb, q, qf) bind(C, name='pomgpu_advq')
       import; type(c_ptr), value :: ctx, qb, q, qf
     end function

@@ -53,6 +53,7 @@ _SIGS = {
     "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pomgpu_run": (_I, [_P, _I]),
+    "pomgpu_domain_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double), _I]),
     "pomgpu_advq": (_I, [_P, _P, _P, _P]),
     "pomgpu_advt1": (_I, [_P, _P, _P, _P, _P]),
     "pomgpu_advt2": (_I, [_P, _P, _P, _P, _P]),

@@ -93,6 +93,12 @@ class PomGpu:
         self._exch_cb = _lib.EXCHANGE_FN(cb)
         self._chk(self.L.pomgpu_set_exchange(self.h, self._exch_cb, None), "set_exchange")
 
+    def domain_stats(self, sums_only=False):
+        """(vtot, atot, mtot, stot, tavg, savg, eavg, ekin) of advance.f:644-756, reduced on the device"""
+        out = (ctypes.c_double * 8)()
+        self._chk(self.L.pomgpu_domain_stats(self.h, out, 1 if sums_only else 0), "domain_stats")
+        return tuple(out)
+
     def set_order_exchange(self, fn):
         """fn(send_east, n_east, send_north, n_north, recv_west, recv_south): device addresses (baropg_mcc's
         order2d_mpi / order3d_mpi, packed by the library) -- see extpom_amd.halo.Halo.device_order_hook"""

@@ -117,6 +117,12 @@ int pomgpu_mode_external(pomgpu_ctx *ctx);       /* advance.f:205-353; uses blkc
 int pomgpu_mode_internal(pomgpu_ctx *ctx);       /* advance.f:356-537 */
 /* advance.f:611-641; any of the out pointers may be NULL.  Synchronises the stream. */
 int pomgpu_check_velocity(pomgpu_ctx *ctx, double *vamax, int *imax, int *jmax);
+/* domain_stats (advance.f:644-756), the sums behind print_section, reduced on the device (deterministic
+ * tree; no state download).  out[8] = vtot, atot, mtot, stot, tavg, savg, eavg, ekin in the reference's
+ * argument order.  sums_only != 0: this tile's partial sums as they stand before sum0d_mpi (out[4] =
+ * sum(tb*dvol), out[6] = sum(et*darea), out[5] = 0) -- the caller reduces over ranks and forms the averages
+ * exactly as the reference does on my_task 0; sums_only == 0: the single-task result. */
+int pomgpu_domain_stats(pomgpu_ctx *ctx, double *out, int sums_only);
 /* One internal step for the current blkcon.iint: get_time, lateral_viscosity, mode_interaction,
  * isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus file forcing,
  * print and output, which stay on the host).  Does not synchronise. */

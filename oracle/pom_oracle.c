@@ -1487,6 +1487,34 @@ void pomo_mode_internal(pomo_tile *T) {
 }
 
 /* check_velocity -- advance.f:611-641 */
+/* domain_stats -- advance.f:644-756.  dvol is assigned on 2:imm1 x 2:jmm1 only (:692-695) and is zero
+ * elsewhere, so every 3-D sum -- including the "physical edge" additions of vtot, tavg, stot, ekin, which
+ * read the zero edge of dvol / dmass -- is a sum over the interior; atot and eavg do include the edges
+ * (without corners).  Plain left-to-right additions here (k outermost as in the array expressions). */
+void pomo_domain_stats(pomo_tile *T, double *out, int sums_only) {
+  int i, j, k;
+  double vtot = 0., atot = 0., mtot = 0., stot = 0., tavg = 0., savg = 0., eavg = 0., ekin = 0.;
+#define DAREA(i,j) (dx(i,j)*dy(i,j)*fsm(i,j))
+  for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++) { atot += DAREA(i,j); eavg += et(i,j)*DAREA(i,j); }   /* :666, :672 */
+  if (n_west == -1)  for (j = 2; j <= jmm1; j++) { atot += DAREA(1,j);  eavg += et(1,j)*DAREA(1,j); }            /* :667, :673 */
+  if (n_east == -1)  for (j = 2; j <= jmm1; j++) { atot += DAREA(im,j); eavg += et(im,j)*DAREA(im,j); }
+  if (n_south == -1) for (i = 2; i <= imm1; i++) { atot += DAREA(i,1);  eavg += et(i,1)*DAREA(i,1); }
+  if (n_north == -1) for (i = 2; i <= imm1; i++) { atot += DAREA(i,jm); eavg += et(i,jm)*DAREA(i,jm); }
+  for (k = 1; k <= kbm1; k++) for (j = 2; j <= jmm1; j++) for (i = 2; i <= imm1; i++) {
+    const double dvol = DAREA(i,j)*dt(i,j)*dz(k);                                                             /* :692-695 */
+    const double dmass = dvol*(rho(i,j,k)*rhoref+1000.);                                                       /* :702-703 */
+    vtot += dvol; mtot += dmass;
+    tavg += tb(i,j,k)*dvol; stot += sb(i,j,k)*dvol;                                                            /* :707-708 */
+    ekin += .5*(dmass*(u(i,j,k)*u(i,j,k)+v(i,j,k)*v(i,j,k)));                                                  /* :738-740 */
+  }
+#undef DAREA
+  if (!sums_only) {                                                                                           /* :680-686, :728-736 */
+    eavg = (atot != 0) ? eavg/atot : 0.;
+    if (vtot != 0) { tavg = tavg/vtot; savg = stot/vtot; } else { tavg = 0.; savg = 0.; }
+  }
+  out[0] = vtot; out[1] = atot; out[2] = mtot; out[3] = stot; out[4] = tavg; out[5] = savg; out[6] = eavg; out[7] = ekin;
+}
+
 void pomo_check_velocity(pomo_tile *T) {
   int i, j;
   double vamax = 0.; int imax = 0, jmax = 0;

@@ -77,6 +77,11 @@ void pomo_mode_interaction(pomo_tile *t);
 void pomo_mode_external(pomo_tile *t);
 void pomo_mode_internal(pomo_tile *t);
 void pomo_check_velocity(pomo_tile *t);
+/* domain_stats -- advance.f:644-756.  out = vtot, atot, mtot, stot, tavg, savg, eavg, ekin (the reference's
+ * argument order).  sums_only != 0: this tile's partial sums before sum0d_mpi (tavg = sum tb*dvol, eavg =
+ * sum et*darea, savg = 0); == 0: the single-task result (averages formed as on my_task 0).  The reference
+ * uses the SUM intrinsic, whose order of additions is the compiler's: parity is to rounding, not bitwise. */
+void pomo_domain_stats(pomo_tile *t, double *out, int sums_only);
 /* hot-path sequence of advance (advance.f:6-59) for the step con->iint */
 void pomo_advance(pomo_tile *t);
 /* nsteps x { iint += 1; advance } */

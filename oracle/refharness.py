@@ -108,6 +108,16 @@ class RefLib:
         fn.restype = None
         fn(*args)
 
+    def mpi_init(self):
+        """the reference's own initialize_mpi (parallel_mpi.f:6-20) once per process: a singleton MPI_COMM_WORLD,
+        needed only by routines that reduce over ranks (domain_stats -> sum0d_mpi)"""
+        flag = ctypes.c_int(0)
+        self.lib.MPI_Initialized(ctypes.byref(flag))
+        if not flag.value:
+            keep = int(self.con["error_status"][0])
+            self.call("initialize_mpi")
+            self.con["error_status"][0] = keep
+
     def call_idx(self, name, idx):
         self.call(name, ctypes.byref(ctypes.c_int(idx)))
 

@@ -69,3 +69,10 @@ def test_fortran_driver_matches_oracle(tmp_path):
     bad = [n for i, n in enumerate(BLK2D) if n not in SCRATCH and not np.array_equal(a.blk2d[i], b2[i])]
     bad += [n for i, n in enumerate(BLK3D) if n not in SCRATCH and not np.array_equal(a.blk3d[i], b3[i])]
     assert not bad, bad
+    # print_section's sums came from the device through the Fortran domain_stats wrapper (no state download)
+    import ctypes
+    line = [l for l in r.stdout.splitlines() if l.startswith("domain_stats:")][0]
+    got = np.array([float(x) for x in line.split()[1:]])
+    out = (ctypes.c_double * 8)()
+    OracleTile(a).call("domain_stats", out, ctypes.c_int(0))
+    np.testing.assert_allclose(got, np.array(list(out)), rtol=1e-12, atol=0)

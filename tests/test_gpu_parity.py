@@ -147,6 +147,27 @@ def test_check_velocity_wavefront_reduction():
         a.error_status = 0
 
 
+def test_domain_stats_on_device():
+    """print_section's sums (advance.f:644-756) reduced on the device: equal to the oracle to rounding,
+    and the same bits every time (fixed reduction tree, no atomics)"""
+    import ctypes
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("island", 130, 97, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    ot.run(4)
+    g = _gpu(b)
+    g.run(4)
+    for sums_only in (0, 1):
+        out = (ctypes.c_double * 8)()
+        ot.call("domain_stats", out, ctypes.c_int(sums_only))
+        got = np.array(g.domain_stats(sums_only=bool(sums_only)))
+        np.testing.assert_allclose(got, np.array(list(out)), rtol=1e-12, atol=0)
+        assert got.tolist() == list(g.domain_stats(sums_only=bool(sums_only)))
+    g.close()
+
+
 def test_1000_internal_steps_within_1e_10():
     """north_star's bar: all prognostic fields within 1e-10 relative after 1000 internal steps"""
     OracleTile, oracle_finish_initial = _oracle()

@@ -105,3 +105,25 @@ def test_order_exchange_of_baropg_mcc_is_decomposition_invariant():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "halo_worker.py"), "xy", "npg2"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "HALO-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_domain_stats_partial_sums_add_up_over_tiles():
+    """sums_only: the tile-local sums of a 2x2 split (what sum0d_mpi would add) equal the single-tile sums"""
+    import ctypes
+    import numpy as np
+    from extpom_amd import decomp
+    from extpom_amd.cases import cut_tile, make_case
+    from oracle.pyoracle import OracleTile, oracle_finish_initial
+    g = make_case("island", 41, 35, 11, dte=6.0, isplit=10)
+    oracle_finish_initial(g)
+    OracleTile(g).run(3)
+
+    def sums(st):
+        out = (ctypes.c_double * 8)()
+        OracleTile(st).call("domain_stats", out, ctypes.c_int(1))
+        return np.array(list(out))
+
+    whole = sums(g)
+    iml, jml = decomp.local_size(41, 35, 2, 2)
+    parts = sum(sums(cut_tile(g, decomp.make_tile(r, 41, 35, iml, jml, n_proc=4))) for r in range(4))
+    np.testing.assert_allclose(parts, whole, rtol=1e-12, atol=0)

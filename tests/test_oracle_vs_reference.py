@@ -79,3 +79,21 @@ def test_each_routine_bit_identical():
         both("bcond", (i(idx),), (ctypes.c_int(idx),))
     for idx in (3, 5):
         both("bcondorl", (i(idx),), (ctypes.c_int(idx),))
+
+
+def test_domain_stats_matches_reference_to_rounding():
+    """advance.f:644-756 uses the SUM intrinsic (order of additions is the compiler's): 1e-13 relative"""
+    a = make_case("island", 65, 49, 21, dte=6.0, isplit=30)
+    ref_finish_initial(a)
+    lib = RefLib(65, 49, 21)
+    lib.put(a)
+    for n in range(1, 6):
+        lib.con["iint"][0] = n
+        lib.advance()
+    lib.get(a)
+    lib.mpi_init()
+    vals = [ctypes.c_double() for _ in range(8)]
+    lib.call("domain_stats", *[ctypes.byref(v) for v in vals])
+    out = (ctypes.c_double * 8)()
+    OracleTile(a).call("domain_stats", out, ctypes.c_int(0))
+    np.testing.assert_allclose(np.array(list(out)), np.array([v.value for v in vals]), rtol=1e-13, atol=0)
