@@ -38,7 +38,6 @@ NML = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
 # + write once; 2-D arrays cost 1/kb and are not counted) -- DESIGN.md "Kernels" derives each row from
 # SURVEY 8(a)/(d).  bytes per launch = passes * 8 B * im*jm*kb of the tile.
 KERNEL_PASSES = {
-    "k_advt2_fused": 7,      # a13: R fb,fclim,u,v,w,aam  W ff
     "k_profq": 23,           # a10 + a11, one tile (production term and the q2/q2l Asselin filter inside): R kq,km,kh,t,s,rho,q2b,q2lb,q2,q2l,uf,vf,u,v W q2b,q2lb,q2,q2l,l,dtef,kq,km,kh
     "k_profq/tiles": 22,     # several tiles: prod comes from k_profq_prod (exchanged): R ...,prod instead of u,v
     "k_advct_col": 7,        # a2, one tile: R u,v,ub,vb,aam W advx,advy
@@ -63,7 +62,6 @@ KERNEL_PASSES = {
     "k_advuv_col": 11,       # a17: R w,u,v,ub,vb,advx,advy,drhox,drhoy W uf,vf
     "k_aam_pair": 3,
     "k_realvertvl_col": 4,
-    "k_ts_filter": 10,       # a15: R uf,vf,t,tb,s,sb W tb,t,sb,s (+uf,vf masks)
     "k_q_filter": 10,
     "k_restore": 13,         # R trstrb/f,srstrb/f,taurstrb/f,t,tb,s,sb W trstr,srstr,taurstr,t,tb,s,sb (not in SURVEY's 133)
     "k_dens": 3,             # a16

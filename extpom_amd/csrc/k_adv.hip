@@ -416,66 +416,9 @@ __device__ __forceinline__ void c_advt2_diff(const KP &P, const int i, const int
                               advt2_ydiff(P, fb, fc, i, j + 1, k) - advt2_ydiff(P, fb, fc, i, j, k)) /
                         ((h_(i, j) + F2(etf, i, j)) * F2(art, i, j));
 }
-// nitera == 1: the whole of advt2 in one pass.  Mass fluxes and upwind/diffusive face fluxes are
-// formed in registers from u, v, w, fb; the first (intermediate) halo exchange of ff and the
-// trailing smol_adif flux update are dead for nitera = 1 and only smol_adif's mask survives.
-__device__ __forceinline__ void c_advt2_fused(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fcl, double *ff);
-__global__ void k_advt2_fused(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
-  MARCH3(c_advt2_fused(P, i, j, k, fb, f, fcl, ff))
-}
-__device__ __forceinline__ void c_advt2_fused(const KP &P, const int i, const int j, const int k, const double *fb, const double *f, const double *fcl, double *ff) {
-  if (!(k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1)) {
-    G3(ff, i, j, k) = G3(ff, i, j, k) * F2(fsm, i, j);                                   // solver.f:1898-1900
-    return;
-  }
-  const double art = F2(art, i, j);
-  const double fc = G3(fb, i, j, k);
-  const double dtc = dt_(i, j), dyc = dy_(i, j), dxc = dx_(i, j);
-  const double xme = 0.25 * (dyc + dy_(i + 1, j)) * (dtc + dt_(i + 1, j)) * u_(i + 1, j, k);
-  const double xmw = 0.25 * (dy_(i - 1, j) + dyc) * (dt_(i - 1, j) + dtc) * u_(i, j, k);
-  const double ymn = 0.25 * (dxc + dx_(i, j + 1)) * (dtc + dt_(i, j + 1)) * v_(i, j + 1, k);
-  const double yms = 0.25 * (dx_(i, j - 1) + dxc) * (dt_(i, j - 1) + dtc) * v_(i, j, k);
-  // solver.f:605-606 defines xmassflux for j<=jmm1 only and :612-613 ymassflux for i<=imm1 only:
-  // both hold for every face of an interior cell
-  const double xe = upw(xme, fc, G3(fb, i + 1, j, k));
-  const double xw = upw(xmw, G3(fb, i - 1, j, k), fc);
-  const double yn = upw(ymn, fc, G3(fb, i, j + 1, k));
-  const double ys = upw(yms, G3(fb, i, j - 1, k), fc);
-  double zu, zl;
-  if (k == 1) zu = w_(i, j, 1) * G3(f, i, j, 1) * art;
-  else zu = upw(w_(i, j, k), fc, G3(fb, i, j, k - 1)) * art;
-  if (k == P.kbm1) zl = 0.;
-  else zl = upw(w_(i, j, k + 1), G3(fb, i, j, k + 1), fc) * art;
-  double r = xe - xw + yn - ys + (zu - zl) / F1(dz, k);
-  r = (fc * ((h_(i, j) + F2(etb, i, j)) * art) - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
-  r = r * F2(fsm, i, j);
-  r = r - P.dti2 * (advt2_xdiff(P, fb, fcl, i + 1, j, k) - advt2_xdiff(P, fb, fcl, i, j, k) +
-                    advt2_ydiff(P, fb, fcl, i, j + 1, k) - advt2_ydiff(P, fb, fcl, i, j, k)) /
-              ((h_(i, j) + F2(etf, i, j)) * art);
-  G3(ff, i, j, k) = r;
-}
+// (nitera == 1 takes k_advt2_col, k_tile.hip)
 
 // ---------------------------------------------------------------------------------------------
-// bcond(4) mask + Asselin filter + rotation of t/s -- bounds_forcing.f:233-240, advance.f:444-449
-__device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int j, const int k, int mask);
-__global__ void k_ts_filter(KP P, int mask) {
-  MARCH3(c_ts_filter(P, i, j, k, mask))
-}
-__device__ __forceinline__ void c_ts_filter(const KP &P, const int i, const int j, const int k, int mask) {
-  double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
-  if (mask && k <= P.kbm1 && i <= P.im && j <= P.jm) {
-    const double m = F2(fsm, i, j);
-    uf = uf * m;
-    vf = vf * m;
-    F3(uf, i, j, k) = uf;
-    F3(vf, i, j, k) = vf;
-  }
-  const double t = F3(t, i, j, k), s = F3(s, i, j, k);
-  F3(tb, i, j, k) = t + .5 * P.smoth * (uf + F3(tb, i, j, k) - 2. * t);
-  F3(t, i, j, k) = uf;
-  F3(sb, i, j, k) = s + .5 * P.smoth * (vf + F3(sb, i, j, k) - 2. * s);
-  F3(s, i, j, k) = vf;
-}
 // mode_internal, tracer tail in ONE pass (nadv=2 path): the in-place round trips of advt2 on tb/sb
 // (solver.f:691,715), bcond(4)'s mask (bounds_forcing.f:233-240), the Asselin filter and rotation of
 // t,s (advance.f:444-449), restore_interior's interpolation, relaxation and mask
@@ -839,11 +782,6 @@ __global__ void __launch_bounds__(256) k_aam_pair(KP P) {
 #undef LD2
 #undef A3
 
-__global__ void k_fill(double *p, size_t n, double v) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; t < n; t += stride) p[t] = v;
-}
 
 // ---- launchers --------------------------------------------------------------------------------
 void launch_advct_a(pomgpu_ctx *c) { LAUNCH(c, k_advct_a, gridm(c->P), blk2(), c->P); }
@@ -887,14 +825,10 @@ void launch_mask3(pomgpu_ctx *c, double *a, const double *m2) { LAUNCH(c, k_mask
 void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, gridm(c->P), blk2(), c->P, ff); }
 void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, gridm(c->P), blk2(), c->P, dst, src); }
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, gridm(c->P), blk2(), c->P, fb, fc, ff); }
-void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
-  LAUNCH(c, k_advt2_fused, gridm(c->P), blk2(), c->P, fb, f, fc, ff);
-}
 void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst) {
   LAUNCH(c, k_ts_update, gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst);
 }
 void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore_fields, gridm(c->P), blk2(), c->P, fold, fnew); }
-void launch_ts_filter(pomgpu_ctx *c, int mask) { LAUNCH(c, k_ts_filter, gridm(c->P), blk2(), c->P, mask); }
 void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, gridm(c->P), blk2(), c->P); }
 void launch_mask_uv(pomgpu_ctx *c) { LAUNCH(c, k_mask_uv, gridm(c->P), blk2(), c->P); }
 void launch_mask_w(pomgpu_ctx *c) { LAUNCH(c, k_mask_w, gridm(c->P), blk2(), c->P); }
@@ -905,10 +839,4 @@ void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo
 void launch_realvertvl(pomgpu_ctx *c) {
   if (getenv("POMGPU_REALVERTVL_CELLS")) LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P);
   else LAUNCHN(c, "k_realvertvl_col", k_realvertvl_col, grid2(c->P), blk2(), c->P);
-}
-void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v) {
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  LAUNCH(c, k_fill, dim3(blocks), dim3(256), p, n, v);
 }

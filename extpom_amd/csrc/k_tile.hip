@@ -1,20 +1,14 @@
-// k_tile.hip -- wavefront-row stencil kernels.
+// k_tile.hip -- column-marching stencil kernels and the derived 2-D coefficient arrays.
 //
 // Profile of the first-cut cell kernels on MI355X (2048x1536x50): a cell of advt2 issued 56 global
 // loads (each i+-1 / j+-1 neighbour a separate 512-byte wavefront request) and evaluated every face
 // flux twice; the kernels ran at ~1.4-1.9 TB/s of algorithmic traffic, bound by the L1/TA request
-// rate and fp64 divides, not by HBM.  Here a wavefront owns 64 consecutive i and MARCHES over a strip
-// of rows at one level:
-//   * i+-1 operands and the east face flux come from the neighbour lane (lane_w / lane_e), so a word
-//     is requested once per wavefront, in aligned 512-byte rows;
-//   * the strip keeps a two-row window in registers: the north face of row j is the south face of
-//     row j+1, so every y-face flux (and its divide) is evaluated once;
-//   * per-face metric sums/products come from the derived 2-D coefficient arrays (enum pomgpu_coef2).
-// blockIdx.z = (row band, level) as for the cell kernels, so that a band's 2-D coefficients stay in
-// L2 / Infinity Cache across the levels.
+// rate and fp64 divides, not by HBM.  A row-marching version (a wavefront walks a strip of rows at one
+// level) moved the bottleneck to L2-miss traffic: the 14 two-dimensional coefficient operands of a
+// cell were re-fetched for every level (31 GB per launch against 7.5 GB algorithmic).  The kernels
+// here let a thread own the water column (i,j) instead; see the comment above k_advt2_col.
 #include "pomgpu_internal.hpp"
 
-#define ROWS_PER_STRIP 16
 
 // ---- derived 2-D coefficients -------------------------------------------------------------------
 __global__ void k_coef_static(KP P) {
@@ -57,90 +51,6 @@ __device__ __forceinline__ double upw_(double m, double lo, double hi) {     // 
   return 0.5 * ((m + fabs(m)) * lo + (m - fabs(m)) * hi);
 }
 struct FaceT { double adv, dif; };
-// west face of cell (i,j): operands of cell i ("c") and of cell i-1 ("w")
-__device__ __forceinline__ FaceT advt2_xface(const KP &P, int i, int j, double uc, double fbc, double fbw, double fcc,
-                                             double fcw, double amc, double amw) {
-  FaceT f;
-  f.adv = upw_(K2(CMX, i, j) * uc, fbw, fbc);                                  // :605-606, :631-635
-  const double am = 0.5 * (amc + amw);                                         // :696
-  f.dif = -am * K2(HSX, i, j) * P.tprni * ((fbc - fcc) - (fbw - fcw)) * F2(dum, i, j) * K2(DYSX, i, j) * 0.5 /
-          K2(DXSX, i, j);                                                      // :705-707
-  return f;
-}
-// south face of cell (i,j): operands of row j ("c") and of row j-1 ("s")
-__device__ __forceinline__ FaceT advt2_yface(const KP &P, int i, int j, double vc, double fbc, double fbs, double fcc,
-                                             double fcs, double amc, double ams) {
-  FaceT f;
-  f.adv = upw_(K2(CMY, i, j) * vc, fbs, fbc);                                  // :612-613, :637-641
-  const double am = 0.5 * (amc + ams);                                         // :697
-  f.dif = -am * K2(HSY, i, j) * P.tprni * ((fbc - fcc) - (fbs - fcs)) * F2(dvm, i, j) * K2(DXSY, i, j) * 0.5 /
-          K2(DYSY, i, j);                                                      // :708-710
-  return f;
-}
-__global__ void __launch_bounds__(256) k_advt2_rows(KP P, const double *fb, const double *f, const double *fcl, double *ff) {
-  const int band = (int)blockIdx.z / P.kb;
-  const int k = (int)blockIdx.z - band * P.kb + 1;
-  const int strips_per_band = (int)(gridDim.y * blockDim.y);
-  const int j0 = (band * strips_per_band + (int)(blockIdx.y * blockDim.y + threadIdx.y)) * ROWS_PER_STRIP + 1;
-  if (j0 > P.jml) return;                                  // whole wavefront leaves together
-  int j1 = j0 + ROWS_PER_STRIP - 1;
-  if (j1 > P.jml) j1 = P.jml;
-  const int i = TID_I;
-  const bool icol = (i <= P.iml);
-  const int ic = icol ? i : P.iml;                         // lanes past the array edge shadow the last column
-  if (k > P.kbm1) {                                        // level kb: only smol_adif's mask
-    if (icol)
-      for (int j = j0; j <= j1; j++) G3(ff, ic, j, k) = G3(ff, ic, j, k) * F2(fsm, ic, j);
-    return;
-  }
-  const bool iin = (i >= 2 && i <= P.imm1);
-  const int iw = ic > 1 ? ic - 1 : 1, ie = ic < P.iml ? ic + 1 : P.iml;
-  const double dzk = F1(dz, k);
-  const bool top = (k == 1), bot = (k == P.kbm1);
-  // two-row window of the operands that the y faces need
-  int js = j0 > 1 ? j0 - 1 : 1;
-  double fb_s = G3(fb, ic, js, k), fc_s = G3(fcl, ic, js, k), am_s = F3(aam, ic, js, k);
-  double fb_c = G3(fb, ic, j0, k), fc_c = G3(fcl, ic, j0, k), am_c = F3(aam, ic, j0, k);
-  FaceT ys = advt2_yface(P, ic, j0, F3(v, ic, j0, k), fb_c, fb_s, fc_c, fc_s, am_c, am_s);
-  for (int j = j0; j <= j1; j++) {
-    const int jn = j < P.jml ? j + 1 : P.jml;
-    const double fb_n = G3(fb, ic, jn, k), fc_n = G3(fcl, ic, jn, k), am_n = F3(aam, ic, jn, k);
-    const FaceT yn = advt2_yface(P, ic, jn, F3(v, ic, jn, k), fb_n, fb_c, fc_n, fc_c, am_n, am_c);
-    // west face from the neighbour lane's operands; east face = the eastern lane's west face
-    const double fb_w = lane_w(fb_c, [&] { return G3(fb, iw, j, k); });
-    const double fc_w = lane_w(fc_c, [&] { return G3(fcl, iw, j, k); });
-    const double am_w = lane_w(am_c, [&] { return F3(aam, iw, j, k); });
-    const FaceT xw = advt2_xface(P, ic, j, F3(u, ic, j, k), fb_c, fb_w, fc_c, fc_w, am_c, am_w);
-    FaceT xe;
-    xe.adv = lane_e(xw.adv, [&] {
-      return advt2_xface(P, ie, j, F3(u, ie, j, k), G3(fb, ie, j, k), fb_c, G3(fcl, ie, j, k), fc_c, F3(aam, ie, j, k), am_c).adv;
-    });
-    xe.dif = lane_e(xw.dif, [&] {
-      return advt2_xface(P, ie, j, F3(u, ie, j, k), G3(fb, ie, j, k), fb_c, G3(fcl, ie, j, k), fc_c, F3(aam, ie, j, k), am_c).dif;
-    });
-    if (icol) {
-      double r;
-      if (iin && j >= 2 && j <= P.jmm1) {
-        const double art = F2(art, ic, j);
-        const double zu = top ? F3(w, ic, j, 1) * G3(f, ic, j, 1) * art
-                              : upw_(F3(w, ic, j, k), fb_c, G3(fb, ic, j, k - 1)) * art;       // :646-662
-        const double zl = bot ? 0. : upw_(F3(w, ic, j, k + 1), G3(fb, ic, j, k + 1), fb_c) * art;
-        const double hfa = K2(HFA, ic, j);
-        r = xe.adv - xw.adv + yn.adv - ys.adv + (zu - zl) / dzk;                              // :670-672
-        r = (fb_c * K2(HEA, ic, j) - P.dti2 * r) / hfa;                                       // :673-674
-        r = r * F2(fsm, ic, j);                                                               // :1899
-        r = r - P.dti2 * (xe.dif - xw.dif + yn.dif - ys.dif) / hfa;                           // :721-723
-      } else {
-        r = G3(ff, ic, j, k) * F2(fsm, ic, j);                                                // :1899 (rim cells)
-      }
-      G3(ff, ic, j, k) = r;
-    }
-    fb_s = fb_c; fc_s = fc_c; am_s = am_c;
-    fb_c = fb_n; fc_c = fc_n; am_c = am_n;
-    ys = yn;
-  }
-}
-
 // ---- advt2, nitera == 1, COLUMN-MARCHING version -----------------------------------------------------
 // PMC profile of the row-marching kernel above (2048x1536x50): 31 GB of L2-miss traffic per launch
 // against 7.5 GB algorithmic -- the 14 two-dimensional coefficient operands of a cell are re-fetched
@@ -190,7 +100,7 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   return f;
 }
 template <int NF>
-__global__ void __launch_bounds__(256) k_advt2_col(KP P, TFields A) {
+__global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
@@ -299,7 +209,7 @@ __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double 
   return .5 * c.ds_num * x;
 }
 template <int NF>
-__global__ void __launch_bounds__(256) k_advq_col(KP P, QFields A, int zero_else) {
+__global__ void __launch_bounds__(64 * COL_ROWS) k_advq_col(KP P, QFields A, int zero_else) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;
@@ -405,7 +315,7 @@ __device__ double advct_xg_mem(const KP &P, int i, int j, int k) {              
   return .25 * dy4 * xg;
 }
 // sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
-__global__ void __launch_bounds__(256) k_advct_col(KP P, int sum2d) {
+__global__ void __launch_bounds__(64 * COL_ROWS) k_advct_col(KP P, int sum2d) {
   HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
   if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
@@ -531,7 +441,7 @@ __device__ __forceinline__ LevUV advuv_load(const KP &P, int i, int js, int j, i
   L.advx = F3(advx, i, j, k);  L.advy = F3(advy, i, j, k);  L.drhox = F3(drhox, i, j, k); L.drhoy = F3(drhoy, i, j, k);
   return L;
 }
-__global__ void __launch_bounds__(256) k_advuv_col(KP P) {
+__global__ void __launch_bounds__(64 * COL_ROWS) k_advuv_col(KP P) {
   HALO_XCD_DECODE
   if (j > P.jm) return;                                     // whole wavefront (one row)
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.im);
@@ -594,37 +504,26 @@ __global__ void __launch_bounds__(256) k_advuv_col(KP P) {
 void launch_coef_static(pomgpu_ctx *c) { LAUNCH(c, k_coef_static, grid2(c->P), blk2(), c->P); }
 void launch_coef_dt(pomgpu_ctx *c) { LAUNCH(c, k_coef_dt, grid2(c->P), blk2(), c->P); }
 void launch_coef_eta(pomgpu_ctx *c) { LAUNCH(c, k_coef_eta, grid2(c->P), blk2(), c->P); }
-// strips of ROWS_PER_STRIP rows; bands as gridm() but counted in strips
-static dim3 grid_rows(const KP &P) {
-  long rows = (4L << 20) / ((long)P.iml * 8);
-  if (rows > P.jml) rows = P.jml;
-  long strips = (rows + ROWS_PER_STRIP - 1) / ROWS_PER_STRIP;
-  strips = ((strips + 3) / 4) * 4;                          // 4 wavefronts per workgroup
-  const long band_rows = strips * ROWS_PER_STRIP;
-  const int nbands = (int)((P.jml + band_rows - 1) / band_rows);
-  return dim3((P.iml + 63) / 64, (unsigned)(strips / 4), (unsigned)(nbands * P.kb));
-}
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
   QFields A; A.q[0] = A.q[1] = q; A.qb[0] = A.qb[1] = qb; A.qf[0] = A.qf[1] = qf;
-  LAUNCHN(c, "k_advq_col", (k_advq_col<1>), grid1_halo(c->P), blk2(), c->P, A, zero_else);
+  LAUNCHN(c, "k_advq_col", (k_advq_col<1>), grid1_halo(c->P), blk_col(), c->P, A, zero_else);
 }
 void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *ql, const double *qlb, double *qlf, int zero_else) {
   QFields A; A.q[0] = q; A.qb[0] = qb; A.qf[0] = qf; A.q[1] = ql; A.qb[1] = qlb; A.qf[1] = qlf;
-  LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo(c->P), blk2(), c->P, A, zero_else);
+  LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo(c->P), blk_col(), c->P, A, zero_else);
 }
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
-  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk2(), c->P, sum2d);
+  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk_col(), c->P, sum2d);
 }
-void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk2(), c->P); }
+void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk_col(), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
-  if (getenv("POMGPU_ADVT2_ROWS")) LAUNCH(c, k_advt2_rows, grid_rows(c->P), dim3(64, 4, 1), c->P, fb, f, fc, ff);
-  else {
+  {
     TFields A; A.fb[0] = A.fb[1] = fb; A.f[0] = A.f[1] = f; A.fcl[0] = A.fcl[1] = fc; A.ff[0] = A.ff[1] = ff;
-    LAUNCHN(c, "k_advt2_col", (k_advt2_col<1>), grid1_halo(c->P), blk2(), c->P, A);
+    LAUNCHN(c, "k_advt2_col", (k_advt2_col<1>), grid1_halo(c->P), blk_col(), c->P, A);
   }
 }
 void launch_advt2x2_col(pomgpu_ctx *c, const double *tb, const double *t, const double *tc, double *tf, const double *sb, const double *s_,
                         const double *sc, double *sf) {
   TFields A; A.fb[0] = tb; A.f[0] = t; A.fcl[0] = tc; A.ff[0] = tf; A.fb[1] = sb; A.f[1] = s_; A.fcl[1] = sc; A.ff[1] = sf;
-  LAUNCHN(c, "k_advt2x2_col", (k_advt2_col<2>), grid1_halo(c->P), blk2(), c->P, A);
+  LAUNCHN(c, "k_advt2x2_col", (k_advt2_col<2>), grid1_halo(c->P), blk_col(), c->P, A);
 }

@@ -680,7 +680,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
         seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
       } else if (k.nadv == 2) {
-        if (P.nitera == 1 && !getenv("POMGPU_ADVT2_SINGLE") && !getenv("POMGPU_ADVT2_ROWS")) {   // T and S in one pass
+        if (P.nitera == 1 && !getenv("POMGPU_ADVT2_SINGLE")) {   // T and S in one pass
           launch_coef_eta(c);
           launch_advt2x2_col(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
           xch(c, 1, D3(c, uf), P.kbm1);                         // solver.f:728 (T)

@@ -143,19 +143,23 @@ template <class F> __device__ __forceinline__ double halo_e(double x, F) { retur
 // it row by row, so the ~3 block-rows an XCD has resident at any time are neighbours and the halo rows
 // are L2 hits.  The mapping is only a performance hint: any dispatch order gives the same results.
 // HALO_XCD_DECODE defines i0 (1-based column, halo-lane numbering) and j (1-based row), or returns.
+#ifndef COL_ROWS
+#define COL_ROWS 4                                          /* rows (wavefronts) per workgroup of the column kernels */
+#endif
 #define HALO_XCD_DECODE                                                                   \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
-  const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + 3) / 4;           \
+  const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS; \
   const int rpx__ = (nby__ + 7) / 8;                                                      \
   const int by__ = (L__ & 7) * rpx__ + (L__ >> 3) / nbx__;                                \
   if ((L__ >> 3) / nbx__ >= rpx__ || by__ >= nby__) return;                               \
   const int lane = g__ & 63;                                                              \
   const int i0 = ((L__ >> 3) % nbx__) * 62 + lane;                                        \
-  const int j = by__ * 4 + (int)threadIdx.y + 1;
+  const int j = by__ * COL_ROWS + (int)threadIdx.y + 1;
 static inline dim3 grid1_halo(const KP &P) {
-  const int nbx = (P.iml + 61) / 62, nby = (P.jml + 3) / 4, rpx = (nby + 7) / 8;
+  const int nbx = (P.iml + 61) / 62, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;
   return dim3((unsigned)(8 * rpx * nbx), 1, 1);
 }
+static inline dim3 blk_col() { return dim3(64, COL_ROWS, 1); }
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
 
@@ -284,8 +288,6 @@ void launch_mask3(pomgpu_ctx *c, double *a, const double *m2);
 void launch_smol(pomgpu_ctx *c, const double *ff);
 void launch_copy3(pomgpu_ctx *c, double *dst, const double *src);
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff);
-void launch_advt2_fused(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff);
-void launch_ts_filter(pomgpu_ctx *c, int mask);
 void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst);
 void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew);
 void launch_mask_ts(pomgpu_ctx *c);
@@ -296,7 +298,6 @@ void launch_restore_shift(pomgpu_ctx *c);
 void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau);
 void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo);
 void launch_realvertvl(pomgpu_ctx *c);
-void launch_fill(pomgpu_ctx *c, double *p, size_t n, double v);
 // k_vert.hip
 void launch_baropg(pomgpu_ctx *c, int sum2d);
 void launch_baropg_mcc(pomgpu_ctx *c, int sum2d);

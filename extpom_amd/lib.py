@@ -81,7 +81,7 @@ _cache = {}
 
 
 def load(path: str | None = None):
-    path = path or LIBPATH
+    path = path or os.environ.get("POMGPU_LIBPATH") or LIBPATH     # POMGPU_LIBPATH: developer builds (kernel variants)
     if path in _cache:
         return _cache[path]
     if not os.path.exists(path):
