@@ -37,6 +37,13 @@ static int fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
     if (_e != hipSuccess) return fail((c), POMGPU_EHIP, "%s: %s", #call, hipGetErrorString(_e)); \
   } while (0)
 
+void pomgpu_launch_check(pomgpu_ctx *c, const char *name) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess || c->launch_err) return;
+  c->launch_err = (int)e;
+  (void)fail(c, POMGPU_EHIP, "launch of %s refused: %s", name, hipGetErrorString(e));
+}
+
 // ---- profiling ---------------------------------------------------------------------------------
 int pomgpu_prof_slot(pomgpu_ctx *c, const char *name) {
   ProfState *ps = PS(c);
@@ -255,6 +262,7 @@ extern "C" const char *pomgpu_last_error(const pomgpu_ctx *c) { return c ? c->er
 extern "C" void *pomgpu_stream(pomgpu_ctx *c) { return c ? (void *)c->stream : NULL; }
 
 static int pull_err(pomgpu_ctx *c) {
+  if (c->launch_err) return POMGPU_EHIP;                      // message already in last_error
   int e = 0;
   HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -264,7 +272,7 @@ static int pull_err(pomgpu_ctx *c) {
 extern "C" int pomgpu_sync(pomgpu_ctx *c) {
   if (!c) return POMGPU_EINVAL;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return POMGPU_OK;
+  return c->launch_err ? POMGPU_EHIP : POMGPU_OK;
 }
 
 // ---- state transfer ----------------------------------------------------------------------------

@@ -197,6 +197,7 @@ struct pomgpu_ctx {
   ProfEntry prof[96];
   int nprof;
   void *prof_state;
+  int launch_err;            // first hipError_t a kernel launch returned (0 = none); reported by the next sync / get_con
   char err[512];
 };
 
@@ -204,12 +205,14 @@ struct pomgpu_ctx {
 int pomgpu_prof_slot(pomgpu_ctx *c, const char *name);
 void pomgpu_prof_pre(pomgpu_ctx *c);
 void pomgpu_prof_post(pomgpu_ctx *c, int slot);
+void pomgpu_launch_check(pomgpu_ctx *c, const char *name);   // a refused launch sets error_status, fills last_error, prints
 
 #define LAUNCH(c, kern, grid, block, ...)                                        \
   do {                                                                           \
     int _s = (c)->prof_on ? pomgpu_prof_slot((c), #kern) : -1;                   \
     if (_s >= 0) pomgpu_prof_pre(c);                                             \
     hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    pomgpu_launch_check((c), #kern);                                             \
     if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
   } while (0)
 
@@ -219,6 +222,7 @@ void pomgpu_prof_post(pomgpu_ctx *c, int slot);
     int _s = (c)->prof_on ? pomgpu_prof_slot((c), name) : -1;                    \
     if (_s >= 0) pomgpu_prof_pre(c);                                             \
     hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    pomgpu_launch_check((c), name);                                              \
     if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
   } while (0)
 
