@@ -221,6 +221,15 @@ def make_case(name: str, im: int, jm: int, kb: int, tile=None, **nml) -> PomStat
         (st.tclim[A3].copy(), st.sclim[A3].copy()),
         ((st.tclim[A3] + 0.01) * st.fsm[A][None], (st.sclim[A3] + 0.002) * st.fsm[A][None]),
     ]
+    # records behind surface_forcing (bounds_forcing.f:871-983: wind and heat every 0.125 d, time-interpolated;
+    # surface = SST without interpolation): the constant fields above modulated per record, so that the
+    # interpolation weights, the record shift and the masks all show up in the result
+    ramp = lambda r, a: a * (1.0 + 0.25 * math.sin(0.9 * r)) * st.fsm[A]
+    st.forcing_records = {
+        "wind": [(ramp(r, st.wusurf[A]) - 1.0e-6 * r * st.fsm[A], ramp(r + 3, st.wvsurf[A])) for r in range(1, 5)],
+        "heat": [(ramp(r, st.wtsurf[A]) + 1.0e-7 * r * st.fsm[A], 1.0e-5 * (1.0 + 0.1 * r) * st.fsm[A]) for r in range(1, 5)],
+        "surface": [((st.t[0][A] + 0.05 * r) * st.fsm[A], st.s[0][A] * st.fsm[A]) for r in range(1, 5)],
+    }
     return st
 
 
@@ -298,6 +307,9 @@ def cut_tile(g: PomState, tile) -> PomState:
     st.con[...] = g.con
     st.n_west, st.n_east, st.n_south, st.n_north = tile.n_west, tile.n_east, tile.n_south, tile.n_north
     st.i_off, st.j_off = i0, j0
+    if hasattr(g, "forcing_records"):
+        st.forcing_records = {k: [(np.ascontiguousarray(a[j0:j0 + jm, i0:i0 + im]), np.ascontiguousarray(b[j0:j0 + jm, i0:i0 + im]))
+                                  for a, b in v] for k, v in g.forcing_records.items()}
     if hasattr(g, "restore_records"):
         st.restore_records = [(np.ascontiguousarray(a[:, j0:j0 + jm, i0:i0 + im]),
                                np.ascontiguousarray(b[:, j0:j0 + jm, i0:i0 + im])) for a, b in g.restore_records]

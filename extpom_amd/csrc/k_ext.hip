@@ -615,7 +615,31 @@ __global__ void k_int_tail(KP P) {
   F2(vfluxb, i, j) = F2(vfluxf, i, j);
 }
 
+// ---------------------------------------------------------------------------------------------
+// surface forcing (bounds_forcing.f:871-983): x(1:im,1:jm) = record, and the linear interpolation in time
+__global__ void k_frc_load(KP P, const double *ra, const double *rb, double *xf, double *yf) {   // records are (im,jm)
+  const int i = TID_I, j = TID_J;
+  if (i > P.im || j > P.jm) return;
+  const size_t r = (size_t)(j - 1) * P.im + (size_t)(i - 1);
+  G2(xf, i, j) = ra[r];
+  if (yf) G2(yf, i, j) = rb[r];
+}
+__global__ void k_frc_interp(KP P, double fold, double fnew, double *x, const double *xb, const double *xf, double *y, const double *yb,
+                             const double *yf) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.im || j > P.jm) return;
+  G2(x, i, j) = fold * G2(xb, i, j) + fnew * G2(xf, i, j);                                  // :909-910 / :952-955
+  G2(y, i, j) = fold * G2(yb, i, j) + fnew * G2(yf, i, j);
+}
+
 // ---- launchers --------------------------------------------------------------------------------
+void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf) {
+  LAUNCH(c, k_frc_load, grid2(c->P), blk2(), c->P, ra, rb, xf, yf);
+}
+void launch_frc_interp(pomgpu_ctx *c, double fold, double fnew, double *x, const double *xb, const double *xf, double *y, const double *yb,
+                       const double *yf) {
+  LAUNCH(c, k_frc_interp, grid2(c->P), blk2(), c->P, fold, fnew, x, xb, xf, y, yb, yf);
+}
 void launch_advave_a(pomgpu_ctx *c) { LAUNCH(c, k_advave_a, grid2(c->P), blk2(), c->P); }
 void launch_advave_b(pomgpu_ctx *c) { LAUNCH(c, k_advave_b, grid2(c->P), blk2(), c->P); }
 void launch_advave_c(pomgpu_ctx *c) { LAUNCH(c, k_advave_c, grid2(c->P), blk2(), c->P); }

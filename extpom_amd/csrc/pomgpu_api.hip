@@ -248,6 +248,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
+  for (int k = 0; k < 3; k++) for (int sl = 0; sl < 4; sl++) { (void)hipFree(c->frc_dev[k][sl][0]); (void)hipFree(c->frc_dev[k][sl][1]); }
   ProfState *ps = PS(c);
   if (ps) {
     for (auto &p : ps->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -747,6 +748,66 @@ extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, in
     c->con.error_status = 1;
   }
   return POMGPU_OK;
+}
+// ---- surface forcing -- advance.f:77-93, bounds_forcing.f:871-983 ---------------------------------
+extern "C" int pomgpu_set_forcing_record(pomgpu_ctx *c, int kind, int n, const double *a, const double *b) {
+  NEED(c);
+  if (kind < 0 || kind > 2 || n < 1 || !a || !b) return fail(c, POMGPU_EINVAL, "set_forcing_record: kind 0..2, n >= 1, two (im,jm) fields");
+  const int sl = n % 4;
+  const size_t bytes = sizeof(double) * (size_t)c->P.im * c->P.jm;
+  for (int f = 0; f < 2; f++) {
+    if (!c->frc_dev[kind][sl][f]) HIPCHK(c, hipMalloc((void **)&c->frc_dev[kind][sl][f], bytes));
+    HIPCHK(c, hipMemcpyAsync(c->frc_dev[kind][sl][f], f ? b : a, bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));                 // the caller may reuse its buffers
+  c->frc_n[kind][sl] = n;
+  return POMGPU_OK;
+}
+static int frc_read(pomgpu_ctx *c, int kind, int n, double *xf, double *yf) {   // what read_*_pnetcdf(n, ...) delivers
+  const int sl = ((n % 4) + 4) % 4;
+  if (n < 1 || c->frc_n[kind][sl] != n)
+    return fail(c, POMGPU_EINVAL, "%s: record %d was not supplied (pomgpu_set_forcing_record)", kind == 0 ? "wind" : kind == 1 ? "heat" : "surface", n);
+  launch_frc_load(c, c->frc_dev[kind][sl][0], c->frc_dev[kind][sl][1], xf, yf);
+  return POMGPU_OK;
+}
+// wind and heat: two fields, a record every `tint` days, linear in time
+static int frc_interp(pomgpu_ctx *c, int kind, double tint, int x, int xb, int xf, int y, int yb, int yf) {
+  const pom_blkcon &k = c->con;
+  const int istep = (int)(tint * 86400. / k.dti);
+  if (istep < 1) return fail(c, POMGPU_EINVAL, "surface forcing: dti is longer than the record interval");
+  int rc;
+  if (k.iint == 1 && (rc = frc_read(c, kind, (k.iint + k.cont_bry) / istep + 1, SLOT2(c, xf), SLOT2(c, yf)))) return rc;   // :884-888
+  if (k.iint == 1 || (k.iint + k.cont_bry) % istep == 0) {                                                                   // :890-902
+    launch_copy2(c, SLOT2(c, xb), SLOT2(c, xf));
+    launch_copy2(c, SLOT2(c, yb), SLOT2(c, yf));
+    if (k.iint != k.iend && (rc = frc_read(c, kind, (k.iint + k.cont_bry + istep) / istep + 1, SLOT2(c, xf), SLOT2(c, yf)))) return rc;
+  }
+  const int ntime = (int)(k.time / tint);                                                                                    // :905-907
+  const double fnew = k.time / tint - ntime, fold = 1. - fnew;
+  launch_frc_interp(c, fold, fnew, SLOT2(c, x), SLOT2(c, xb), SLOT2(c, xf), SLOT2(c, y), SLOT2(c, yb), SLOT2(c, yf));
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_wind(pomgpu_ctx *c) {                   // bounds_forcing.f:871-912, twind = .125
+  NEED(c);
+  return frc_interp(c, 0, .125, P2_wusurf, P2_wusurfb, P2_wusurff, P2_wvsurf, P2_wvsurfb, P2_wvsurff);
+}
+extern "C" int pomgpu_heat(pomgpu_ctx *c) {                   // bounds_forcing.f:915-960, theat = .125
+  NEED(c);
+  return frc_interp(c, 1, .125, P2_wtsurf, P2_wtsurfb, P2_wtsurff, P2_swrad, P2_swradb, P2_swradf);
+}
+extern "C" int pomgpu_surface(pomgpu_ctx *c) {                // bounds_forcing.f:963-983: SST, no interpolation
+  NEED(c);
+  const pom_blkcon &k = c->con;
+  const int isrf = (int)(.125 * 86400. / k.dti);
+  if (isrf < 1) return fail(c, POMGPU_EINVAL, "surface forcing: dti is longer than the record interval");
+  if (k.iint == 1 || (k.iint + k.cont_bry) % isrf == 0) return frc_read(c, 2, (k.iint + k.cont_bry) / isrf + 1, SLOT2(c, P2_tsurf), NULL);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_surface_forcing(pomgpu_ctx *c) {        // advance.f:77-93
+  int rc;
+  if ((rc = pomgpu_wind(c))) return rc;
+  if ((rc = pomgpu_heat(c))) return rc;
+  return pomgpu_surface(c);
 }
 extern "C" int pomgpu_domain_stats(pomgpu_ctx *c, double *out, int sums_only) {   // advance.f:644-756
   NEED(c);

@@ -192,6 +192,8 @@ struct pomgpu_ctx {
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
   int *d_err;                // device error flag
   double *d_stats;           // device: the seven sums of domain_stats
+  double *frc_dev[3][4][2];  // forcing records on the device: [kind][slot = n % 4][field], (im,jm) each
+  int frc_n[3][4];           // which record number a slot holds (0 = empty)
   // profiling
   bool prof_on;
   ProfEntry prof[96];
@@ -271,6 +273,9 @@ void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f);
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
+void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf);
+void launch_frc_interp(pomgpu_ctx *c, double fold, double fnew, double *x, const double *xb, const double *xf, double *y, const double *yb,
+                       const double *yf);
 void launch_int_tail(pomgpu_ctx *c);
 void launch_bcond1(pomgpu_ctx *c);
 // k_adv.hip

@@ -39,6 +39,9 @@ module pomgpu_iface
     integer(c_int) function pomgpu_check_velocity(ctx, vamax, imax, jmax) bind(C, name='pomgpu_check_velocity')
       import; type(c_ptr), value :: ctx; real(c_double) :: vamax; integer(c_int) :: imax, jmax
     end function
+    integer(c_int) function pomgpu_set_forcing_record(ctx, kind, n, a, b) bind(C, name='pomgpu_set_forcing_record')
+      import; type(c_ptr), value :: ctx, a, b; integer(c_int), value :: kind, n
+    end function
     integer(c_int) function pomgpu_domain_stats(ctx, out, sums_only) bind(C, name='pomgpu_domain_stats')
       import; type(c_ptr), value :: ctx; real(c_double) :: out(8); integer(c_int), value :: sums_only
     end function
@@ -80,6 +83,9 @@ module pomgpu_iface
   procedure(pomgpu_noarg), bind(C, name='pomgpu_advv') :: pomgpu_advv
   procedure(pomgpu_noarg), bind(C, name='pomgpu_baropg') :: pomgpu_baropg
   procedure(pomgpu_noarg), bind(C, name='pomgpu_baropg_mcc') :: pomgpu_baropg_mcc
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_wind') :: pomgpu_wind
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_heat') :: pomgpu_heat
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_surface') :: pomgpu_surface
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profq') :: pomgpu_profq
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profu') :: pomgpu_profu
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profv') :: pomgpu_profv

@@ -61,6 +61,16 @@ class PomGpu:
             sr = np.ascontiguousarray(sr, dtype=np.float64)
             self._chk(self.L.pomgpu_set_restore_record(self.h, n, self._p(tr), self._p(sr)), "set_restore_record")
 
+    def set_forcing_records(self, first: int = 1, count: int = 4):
+        """hand records first..first+count-1 of st.forcing_records (wind / heat / surface) to the library: what the
+        host's read_wind_pnetcdf etc. would deliver; the library keeps the last four per kind"""
+        for kind, name in enumerate(("wind", "heat", "surface")):
+            recs = getattr(self.st, "forcing_records", {}).get(name, [])
+            for n in range(first, min(first + count, len(recs) + 1)):
+                a = np.ascontiguousarray(recs[n - 1][0], dtype=np.float64)
+                b = np.ascontiguousarray(recs[n - 1][1], dtype=np.float64)
+                self._chk(self.L.pomgpu_set_forcing_record(self.h, kind, n, self._p(a), self._p(b)), "set_forcing_record")
+
     def download(self, st: PomState | None = None) -> PomState:
         st = st or self.st
         self._chk(self.L.pomgpu_download(self.h, self._p(st.blk1d), self._p(st.blk2d), self._p(st.blk3d), self._p(st.bdry),

@@ -99,6 +99,19 @@ typedef void (*pomgpu_order_fn)(void *user, const double *send_east, int n_east,
                                 double *recv_west, double *recv_south);
 int pomgpu_set_order_exchange(pomgpu_ctx *ctx, pomgpu_order_fn fn, void *user);
 
+/* ---- surface forcing on the device (bounds_forcing.f:871-983, called from advance.f:77-93) ---------------
+ * wind and heat keep two records (…b, …f members of blk2d) and interpolate linearly in time; surface sets the
+ * SST without interpolation.  The readers stay the host's (read_wind_pnetcdf, read_heat_pnetcdf,
+ * read_surface_pnetcdf: io_pnetcdf.F:2912,3110,3170): the host hands the library the pair of (im,jm) fields
+ * of record n -- kind 0 = wind (wu, wv), 1 = heat (shf, swr), 2 = surface (sst, sss) -- before the step whose
+ * wind / heat / surface call asks for it; the last four records per kind are kept.  pomgpu_get_time must have
+ * set the step's time.  A record that was not supplied: error_status = 1, POMGPU_EINVAL. */
+int pomgpu_set_forcing_record(pomgpu_ctx *ctx, int kind, int n, const double *a, const double *b);
+int pomgpu_wind(pomgpu_ctx *ctx);              /* bounds_forcing.f:871-912 */
+int pomgpu_heat(pomgpu_ctx *ctx);              /* bounds_forcing.f:915-960 */
+int pomgpu_surface(pomgpu_ctx *ctx);           /* bounds_forcing.f:963-983 */
+int pomgpu_surface_forcing(pomgpu_ctx *ctx);   /* advance.f:77-93: wind, heat, surface */
+
 /* Pack / unpack helpers for the hook (one kernel launch per direction instead of one copy per
  * array and edge).  dir 0 = east/west phase, 1 = north/south phase.  pack: the edge the western
  * (southern) neighbour needs -- column 2 (row 2) of every array -- goes to `to_lo`, column im-1

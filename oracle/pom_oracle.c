@@ -1487,6 +1487,54 @@ void pomo_mode_internal(pomo_tile *T) {
 }
 
 /* check_velocity -- advance.f:611-641 */
+/* ===================================================================================== */
+/* surface_forcing -- advance.f:77-93 -> wind, heat, surface (bounds_forcing.f:871-983).  The readers
+ * (read_wind_pnetcdf ...) are the caller's: records registered with pomo_set_forcing_record. */
+void pomo_set_forcing_record(pomo_tile *T, int kind, int n, const double *a, const double *b) {
+  if (kind < 0 || kind > 2 || n < 1 || n > POMO_MAXFREC) { fprintf(stderr, "pomo: bad forcing record %d/%d\n", kind, n); abort(); }
+  T->frc_a[kind][n] = a; T->frc_b[kind][n] = b;
+}
+static void frc_read(pomo_tile *T, int kind, int n, double *fa, double *fb) {   /* x(1:im,1:jm) = record */
+  int i, j;
+  if (n < 1 || n > POMO_MAXFREC || !T->frc_a[kind][n]) { fprintf(stderr, "pomo: forcing record %d/%d was not supplied\n", kind, n); abort(); }
+  for (j = 1; j <= jm; j++) for (i = 1; i <= im; i++) {
+    G2_(fa,i,j) = L2_(T->frc_a[kind][n],i,j);
+    if (fb) G2_(fb,i,j) = L2_(T->frc_b[kind][n],i,j);
+  }
+}
+/* the shared shape of wind and heat: two fields, records every `tint` days, linear in time */
+static void frc_interp(pomo_tile *T, int kind, double tint, double *x, double *xb, double *xf, double *y, double *yb, double *yf) {
+  const double time = CON_(time);
+  const int cont_bry = CON_(cont_bry);
+  const int istep = (int)(tint*86400./dti);
+  int i, j, ntime;
+  double fold, fnew;
+  if (iint == 1) frc_read(T, kind, (iint+cont_bry)/istep+1, xf, yf);                     /* :884-888 */
+  if (iint == 1 || (iint+cont_bry) % istep == 0) {                                        /* :890-902 */
+    for (j = 1; j <= jm; j++) for (i = 1; i <= im; i++) { G2_(xb,i,j) = G2_(xf,i,j); G2_(yb,i,j) = G2_(yf,i,j); }
+    if (iint != iend) frc_read(T, kind, (iint+cont_bry+istep)/istep+1, xf, yf);
+  }
+  ntime = (int)(time/tint);                                                               /* :905-909 */
+  fnew = time/tint-ntime;
+  fold = 1.-fnew;
+  for (j = 1; j <= jm; j++) for (i = 1; i <= im; i++) {
+    G2_(x,i,j) = fold*G2_(xb,i,j)+fnew*G2_(xf,i,j);
+    G2_(y,i,j) = fold*G2_(yb,i,j)+fnew*G2_(yf,i,j);
+  }
+}
+void pomo_wind(pomo_tile *T) {   /* twind = .125 */
+  frc_interp(T, 0, .125, A2_(wusurf), A2_(wusurfb), A2_(wusurff), A2_(wvsurf), A2_(wvsurfb), A2_(wvsurff));
+}
+void pomo_heat(pomo_tile *T) {   /* theat = .125 */
+  frc_interp(T, 1, .125, A2_(wtsurf), A2_(wtsurfb), A2_(wtsurff), A2_(swrad), A2_(swradb), A2_(swradf));
+}
+void pomo_surface(pomo_tile *T) {   /* tsrf = .125; SST only, no interpolation (:975-980) */
+  const int cont_bry = CON_(cont_bry);
+  const int isrf = (int)(.125*86400./dti);
+  if (iint == 1 || (iint+cont_bry) % isrf == 0) frc_read(T, 2, (iint+cont_bry)/isrf+1, A2_(tsurf), NULL);
+}
+void pomo_surface_forcing(pomo_tile *T) { pomo_wind(T); pomo_heat(T); pomo_surface(T); }
+
 /* domain_stats -- advance.f:644-756.  dvol is assigned on 2:imm1 x 2:jmm1 only (:692-695) and is zero
  * elsewhere, so every 3-D sum -- including the "physical edge" additions of vtot, tavg, stot, ekin, which
  * read the zero edge of dvol / dmass -- is a sum over the interior; atot and eavg do include the edges

@@ -18,6 +18,7 @@
 #define POMO_MAXREC 8
 #define POMO_NSCR 16
 
+#define POMO_MAXFREC 16
 typedef struct pomo_tile {
   int im_, jm_, kb_;         /* active extents im, jm, kb (blksiz) */
   int iml, jml;              /* leading dimensions im_local, jm_local */
@@ -41,6 +42,9 @@ typedef struct pomo_tile {
    * (nx,ny[,nz]) array and take the west / south neighbour's into ghost_w (ny*nz values, j fastest) and
    * ghost_s (nx*nz values, i fastest); either ghost stays untouched on a physical edge.  NULL = one tile. */
   void (*order)(void *user, const double *a, int nx, int ny, int nz, double *ghost_w, double *ghost_s);
+  /* records served to wind / heat / surface (what read_wind_pnetcdf etc. would return): kind 0 wind (wu,wv),
+   * 1 heat (shf,swr), 2 surface (sst,sss); records 1..POMO_MAXFREC, (im,jm) each */
+  const double *frc_a[3][POMO_MAXFREC + 1], *frc_b[3][POMO_MAXFREC + 1];
 } pomo_tile;
 
 /* bind storage; returns 0 or -1 on allocation failure */
@@ -61,6 +65,11 @@ void pomo_baropg(pomo_tile *t);
 void pomo_baropg_mcc(pomo_tile *t);   /* solver.f:943-1159 (npg = 2) */
 typedef void (*pomo_order_fn)(void *user, const double *a, int nx, int ny, int nz, double *ghost_w, double *ghost_s);
 void pomo_set_order(pomo_tile *t, pomo_order_fn fn);
+void pomo_set_forcing_record(pomo_tile *t, int kind, int n, const double *a, const double *b);
+void pomo_wind(pomo_tile *t);               /* bounds_forcing.f:871-912 */
+void pomo_heat(pomo_tile *t);               /* bounds_forcing.f:915-960 */
+void pomo_surface(pomo_tile *t);            /* bounds_forcing.f:963-983 */
+void pomo_surface_forcing(pomo_tile *t);    /* advance.f:77-93 */
 void pomo_dens(pomo_tile *t, double *si, double *ti, double *rhoo);
 void pomo_profq(pomo_tile *t);
 void pomo_proft(pomo_tile *t, double *f, double *wfsurf, double *fsurf, int nbc);

@@ -77,6 +77,15 @@ class OracleTile:
             self._recs.append((tr, sr))
             self._poke(self._off_rec_t + n * ptr, tr.ctypes.data)
             self._poke(self._off_rec_s + n * ptr, sr.ctypes.data)
+        self._frecs = []
+        L.pomo_set_forcing_record.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.pomo_set_forcing_record.restype = None
+        for kind, name in enumerate(("wind", "heat", "surface")):
+            for n, (a, b) in enumerate(getattr(st, "forcing_records", {}).get(name, []), start=1):
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                b = np.ascontiguousarray(b, dtype=np.float64)
+                self._frecs.append((a, b))
+                L.pomo_set_forcing_record(self.t, kind, n, a.ctypes.data, b.ctypes.data)
         self._cb = []
         if exch2d is not None:
             cb = _EXCH2(lambda user, a, nx, ny: exch2d(np.ctypeslib.as_array(a, shape=(ny, nx))))

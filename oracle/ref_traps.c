@@ -17,6 +17,12 @@
  * INPUT hook -- it hands the reference the same synthetic relaxation targets
  * the oracle and the HIP path are given -- and performs no arithmetic.  Asking
  * for a record that was not registered aborts.
+ *
+ * The same goes for the three readers behind surface_forcing (wind, heat, surface:
+ * bounds_forcing.f:871-983): read_wind_pnetcdf(n,wu,wv), read_heat_pnetcdf(n,shf,swr),
+ * read_surface_pnetcdf(n,sst,sss) hand over the pair of (im,jm) fields the harness
+ * registered for record n with pomref_set_forcing_record(kind, n, a, b, count) --
+ * the time interpolation that follows is the reference's own.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,9 +37,6 @@
 TRAP(read_grid_pnetcdf_)
 TRAP(read_initial_ts_pnetcdf_)
 TRAP(read_clim_ts_pnetcdf_)
-TRAP(read_wind_pnetcdf_)
-TRAP(read_heat_pnetcdf_)
-TRAP(read_surface_pnetcdf_)
 TRAP(read_water_pnetcdf_)
 TRAP(read_boundary_conditions_pnetcdf_)
 TRAP(read_restart_pnetcdf_)
@@ -62,3 +65,24 @@ void read_restore_ts_interior_pnetcdf_(int *n, int *k, double *tr, double *sr) {
   memcpy(tr, rec_t[*n], rec_n[*n] * sizeof(double));
   memcpy(sr, rec_s[*n], rec_n[*n] * sizeof(double));
 }
+
+
+/* ---- surface forcing records: kind 0 = wind (wu, wv), 1 = heat (shf, swr), 2 = surface (sst, sss) ---- */
+#define POMREF_MAXFREC 16
+static const double *frc_a[3][POMREF_MAXFREC + 1], *frc_b[3][POMREF_MAXFREC + 1];
+static size_t frc_n[3][POMREF_MAXFREC + 1];
+void pomref_set_forcing_record(int kind, int n, const double *a, const double *b, size_t count) {
+  if (kind < 0 || kind > 2 || n < 1 || n > POMREF_MAXFREC) { fprintf(stderr, "pomref: bad forcing record %d/%d\n", kind, n); abort(); }
+  frc_a[kind][n] = a; frc_b[kind][n] = b; frc_n[kind][n] = count;
+}
+static void serve(int kind, const char *what, int n, double *a, double *b) {
+  if (n < 1 || n > POMREF_MAXFREC || !frc_a[kind][n]) {
+    fprintf(stderr, "oracle/_ref: %s record %d was not registered by the harness\n", what, n);
+    abort();
+  }
+  memcpy(a, frc_a[kind][n], frc_n[kind][n] * sizeof(double));
+  memcpy(b, frc_b[kind][n], frc_n[kind][n] * sizeof(double));
+}
+void read_wind_pnetcdf_(int *n, double *wu, double *wv) { serve(0, "wind", *n, wu, wv); }          /* io_pnetcdf.F:2912 */
+void read_heat_pnetcdf_(int *n, double *shf, double *swr) { serve(1, "heat", *n, shf, swr); }      /* io_pnetcdf.F:3110 */
+void read_surface_pnetcdf_(int *n, double *sst, double *sss) { serve(2, "surface", *n, sst, sss); } /* io_pnetcdf.F:3170 */

@@ -84,6 +84,16 @@ class RefLib:
             self.lib.pomref_set_restore_record(ctypes.c_int(n), ctypes.c_void_p(tr.ctypes.data),
                                                ctypes.c_void_p(sr.ctypes.data), ctypes.c_size_t(tr.size))
 
+        # surface-forcing records (wind / heat / surface), see ref_traps.c: input hooks as well
+        self._frecs = []
+        for kind, name in enumerate(("wind", "heat", "surface")):
+            for n, (a, b) in enumerate(getattr(st, "forcing_records", {}).get(name, []), start=1):
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                b = np.ascontiguousarray(b, dtype=np.float64)
+                self._frecs.append((a, b))
+                self.lib.pomref_set_forcing_record(ctypes.c_int(kind), ctypes.c_int(n), ctypes.c_void_p(a.ctypes.data),
+                                                   ctypes.c_void_p(b.ctypes.data), ctypes.c_size_t(a.size))
+
     def get(self, st):
         st.blk1d[...] = self.c1.reshape(st.blk1d.shape)
         st.blk2d[...] = self.c2.reshape(st.blk2d.shape)

@@ -147,6 +147,29 @@ def test_check_velocity_wavefront_reduction():
         a.error_status = 0
 
 
+def test_surface_forcing_on_device_across_record_changes():
+    """wind / heat / surface (bounds_forcing.f:871-983) with the records in HBM: per step get_time,
+    surface_forcing, advance as advance.f:11-33; dti = 360 s puts the record changes at steps 30 and 60"""
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=60, days=1.0)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = _gpu(b)
+    g.set_forcing_records()
+    for n in range(1, 63):
+        a.iint = n
+        for r in ("get_time", "surface_forcing", "advance"):
+            ot.call(r)
+        g.set_con(iint=n)
+        for r in ("get_time", "surface_forcing", "advance"):
+            g.call(r)
+        if n in (1, 2, 30, 31, 60, 61, 62):
+            g.download()
+            assert not diff(a, b), f"step {n}: {diff(a, b)}"
+    g.close()
+
+
 def test_domain_stats_on_device():
     """print_section's sums (advance.f:644-756) reduced on the device: equal to the oracle to rounding,
     and the same bits every time (fixed reduction tree, no atomics)"""

@@ -68,6 +68,27 @@ def test_even_leading_dimension_steps(case, im, jm):
         assert not diff(a, b), f"step {n}: {diff(a, b)}"
 
 
+def test_surface_forcing_across_a_record_change():
+    """wind / heat / surface on the device side (bounds_forcing.f:871-983): per step get_time, surface_forcing,
+    advance as advance.f:11-33; dti = 360 s puts the record changes at steps 30 and 60"""
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=60, days=1.0)
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    g.set_forcing_records()
+    for n in range(1, 33):
+        a.iint = n
+        for r in ("get_time", "surface_forcing", "advance"):
+            ot.call(r)
+        g.set_con(iint=n)
+        for r in ("get_time", "surface_forcing", "advance"):
+            g.call(r)
+        if n in (1, 2, 29, 30, 31, 32):
+            g.download()
+            assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
 def test_kb_above_the_register_kernels_bound():
     """kb = 70 > 64: the column kernels with private work vectors take over from the unrolled ones"""
     a = make_case("basin", 64, 48, 70, dte=6.0, isplit=30)

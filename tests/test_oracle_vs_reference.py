@@ -97,3 +97,27 @@ def test_domain_stats_matches_reference_to_rounding():
     out = (ctypes.c_double * 8)()
     OracleTile(a).call("domain_stats", out, ctypes.c_int(0))
     np.testing.assert_allclose(np.array(list(out)), np.array([v.value for v in vals]), rtol=1e-13, atol=0)
+
+
+def test_surface_forcing_bit_identical_across_a_record_change():
+    """wind, heat, surface (bounds_forcing.f:871-983) fed with the same records through the readers' entry
+    points; 62 steps: the records shift at step 60 (0.125 d / 180 s)"""
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30, days=0.4)
+    ref_finish_initial(a)
+    b = a.copy()
+    lib = RefLib(65, 49, 21)
+    lib.put(a)
+    ot = OracleTile(b)
+    for n in range(1, 63):
+        lib.con["iint"][0] = n
+        lib.call("get_time")
+        lib.call("surface_forcing")
+        lib.advance()
+        b.iint = n
+        ot.call("get_time")
+        ot.call("surface_forcing")
+        ot.call("advance")
+        if n in (1, 2, 59, 60, 61, 62):
+            lib.get(a)
+            assert not _diff(a, b), f"step {n}: {_diff(a, b)}"
+    assert float(np.abs(a.tsurf).max()) > 0 and not np.array_equal(a.wusurfb, a.wusurff)
