@@ -314,3 +314,29 @@ def cut_tile(g: PomState, tile) -> PomState:
         st.restore_records = [(np.ascontiguousarray(a[:, j0:j0 + jm, i0:i0 + im]),
                                np.ascontiguousarray(b[:, j0:j0 + jm, i0:i0 + im])) for a, b in g.restore_records]
     return st
+
+
+LATERAL_ORDER = ("tbw", "sbw", "ubw", "vbw", "tbe", "sbe", "ube", "vbe", "tbn", "sbn", "vbn", "ubn", "tbs", "sbs", "vbs", "ubs",
+                 "elw", "ele", "eln", "els")
+
+
+def make_lateral_records(st: PomState, count: int = 4) -> PomState:
+    """Synthetic records for lateral_bc (bounds_forcing.f:593-868): what read_boundary_conditions_pnetcdf would
+    deliver for records 1..count -- the 20 arrays of LATERAL_ORDER in the shape of the bdry members they land in --
+    derived from the boundary values of the finished initial state, modulated per record.  Call after
+    finish_initial()."""
+    recs = []
+    for r in range(1, count + 1):
+        rec = []
+        for n in LATERAL_ORDER:
+            a = st.field(n)
+            if n.startswith("el"):
+                x = a + 1.0e-3 * math.sin(0.7 * r) * (a.shape[0] > 0)
+            elif n[0] in "ts":
+                x = a * (1.0 + 0.002 * r)
+            else:
+                x = a * (1.0 + 0.2 * math.sin(1.3 * r)) + 1.0e-4 * r * (a != 0)
+            rec.append(np.ascontiguousarray(x, dtype=np.float64))
+        recs.append(rec)
+    st.lateral_records = recs
+    return st

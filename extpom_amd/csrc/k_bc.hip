@@ -171,7 +171,114 @@ __global__ void k_bcondorl3(KP P) {
   F3(vf, i, j, k) = vf * F2(dvm, i, j);
 }
 
+// ---------------------------------------------------------------------------------------------
+// lateral_bc -- bounds_forcing.f:593-868.  One thread per edge point: t < jm_local serves the west and
+// east arrays at j = t+1, the others the north and south arrays at i.  phase 0: a record (20 arrays
+// concatenated, in the order of read_boundary_conditions_pnetcdf's arguments) lands in the "...f" members
+// and el?, followed by the depth integrals uab?f, vab?f (:610-636, :755-771); phase 1: the "b" copies that
+// the reference refreshes (:742-753 -- tb?b, sb?b, uabwb, uabeb, vabnb, vabsb only); phase 2: interpolation
+// in time and the integrals uabe, uabw, vabn, vabs (:776-797).
+__global__ void k_lateral(KP P, int phase, const double *rec, double fold, double fnew) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int kb = P.kb, jml = P.jml, iml = P.iml;
+  if (t >= jml + iml) return;
+  const bool west_east = (t < jml);
+  const int a = west_east ? t + 1 : t - jml + 1;                      // j or i, 1-based
+  const size_t njk = (size_t)jml * kb, nik = (size_t)iml * kb;
+  if (phase == 0) {
+    if (west_east) {
+      const double *r = rec;                                         // tbwf sbwf ubwf vbwf tbef sbef ubef vbef: 8 x (jml,kb)
+      double uw = 0., vw = 0., ue = 0., ve = 0.;
+      for (int k = 1; k <= kb; k++) {
+        const size_t o = (size_t)(k - 1) * jml + (a - 1);
+        const double dzk = F1(dz, k);
+        BDJ(tbwf, a, k) = r[o]; BDJ(sbwf, a, k) = r[njk + o];
+        const double x = r[2 * njk + o], y = r[3 * njk + o];
+        BDJ(ubwf, a, k) = x; BDJ(vbwf, a, k) = y;
+        uw = uw + x * dzk; vw = vw + y * dzk;
+        BDJ(tbef, a, k) = r[4 * njk + o]; BDJ(sbef, a, k) = r[5 * njk + o];
+        const double p = r[6 * njk + o], q = r[7 * njk + o];
+        BDJ(ubef, a, k) = p; BDJ(vbef, a, k) = q;
+        ue = ue + p * dzk; ve = ve + q * dzk;
+      }
+      BD1(uabwf, a) = uw; BD1(vabwf, a) = vw; BD1(uabef, a) = ue; BD1(vabef, a) = ve;
+      const double *e = rec + 8 * njk + 8 * nik;                     // elw ele (jml each), then eln els
+      BD1(elw, a) = e[a - 1]; BD1(ele, a) = e[jml + a - 1];
+    } else {
+      const double *r = rec + 8 * njk;                               // tbnf sbnf vbnf ubnf tbsf sbsf vbsf ubsf: 8 x (iml,kb)
+      double un = 0., vn = 0., us = 0., vs = 0.;
+      for (int k = 1; k <= kb; k++) {
+        const size_t o = (size_t)(k - 1) * iml + (a - 1);
+        const double dzk = F1(dz, k);
+        BDI(tbnf, a, k) = r[o]; BDI(sbnf, a, k) = r[nik + o];
+        const double y = r[2 * nik + o], x = r[3 * nik + o];
+        BDI(vbnf, a, k) = y; BDI(ubnf, a, k) = x;
+        un = un + x * dzk; vn = vn + y * dzk;
+        BDI(tbsf, a, k) = r[4 * nik + o]; BDI(sbsf, a, k) = r[5 * nik + o];
+        const double q = r[6 * nik + o], p = r[7 * nik + o];
+        BDI(vbsf, a, k) = q; BDI(ubsf, a, k) = p;
+        us = us + p * dzk; vs = vs + q * dzk;
+      }
+      BD1(uabnf, a) = un; BD1(vabnf, a) = vn; BD1(uabsf, a) = us; BD1(vabsf, a) = vs;
+      const double *e = rec + 8 * njk + 8 * nik + 2 * (size_t)jml;
+      BD1(eln, a) = e[a - 1]; BD1(els, a) = e[iml + a - 1];
+    }
+  } else if (phase == 1) {
+    if (west_east) {
+      for (int k = 1; k <= kb; k++) {
+        BDJ(tbwb, a, k) = BDJ(tbwf, a, k); BDJ(sbwb, a, k) = BDJ(sbwf, a, k);
+        BDJ(tbeb, a, k) = BDJ(tbef, a, k); BDJ(sbeb, a, k) = BDJ(sbef, a, k);
+      }
+      BD1(uabwb, a) = BD1(uabwf, a); BD1(uabeb, a) = BD1(uabef, a);
+    } else {
+      for (int k = 1; k <= kb; k++) {
+        BDI(tbnb, a, k) = BDI(tbnf, a, k); BDI(sbnb, a, k) = BDI(sbnf, a, k);
+        BDI(tbsb, a, k) = BDI(tbsf, a, k); BDI(sbsb, a, k) = BDI(sbsf, a, k);
+      }
+      BD1(vabnb, a) = BD1(vabnf, a); BD1(vabsb, a) = BD1(vabsf, a);
+    }
+  } else {
+    if (west_east) {
+      double ue = 0., uw = 0.;
+      if (a <= P.jm)
+        for (int k = 1; k <= kb; k++) {
+          const double dzk = F1(dz, k);
+          BDJ(tbw, a, k) = fold * BDJ(tbwb, a, k) + fnew * BDJ(tbwf, a, k);
+          BDJ(sbw, a, k) = fold * BDJ(sbwb, a, k) + fnew * BDJ(sbwf, a, k);
+          const double x = fold * BDJ(ubwb, a, k) + fnew * BDJ(ubwf, a, k);
+          BDJ(ubw, a, k) = x;
+          BDJ(tbe, a, k) = fold * BDJ(tbeb, a, k) + fnew * BDJ(tbef, a, k);
+          BDJ(sbe, a, k) = fold * BDJ(sbeb, a, k) + fnew * BDJ(sbef, a, k);
+          const double p = fold * BDJ(ubeb, a, k) + fnew * BDJ(ubef, a, k);
+          BDJ(ube, a, k) = p;
+          ue = ue + p * dzk; uw = uw + x * dzk;
+        }
+      BD1(uabe, a) = ue; BD1(uabw, a) = uw;                          // zero beyond jm (:788-789)
+    } else {
+      double vn = 0., vs = 0.;
+      if (a <= P.im)
+        for (int k = 1; k <= kb; k++) {
+          const double dzk = F1(dz, k);
+          BDI(tbn, a, k) = fold * BDI(tbnb, a, k) + fnew * BDI(tbnf, a, k);
+          BDI(sbn, a, k) = fold * BDI(sbnb, a, k) + fnew * BDI(sbnf, a, k);
+          const double y = fold * BDI(vbnb, a, k) + fnew * BDI(vbnf, a, k);
+          BDI(vbn, a, k) = y;
+          BDI(tbs, a, k) = fold * BDI(tbsb, a, k) + fnew * BDI(tbsf, a, k);
+          BDI(sbs, a, k) = fold * BDI(sbsb, a, k) + fnew * BDI(sbsf, a, k);
+          const double q = fold * BDI(vbsb, a, k) + fnew * BDI(vbsf, a, k);
+          BDI(vbs, a, k) = q;
+          vn = vn + y * dzk; vs = vs + q * dzk;
+        }
+      BD1(vabn, a) = vn; BD1(vabs, a) = vs;
+    }
+  }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
+void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew) {
+  const int n = c->P.jml + c->P.iml;
+  LAUNCH(c, k_lateral, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), c->P, phase, rec, fold, fnew);
+}
 void launch_bcond4_edges(pomgpu_ctx *c) {
   const KP &P = c->P;
   if (!(P.W || P.E || P.S || P.N)) return;

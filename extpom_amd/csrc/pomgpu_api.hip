@@ -249,6 +249,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
   for (int k = 0; k < 3; k++) for (int sl = 0; sl < 4; sl++) { (void)hipFree(c->frc_dev[k][sl][0]); (void)hipFree(c->frc_dev[k][sl][1]); }
+  for (int sl = 0; sl < 4; sl++) (void)hipFree(c->lat_dev[sl]);
   ProfState *ps = PS(c);
   if (ps) {
     for (auto &p : ps->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -808,6 +809,49 @@ extern "C" int pomgpu_surface_forcing(pomgpu_ctx *c) {        // advance.f:77-93
   if ((rc = pomgpu_wind(c))) return rc;
   if ((rc = pomgpu_heat(c))) return rc;
   return pomgpu_surface(c);
+}
+// ---- lateral_bc -- bounds_forcing.f:593-868 --------------------------------------------------------
+extern "C" int pomgpu_set_lateral_record(pomgpu_ctx *c, int n, const double *const *a) {
+  NEED(c);
+  if (n < 1 || !a) return fail(c, POMGPU_EINVAL, "set_lateral_record: n >= 1 and 20 arrays");
+  const KP &P = c->P;
+  const size_t njk = (size_t)P.jml * P.kb, nik = (size_t)P.iml * P.kb;
+  const size_t total = 8 * njk + 8 * nik + 2 * (size_t)P.jml + 2 * (size_t)P.iml;
+  const int sl = n % 4;
+  if (!c->lat_dev[sl]) HIPCHK(c, hipMalloc((void **)&c->lat_dev[sl], total * sizeof(double)));
+  size_t off = 0;
+  for (int q = 0; q < 20; q++) {
+    const size_t len = q < 8 ? njk : (q < 16 ? nik : (q < 18 ? (size_t)P.jml : (size_t)P.iml));
+    if (!a[q]) return fail(c, POMGPU_EINVAL, "set_lateral_record: array %d is NULL", q);
+    HIPCHK(c, hipMemcpyAsync(c->lat_dev[sl] + off, a[q], len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    off += len;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->lat_n[sl] = n;
+  return POMGPU_OK;
+}
+static int lat_read(pomgpu_ctx *c, int n) {
+  const int sl = ((n % 4) + 4) % 4;
+  if (n < 1 || c->lat_n[sl] != n) return fail(c, POMGPU_EINVAL, "lateral_bc: record %d was not supplied (pomgpu_set_lateral_record)", n);
+  launch_lat(c, 0, c->lat_dev[sl], 0., 0.);
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_lateral_bc(pomgpu_ctx *c) {
+  NEED(c);
+  const pom_blkcon &k = c->con;
+  const double tbc = (double)(1.f / 24.f);                    // "tbc=1./24.": a REAL(4) constant (:602)
+  const int ibc = (int)(tbc * 86400. / k.dti);
+  if (ibc < 1) return fail(c, POMGPU_EINVAL, "lateral_bc: dti is longer than the record interval");
+  const int ntime = (int)(k.time / tbc);
+  int rc;
+  if (k.iint == 1 && (rc = lat_read(c, (k.iint + k.cont_bry) / ibc + 1))) return rc;           // :607-636
+  if (k.iint == 1 || (k.iint + k.cont_bry) % ibc == 0) {                                       // :740-772
+    launch_lat(c, 1, NULL, 0., 0.);
+    if (k.iint != k.iend && (rc = lat_read(c, (k.iint + k.cont_bry + ibc) / ibc + 1))) return rc;
+  }
+  const double fnew = k.time / tbc - (double)ntime, fold = 1. - fnew;                          // :774-775
+  launch_lat(c, 2, NULL, fold, fnew);
+  return POMGPU_OK;
 }
 extern "C" int pomgpu_domain_stats(pomgpu_ctx *c, double *out, int sums_only) {   // advance.f:644-756
   NEED(c);

@@ -194,6 +194,8 @@ struct pomgpu_ctx {
   double *d_stats;           // device: the seven sums of domain_stats
   double *frc_dev[3][4][2];  // forcing records on the device: [kind][slot = n % 4][field], (im,jm) each
   int frc_n[3][4];           // which record number a slot holds (0 = empty)
+  double *lat_dev[4];        // lateral_bc records: the 20 arrays of one record, concatenated (slot = n % 4)
+  int lat_n[4];
   // profiling
   bool prof_on;
   ProfEntry prof[96];
@@ -273,6 +275,7 @@ void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f);
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
+void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate
 void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf);
 void launch_frc_interp(pomgpu_ctx *c, double fold, double fnew, double *x, const double *xb, const double *xf, double *y, const double *yb,
                        const double *yf);

@@ -42,6 +42,9 @@ module pomgpu_iface
     integer(c_int) function pomgpu_set_forcing_record(ctx, kind, n, a, b) bind(C, name='pomgpu_set_forcing_record')
       import; type(c_ptr), value :: ctx, a, b; integer(c_int), value :: kind, n
     end function
+    integer(c_int) function pomgpu_set_lateral_record(ctx, n, arrays) bind(C, name='pomgpu_set_lateral_record')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: n; type(c_ptr) :: arrays(20)
+    end function
     integer(c_int) function pomgpu_domain_stats(ctx, out, sums_only) bind(C, name='pomgpu_domain_stats')
       import; type(c_ptr), value :: ctx; real(c_double) :: out(8); integer(c_int), value :: sums_only
     end function
@@ -86,6 +89,7 @@ module pomgpu_iface
   procedure(pomgpu_noarg), bind(C, name='pomgpu_wind') :: pomgpu_wind
   procedure(pomgpu_noarg), bind(C, name='pomgpu_heat') :: pomgpu_heat
   procedure(pomgpu_noarg), bind(C, name='pomgpu_surface') :: pomgpu_surface
+  procedure(pomgpu_noarg), bind(C, name='pomgpu_lateral_bc') :: pomgpu_lateral_bc
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profq') :: pomgpu_profq
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profu') :: pomgpu_profu
   procedure(pomgpu_noarg), bind(C, name='pomgpu_profv') :: pomgpu_profv

@@ -130,6 +130,8 @@ class PomState:
             setattr(o, a, getattr(self, a))
         if "restore_records" in self.__dict__:
             o.restore_records = self.restore_records
+        if "lateral_records" in self.__dict__:
+            o.lateral_records = self.lateral_records
         if "forcing_records" in self.__dict__:
             o.forcing_records = self.forcing_records
         if "lramp" in self.__dict__:

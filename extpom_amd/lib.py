@@ -46,6 +46,7 @@ _SIGS = {
     "pomgpu_bind_host": (_I, [_P, _P, _P]),
     "pomgpu_set_restore_record": (_I, [_P, _I, _P, _P]),
     "pomgpu_set_forcing_record": (_I, [_P, _I, _I, _P, _P]),
+    "pomgpu_set_lateral_record": (_I, [_P, _I, ctypes.POINTER(ctypes.c_void_p)]),
     "pomgpu_device_2d": (_P, [_P, _I]),
     "pomgpu_device_3d": (_P, [_P, _I]),
     "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
@@ -72,7 +73,7 @@ _SIGS = {
 }
 # argument-less hot-path entry points, same names as the reference subroutines
 NOARG = ["get_time", "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "advance", "advave",
-         "advct", "advu", "advv", "baropg", "baropg_mcc", "wind", "heat", "surface", "surface_forcing", "profq", "profu", "profv", "vertvl", "realvertvl", "restore_interior"]
+         "advct", "advu", "advv", "baropg", "baropg_mcc", "wind", "heat", "surface", "surface_forcing", "lateral_bc", "profq", "profu", "profv", "vertvl", "realvertvl", "restore_interior"]
 for _n in NOARG:
     _SIGS["pomgpu_" + _n] = (_I, [_P])
 

@@ -71,6 +71,14 @@ class PomGpu:
                 b = np.ascontiguousarray(recs[n - 1][1], dtype=np.float64)
                 self._chk(self.L.pomgpu_set_forcing_record(self.h, kind, n, self._p(a), self._p(b)), "set_forcing_record")
 
+    def set_lateral_records(self, first: int = 1, count: int = 4):
+        """hand records first..first+count-1 of st.lateral_records (20 arrays each, see pomgpu.h) to the library"""
+        recs = getattr(self.st, "lateral_records", [])
+        for n in range(first, min(first + count, len(recs) + 1)):
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in recs[n - 1]]
+            ptrs = (ctypes.c_void_p * 20)(*[a.ctypes.data for a in arrs])
+            self._chk(self.L.pomgpu_set_lateral_record(self.h, n, ptrs), "set_lateral_record")
+
     def download(self, st: PomState | None = None) -> PomState:
         st = st or self.st
         self._chk(self.L.pomgpu_download(self.h, self._p(st.blk1d), self._p(st.blk2d), self._p(st.blk3d), self._p(st.bdry),

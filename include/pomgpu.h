@@ -112,6 +112,14 @@ int pomgpu_heat(pomgpu_ctx *ctx);              /* bounds_forcing.f:915-960 */
 int pomgpu_surface(pomgpu_ctx *ctx);           /* bounds_forcing.f:963-983 */
 int pomgpu_surface_forcing(pomgpu_ctx *ctx);   /* advance.f:77-93: wind, heat, surface */
 
+/* lateral_bc on the device (bounds_forcing.f:593-868): records every 1/24 day, the same shift / load /
+ * interpolate pattern on the open-boundary arrays of `bdry`, plus the depth integrals uab?f, vab?f, uabe, uabw,
+ * vabn, vabs.  The host's reader (read_boundary_conditions_pnetcdf, io_pnetcdf.F:3393) fills 20 arrays: tbwf sbwf
+ * ubwf vbwf tbef sbef ubef vbef tbnf sbnf vbnf ubnf tbsf sbsf vbsf ubsf elw ele eln els -- hand them over in this
+ * order, each in the shape of the bdry member it lands in ((jm_local,kb), (im_local,kb), (jm_local), (im_local)). */
+int pomgpu_set_lateral_record(pomgpu_ctx *ctx, int n, const double *const *arrays20);
+int pomgpu_lateral_bc(pomgpu_ctx *ctx);
+
 /* Pack / unpack helpers for the hook (one kernel launch per direction instead of one copy per
  * array and edge).  dir 0 = east/west phase, 1 = north/south phase.  pack: the edge the western
  * (southern) neighbour needs -- column 2 (row 2) of every array -- goes to `to_lo`, column im-1

@@ -1535,6 +1535,82 @@ void pomo_surface(pomo_tile *T) {   /* tsrf = .125; SST only, no interpolation (
 }
 void pomo_surface_forcing(pomo_tile *T) { pomo_wind(T); pomo_heat(T); pomo_surface(T); }
 
+/* ===================================================================================== */
+/* lateral_bc -- bounds_forcing.f:593-868 (active lines; the z-to-sigma blocks are commented out in the
+ * reference).  Records every tbc = 1./24. days (a REAL(4) constant).  Kept as written: only tb*, sb*, uabw/e
+ * and vabn/s have their "b" copies refreshed at a record change (:742-753) -- ub?b, vb?b keep whatever
+ * they held, although the interpolation reads them (:773-784). */
+static const int LAT_SLOT[20] = {PB_tbwf, PB_sbwf, PB_ubwf, PB_vbwf, PB_tbef, PB_sbef, PB_ubef, PB_vbef, PB_tbnf, PB_sbnf,
+                                 PB_vbnf, PB_ubnf, PB_tbsf, PB_sbsf, PB_vbsf, PB_ubsf, PB_elw, PB_ele, PB_eln, PB_els};
+static size_t bd_len(pomo_tile *T, int slot) {          /* number of doubles of a bdry member */
+  static const char shape[] = {
+#define BDS_(name, shp) (#shp)[0] == 'J' ? ((#shp)[1] ? 'j' : 'J') : ((#shp)[1] ? 'i' : 'I'),
+    POM_BDRY(BDS_)
+#undef BDS_
+  };
+  switch (shape[slot]) { case 'J': return (size_t)jm_local; case 'I': return (size_t)im_local;
+                         case 'j': return (size_t)jm_local*kb; default: return (size_t)im_local*kb; }
+}
+void pomo_set_lateral_record(pomo_tile *T, int n, const double *const *arrays20) {
+  int a;
+  if (n < 1 || n > POMO_MAXFREC) { fprintf(stderr, "pomo: bad lateral record %d\n", n); abort(); }
+  for (a = 0; a < 20; a++) T->lat[n][a] = arrays20[a];
+}
+static void lat_read(pomo_tile *T, int n) {             /* read_boundary_conditions_pnetcdf + the depth integrals (:610-636) */
+  int a, i, j, k;
+  if (n < 1 || n > POMO_MAXFREC || !T->lat[n][0]) { fprintf(stderr, "pomo: lateral record %d was not supplied\n", n); abort(); }
+  for (a = 0; a < 20; a++) memcpy(T->bd[LAT_SLOT[a]], T->lat[n][a], sizeof(double)*bd_len(T, LAT_SLOT[a]));
+  for (j = 1; j <= jm_local; j++) { uabwf(j) = 0.; vabwf(j) = 0.; uabef(j) = 0.; vabef(j) = 0.; }
+  for (i = 1; i <= im_local; i++) { uabnf(i) = 0.; vabnf(i) = 0.; uabsf(i) = 0.; vabsf(i) = 0.; }
+  for (k = 1; k <= kb; k++) {
+    for (j = 1; j <= jm_local; j++) {
+      uabwf(j) = uabwf(j)+ubwf(j,k)*dz(k); vabwf(j) = vabwf(j)+vbwf(j,k)*dz(k);
+      uabef(j) = uabef(j)+ubef(j,k)*dz(k); vabef(j) = vabef(j)+vbef(j,k)*dz(k);
+    }
+    for (i = 1; i <= im_local; i++) {
+      uabnf(i) = uabnf(i)+ubnf(i,k)*dz(k); vabnf(i) = vabnf(i)+vbnf(i,k)*dz(k);
+      uabsf(i) = uabsf(i)+ubsf(i,k)*dz(k); vabsf(i) = vabsf(i)+vbsf(i,k)*dz(k);
+    }
+  }
+}
+void pomo_lateral_bc(pomo_tile *T) {
+  const double time = CON_(time);
+  const int cont_bry = CON_(cont_bry);
+  const double tbc = (double)(1.f/24.f);                                                  /* :602 */
+  const int ibc = (int)(tbc*86400./dti);
+  const int ntime = (int)(time/tbc);
+  int i, j, k;
+  double fold, fnew;
+  if (iint == 1) lat_read(T, (iint+cont_bry)/ibc+1);                                      /* :607-636 */
+  if (iint == 1 || (iint+cont_bry) % ibc == 0) {                                          /* :740-772 */
+    for (k = 1; k <= kb; k++) {
+      for (j = 1; j <= jm_local; j++) { tbwb(j,k) = tbwf(j,k); sbwb(j,k) = sbwf(j,k); tbeb(j,k) = tbef(j,k); sbeb(j,k) = sbef(j,k); }
+      for (i = 1; i <= im_local; i++) { tbnb(i,k) = tbnf(i,k); sbnb(i,k) = sbnf(i,k); tbsb(i,k) = tbsf(i,k); sbsb(i,k) = sbsf(i,k); }
+    }
+    for (j = 1; j <= jm_local; j++) { uabwb(j) = uabwf(j); uabeb(j) = uabef(j); }
+    for (i = 1; i <= im_local; i++) { vabnb(i) = vabnf(i); vabsb(i) = vabsf(i); }
+    if (iint != iend) lat_read(T, (iint+cont_bry+ibc)/ibc+1);
+  }
+  fnew = time/tbc-(double)ntime;                                                          /* :774-775 */
+  fold = 1.-fnew;
+  for (k = 1; k <= kb; k++) {                                                             /* :776-787 */
+    for (j = 1; j <= jm; j++) {
+      tbw(j,k) = fold*tbwb(j,k)+fnew*tbwf(j,k); sbw(j,k) = fold*sbwb(j,k)+fnew*sbwf(j,k); ubw(j,k) = fold*ubwb(j,k)+fnew*ubwf(j,k);
+      tbe(j,k) = fold*tbeb(j,k)+fnew*tbef(j,k); sbe(j,k) = fold*sbeb(j,k)+fnew*sbef(j,k); ube(j,k) = fold*ubeb(j,k)+fnew*ubef(j,k);
+    }
+    for (i = 1; i <= im; i++) {
+      tbn(i,k) = fold*tbnb(i,k)+fnew*tbnf(i,k); sbn(i,k) = fold*sbnb(i,k)+fnew*sbnf(i,k); vbn(i,k) = fold*vbnb(i,k)+fnew*vbnf(i,k);
+      tbs(i,k) = fold*tbsb(i,k)+fnew*tbsf(i,k); sbs(i,k) = fold*sbsb(i,k)+fnew*sbsf(i,k); vbs(i,k) = fold*vbsb(i,k)+fnew*vbsf(i,k);
+    }
+  }
+  for (j = 1; j <= jm_local; j++) { uabe(j) = 0.; uabw(j) = 0.; }                         /* :788-791 */
+  for (i = 1; i <= im_local; i++) { vabn(i) = 0.; vabs(i) = 0.; }
+  for (k = 1; k <= kb; k++) {                                                             /* :792-797 */
+    for (j = 1; j <= jm; j++) { uabe(j) = uabe(j)+ube(j,k)*dz(k); uabw(j) = uabw(j)+ubw(j,k)*dz(k); }
+    for (i = 1; i <= im; i++) { vabn(i) = vabn(i)+vbn(i,k)*dz(k); vabs(i) = vabs(i)+vbs(i,k)*dz(k); }
+  }
+}
+
 /* domain_stats -- advance.f:644-756.  dvol is assigned on 2:imm1 x 2:jmm1 only (:692-695) and is zero
  * elsewhere, so every 3-D sum -- including the "physical edge" additions of vtot, tavg, stot, ekin, which
  * read the zero edge of dvol / dmass -- is a sum over the interior; atot and eavg do include the edges

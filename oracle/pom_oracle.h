@@ -45,6 +45,10 @@ typedef struct pomo_tile {
   /* records served to wind / heat / surface (what read_wind_pnetcdf etc. would return): kind 0 wind (wu,wv),
    * 1 heat (shf,swr), 2 surface (sst,sss); records 1..POMO_MAXFREC, (im,jm) each */
   const double *frc_a[3][POMO_MAXFREC + 1], *frc_b[3][POMO_MAXFREC + 1];
+  /* records served to lateral_bc: the 20 arrays read_boundary_conditions_pnetcdf fills (bounds_forcing.f:610-613):
+   * tbwf sbwf ubwf vbwf tbef sbef ubef vbef tbnf sbnf vbnf ubnf tbsf sbsf vbsf ubsf elw ele eln els, each in the
+   * shape of the bdry member it lands in */
+  const double *lat[POMO_MAXFREC + 1][20];
 } pomo_tile;
 
 /* bind storage; returns 0 or -1 on allocation failure */
@@ -66,6 +70,8 @@ void pomo_baropg_mcc(pomo_tile *t);   /* solver.f:943-1159 (npg = 2) */
 typedef void (*pomo_order_fn)(void *user, const double *a, int nx, int ny, int nz, double *ghost_w, double *ghost_s);
 void pomo_set_order(pomo_tile *t, pomo_order_fn fn);
 void pomo_set_forcing_record(pomo_tile *t, int kind, int n, const double *a, const double *b);
+void pomo_set_lateral_record(pomo_tile *t, int n, const double *const *arrays20);
+void pomo_lateral_bc(pomo_tile *t);         /* bounds_forcing.f:593-868 */
 void pomo_wind(pomo_tile *t);               /* bounds_forcing.f:871-912 */
 void pomo_heat(pomo_tile *t);               /* bounds_forcing.f:915-960 */
 void pomo_surface(pomo_tile *t);            /* bounds_forcing.f:963-983 */

@@ -86,6 +86,14 @@ class OracleTile:
                 b = np.ascontiguousarray(b, dtype=np.float64)
                 self._frecs.append((a, b))
                 L.pomo_set_forcing_record(self.t, kind, n, a.ctypes.data, b.ctypes.data)
+        self._lrecs = []
+        L.pomo_set_lateral_record.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.pomo_set_lateral_record.restype = None
+        for n, rec in enumerate(getattr(st, "lateral_records", []), start=1):
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in rec]
+            ptrs = (ctypes.c_void_p * 20)(*[a.ctypes.data for a in arrs])
+            self._lrecs.append((arrs, ptrs))
+            L.pomo_set_lateral_record(self.t, n, ptrs)
         self._cb = []
         if exch2d is not None:
             cb = _EXCH2(lambda user, a, nx, ny: exch2d(np.ctypeslib.as_array(a, shape=(ny, nx))))

@@ -22,7 +22,9 @@
  * bounds_forcing.f:871-983): read_wind_pnetcdf(n,wu,wv), read_heat_pnetcdf(n,shf,swr),
  * read_surface_pnetcdf(n,sst,sss) hand over the pair of (im,jm) fields the harness
  * registered for record n with pomref_set_forcing_record(kind, n, a, b, count) --
- * the time interpolation that follows is the reference's own.
+ * the time interpolation that follows is the reference's own.  Likewise read_boundary_conditions_pnetcdf
+ * behind lateral_bc (bounds_forcing.f:610-613,755-758): the 20 boundary arrays of record n as registered with
+ * pomref_set_lateral_record(n, arrays, counts).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,7 +40,6 @@ TRAP(read_grid_pnetcdf_)
 TRAP(read_initial_ts_pnetcdf_)
 TRAP(read_clim_ts_pnetcdf_)
 TRAP(read_water_pnetcdf_)
-TRAP(read_boundary_conditions_pnetcdf_)
 TRAP(read_restart_pnetcdf_)
 TRAP(write_output_pnetcdf_)
 TRAP(write_restart_pnetcdf_)
@@ -86,3 +87,23 @@ static void serve(int kind, const char *what, int n, double *a, double *b) {
 void read_wind_pnetcdf_(int *n, double *wu, double *wv) { serve(0, "wind", *n, wu, wv); }          /* io_pnetcdf.F:2912 */
 void read_heat_pnetcdf_(int *n, double *shf, double *swr) { serve(1, "heat", *n, shf, swr); }      /* io_pnetcdf.F:3110 */
 void read_surface_pnetcdf_(int *n, double *sst, double *sss) { serve(2, "surface", *n, sst, sss); } /* io_pnetcdf.F:3170 */
+
+
+/* ---- lateral boundary records: the 20 arrays of read_boundary_conditions_pnetcdf (io_pnetcdf.F:3393) ---- */
+static const double *lat_a[POMREF_MAXFREC + 1][20];
+static size_t lat_n[POMREF_MAXFREC + 1][20];
+void pomref_set_lateral_record(int n, const double *const *arrays, const size_t *counts) {
+  if (n < 1 || n > POMREF_MAXFREC) { fprintf(stderr, "pomref: bad lateral record %d\n", n); abort(); }
+  for (int a = 0; a < 20; a++) { lat_a[n][a] = arrays[a]; lat_n[n][a] = counts[a]; }
+}
+void read_boundary_conditions_pnetcdf_(int *n, int *k, double *t_w, double *s_w, double *u_w, double *v_w, double *t_e, double *s_e,
+                                       double *u_e, double *v_e, double *t_n, double *s_n, double *v_n, double *u_n, double *t_s,
+                                       double *s_s, double *v_s, double *u_s, double *e_w, double *e_e, double *e_n, double *e_s) {
+  double *dst[20] = {t_w, s_w, u_w, v_w, t_e, s_e, u_e, v_e, t_n, s_n, v_n, u_n, t_s, s_s, v_s, u_s, e_w, e_e, e_n, e_s};
+  (void)k;
+  if (*n < 1 || *n > POMREF_MAXFREC || !lat_a[*n][0]) {
+    fprintf(stderr, "oracle/_ref: lateral boundary record %d was not registered by the harness\n", *n);
+    abort();
+  }
+  for (int a = 0; a < 20; a++) memcpy(dst[a], lat_a[*n][a], lat_n[*n][a] * sizeof(double));
+}

@@ -94,6 +94,15 @@ class RefLib:
                 self.lib.pomref_set_forcing_record(ctypes.c_int(kind), ctypes.c_int(n), ctypes.c_void_p(a.ctypes.data),
                                                    ctypes.c_void_p(b.ctypes.data), ctypes.c_size_t(a.size))
 
+        # lateral boundary records (20 arrays each), see ref_traps.c
+        self._lrecs = []
+        for n, rec in enumerate(getattr(st, "lateral_records", []), start=1):
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in rec]
+            ptrs = (ctypes.c_void_p * 20)(*[a.ctypes.data for a in arrs])
+            cnts = (ctypes.c_size_t * 20)(*[a.size for a in arrs])
+            self._lrecs.append((arrs, ptrs, cnts))
+            self.lib.pomref_set_lateral_record(ctypes.c_int(n), ptrs, cnts)
+
     def get(self, st):
         st.blk1d[...] = self.c1.reshape(st.blk1d.shape)
         st.blk2d[...] = self.c2.reshape(st.blk2d.shape)
