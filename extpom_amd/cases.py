@@ -221,15 +221,6 @@ def make_case(name: str, im: int, jm: int, kb: int, tile=None, **nml) -> PomStat
         (st.tclim[A3].copy(), st.sclim[A3].copy()),
         ((st.tclim[A3] + 0.01) * st.fsm[A][None], (st.sclim[A3] + 0.002) * st.fsm[A][None]),
     ]
-    # records behind surface_forcing (bounds_forcing.f:871-983: wind and heat every 0.125 d, time-interpolated;
-    # surface = SST without interpolation): the constant fields above modulated per record, so that the
-    # interpolation weights, the record shift and the masks all show up in the result
-    ramp = lambda r, a: a * (1.0 + 0.25 * math.sin(0.9 * r)) * st.fsm[A]
-    st.forcing_records = {
-        "wind": [(ramp(r, st.wusurf[A]) - 1.0e-6 * r * st.fsm[A], ramp(r + 3, st.wvsurf[A])) for r in range(1, 5)],
-        "heat": [(ramp(r, st.wtsurf[A]) + 1.0e-7 * r * st.fsm[A], 1.0e-5 * (1.0 + 0.1 * r) * st.fsm[A]) for r in range(1, 5)],
-        "surface": [((st.t[0][A] + 0.05 * r) * st.fsm[A], st.s[0][A] * st.fsm[A]) for r in range(1, 5)],
-    }
     return st
 
 
@@ -313,6 +304,22 @@ def cut_tile(g: PomState, tile) -> PomState:
     if hasattr(g, "restore_records"):
         st.restore_records = [(np.ascontiguousarray(a[:, j0:j0 + jm, i0:i0 + im]),
                                np.ascontiguousarray(b[:, j0:j0 + jm, i0:i0 + im])) for a, b in g.restore_records]
+    return st
+
+
+def make_forcing_records(st: PomState, count: int = 4) -> PomState:
+    """Synthetic records behind surface_forcing (bounds_forcing.f:871-983: wind and heat every 0.125 d,
+    time-interpolated; surface = SST without interpolation): the constant fields of make_case modulated per
+    record, so that the interpolation weights, the record shift and the masks all show up in the result.
+    Opt-in: a state WITHOUT these records keeps its constant forcing (advance skips surface_forcing)."""
+    A = (slice(0, st.jm), slice(0, st.im))
+    ramp = lambda r, a: a * (1.0 + 0.25 * math.sin(0.9 * r)) * st.fsm[A]
+    rr = range(1, count + 1)
+    st.forcing_records = {
+        "wind": [(ramp(r, st.wusurf[A]) - 1.0e-6 * r * st.fsm[A], ramp(r + 3, st.wvsurf[A])) for r in rr],
+        "heat": [(ramp(r, st.wtsurf[A]) + 1.0e-7 * r * st.fsm[A], 1.0e-5 * (1.0 + 0.1 * r) * st.fsm[A]) for r in rr],
+        "surface": [((st.t[0][A] + 0.05 * r) * st.fsm[A], st.s[0][A] * st.fsm[A]) for r in rr],
+    }
     return st
 
 

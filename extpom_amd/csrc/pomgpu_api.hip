@@ -762,6 +762,7 @@ extern "C" int pomgpu_set_forcing_record(pomgpu_ctx *c, int kind, int n, const d
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));                 // the caller may reuse its buffers
   c->frc_n[kind][sl] = n;
+  c->frc_on = 1;
   return POMGPU_OK;
 }
 static int frc_read(pomgpu_ctx *c, int kind, int n, double *xf, double *yf) {   // what read_*_pnetcdf(n, ...) delivers
@@ -789,15 +790,15 @@ static int frc_interp(pomgpu_ctx *c, int kind, double tint, int x, int xb, int x
   return POMGPU_OK;
 }
 extern "C" int pomgpu_wind(pomgpu_ctx *c) {                   // bounds_forcing.f:871-912, twind = .125
-  NEED(c);
+  NEED_HOT(c);
   return frc_interp(c, 0, .125, P2_wusurf, P2_wusurfb, P2_wusurff, P2_wvsurf, P2_wvsurfb, P2_wvsurff);
 }
 extern "C" int pomgpu_heat(pomgpu_ctx *c) {                   // bounds_forcing.f:915-960, theat = .125
-  NEED(c);
+  NEED_HOT(c);
   return frc_interp(c, 1, .125, P2_wtsurf, P2_wtsurfb, P2_wtsurff, P2_swrad, P2_swradb, P2_swradf);
 }
 extern "C" int pomgpu_surface(pomgpu_ctx *c) {                // bounds_forcing.f:963-983: SST, no interpolation
-  NEED(c);
+  NEED_HOT(c);
   const pom_blkcon &k = c->con;
   const int isrf = (int)(.125 * 86400. / k.dti);
   if (isrf < 1) return fail(c, POMGPU_EINVAL, "surface forcing: dti is longer than the record interval");
@@ -828,6 +829,7 @@ extern "C" int pomgpu_set_lateral_record(pomgpu_ctx *c, int n, const double *con
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->lat_n[sl] = n;
+  c->lat_on = 1;
   return POMGPU_OK;
 }
 static int lat_read(pomgpu_ctx *c, int n) {
@@ -837,7 +839,7 @@ static int lat_read(pomgpu_ctx *c, int n) {
   return POMGPU_OK;
 }
 extern "C" int pomgpu_lateral_bc(pomgpu_ctx *c) {
-  NEED(c);
+  NEED_HOT(c);
   const pom_blkcon &k = c->con;
   const double tbc = (double)(1.f / 24.f);                    // "tbc=1./24.": a REAL(4) constant (:602)
   const int ibc = (int)(tbc * 86400. / k.dti);
@@ -872,6 +874,9 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
+  // advance.f:14-18: file-driven in the reference; here they run once the host has supplied records
+  if (c->frc_on && (rc = pomgpu_surface_forcing(c))) return rc;
+  if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;
   const int sum2d = (!c->exch && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   if ((rc = lateral_viscosity(c, sum2d))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;

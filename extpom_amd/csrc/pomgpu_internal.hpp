@@ -196,6 +196,7 @@ struct pomgpu_ctx {
   int frc_n[3][4];           // which record number a slot holds (0 = empty)
   double *lat_dev[4];        // lateral_bc records: the 20 arrays of one record, concatenated (slot = n % 4)
   int lat_n[4];
+  int frc_on, lat_on;        // forcing / lateral records were supplied: pomgpu_advance runs surface_forcing / lateral_bc
   // profiling
   bool prof_on;
   ProfEntry prof[96];

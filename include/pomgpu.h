@@ -144,9 +144,10 @@ int pomgpu_check_velocity(pomgpu_ctx *ctx, double *vamax, int *imax, int *jmax);
  * sum(tb*dvol), out[6] = sum(et*darea), out[5] = 0) -- the caller reduces over ranks and forms the averages
  * exactly as the reference does on my_task 0; sums_only == 0: the single-task result. */
 int pomgpu_domain_stats(pomgpu_ctx *ctx, double *out, int sums_only);
-/* One internal step for the current blkcon.iint: get_time, lateral_viscosity, mode_interaction,
- * isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus file forcing,
- * print and output, which stay on the host).  Does not synchronise. */
+/* One internal step for the current blkcon.iint: get_time, [surface_forcing, lateral_bc -- once the host has
+ * supplied forcing / lateral records, see below; skipped otherwise: constant forcing], lateral_viscosity,
+ * mode_interaction, isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus print and
+ * output, which stay on the host).  Does not synchronise. */
 int pomgpu_advance(pomgpu_ctx *ctx);
 /* nsteps x { iint = iint+1; advance }  (pom.f:17-19).  Does not synchronise. */
 int pomgpu_run(pomgpu_ctx *ctx, int nsteps);

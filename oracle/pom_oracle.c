@@ -1654,8 +1654,13 @@ void pomo_check_velocity(pomo_tile *T) {
 }
 
 /* advance -- advance.f:6-59, without the file-driven forcing, print and output calls */
+/* advance.f:6-59.  surface_forcing and lateral_bc (:14-18) read files in the reference; here they run when
+ * the caller has registered the records those readers would deliver, and are skipped otherwise (the
+ * constant-forcing test cases). */
 void pomo_advance(pomo_tile *T) {
   pomo_get_time(T);
+  if (T->frc_a[0][1] || T->frc_a[1][1] || T->frc_a[2][1]) pomo_surface_forcing(T);
+  if (T->lat[1][0]) pomo_lateral_bc(T);
   pomo_lateral_viscosity(T);
   pomo_mode_interaction(T);
   for (iext = 1; iext <= isplit; iext++) pomo_mode_external(T);

@@ -148,13 +148,14 @@ def test_check_velocity_wavefront_reduction():
 
 
 def test_surface_and_lateral_forcing_on_device_across_record_changes():
-    """wind / heat / surface (bounds_forcing.f:871-983) and lateral_bc (:593-868) with the records in HBM: per step
-    get_time, surface_forcing, lateral_bc, advance as advance.f:11-33; dti = 360 s puts the record changes of the
-    surface fields at steps 30 and 60 and those of the lateral boundary values at every tenth step"""
+    """wind / heat / surface (bounds_forcing.f:871-983) and lateral_bc (:593-868) with the records in HBM, called
+    by advance itself (advance.f:14-18); dti = 360 s puts the record changes of the surface fields at steps 30 and
+    60 and those of the lateral boundary values at every tenth step"""
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
     OracleTile, oracle_finish_initial = _oracle()
-    from extpom_amd.cases import make_lateral_records
     a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=60, days=1.0)
     oracle_finish_initial(a)
+    make_forcing_records(a, 4)
     make_lateral_records(a, 8)
     b = a.copy()
     ot = OracleTile(a)
@@ -164,12 +165,8 @@ def test_surface_and_lateral_forcing_on_device_across_record_changes():
     for n in range(1, 63):
         if n % 10 == 0:
             g.set_lateral_records(first=n // 10 + 2, count=1)      # the record lateral_bc asks for at this step
-        a.iint = n
-        for r in ("get_time", "surface_forcing", "lateral_bc", "advance"):
-            ot.call(r)
-        g.set_con(iint=n)
-        for r in ("get_time", "surface_forcing", "lateral_bc", "advance"):
-            g.call(r)
+        ot.run(1)
+        g.run(1)
         if n in (1, 2, 10, 11, 30, 31, 60, 61, 62):
             g.download()
             assert not diff(a, b) and np.array_equal(a.bdry, b.bdry), f"step {n}: {diff(a, b)}"

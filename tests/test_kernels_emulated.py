@@ -69,12 +69,13 @@ def test_even_leading_dimension_steps(case, im, jm):
 
 
 def test_surface_and_lateral_forcing_across_record_changes():
-    """wind / heat / surface (bounds_forcing.f:871-983) and lateral_bc (:593-868) on the device side: per step
-    get_time, surface_forcing, lateral_bc, advance as advance.f:11-33; dti = 360 s puts the record changes of
-    the surface fields at step 30 and those of the lateral boundary values at every tenth step"""
-    from extpom_amd.cases import make_lateral_records
+    """wind / heat / surface (bounds_forcing.f:871-983) and lateral_bc (:593-868) on the device side, called by
+    advance itself (advance.f:14-18) once records are supplied; dti = 360 s puts the record changes of the surface
+    fields at step 30 and those of the lateral boundary values at every tenth step"""
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
     a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=60, days=1.0)
     oracle_finish_initial(a)
+    make_forcing_records(a, 4)
     make_lateral_records(a, 6)
     b = a.copy()
     ot = OracleTile(a)
@@ -84,12 +85,8 @@ def test_surface_and_lateral_forcing_across_record_changes():
     for n in range(1, 33):
         if n % 10 == 0:
             g.set_lateral_records(first=n // 10 + 2, count=1)      # the record lateral_bc asks for at this step
-        a.iint = n
-        for r in ("get_time", "surface_forcing", "lateral_bc", "advance"):
-            ot.call(r)
-        g.set_con(iint=n)
-        for r in ("get_time", "surface_forcing", "lateral_bc", "advance"):
-            g.call(r)
+        ot.run(1)
+        g.run(1)
         if n in (1, 2, 9, 10, 11, 20, 21, 29, 30, 31, 32):
             g.download()
             assert not diff(a, b) and np.array_equal(a.bdry, b.bdry), f"step {n}: {diff(a, b)}"

@@ -99,49 +99,25 @@ def test_domain_stats_matches_reference_to_rounding():
     np.testing.assert_allclose(np.array(list(out)), np.array([v.value for v in vals]), rtol=1e-13, atol=0)
 
 
-def test_surface_forcing_bit_identical_across_a_record_change():
-    """wind, heat, surface (bounds_forcing.f:871-983) fed with the same records through the readers' entry
-    points; 62 steps: the records shift at step 60 (0.125 d / 180 s)"""
+def test_forcing_bit_identical_across_record_changes():
+    """surface_forcing (wind, heat, surface: bounds_forcing.f:871-983) and lateral_bc (:593-868) inside advance
+    (advance.f:14-18), fed with the same records through the readers' entry points.  62 steps: the surface records
+    shift at step 60 (0.125 d / 180 s), the lateral ones every 20 steps (1/24 d).  The whole bdry block is compared
+    (incl. the members the reference never refreshes, :742-753)."""
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
     a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30, days=0.4)
     ref_finish_initial(a)
+    make_forcing_records(a, 4)
+    make_lateral_records(a, 5)
     b = a.copy()
     lib = RefLib(65, 49, 21)
     lib.put(a)
     ot = OracleTile(b)
     for n in range(1, 63):
         lib.con["iint"][0] = n
-        lib.call("get_time")
-        lib.call("surface_forcing")
         lib.advance()
-        b.iint = n
-        ot.call("get_time")
-        ot.call("surface_forcing")
-        ot.call("advance")
-        if n in (1, 2, 59, 60, 61, 62):
+        ot.run(1)
+        if n in (1, 2, 19, 20, 21, 40, 41, 59, 60, 61, 62):
             lib.get(a)
             assert not _diff(a, b), f"step {n}: {_diff(a, b)}"
     assert float(np.abs(a.tsurf).max()) > 0 and not np.array_equal(a.wusurfb, a.wusurff)
-
-
-def test_lateral_bc_bit_identical_across_record_changes():
-    """lateral_bc (bounds_forcing.f:593-868) fed through the reader's entry point; records every 1/24 d = 20 steps.
-    The whole bdry block is compared (incl. the members the reference never refreshes, :742-753)."""
-    from extpom_amd.cases import make_lateral_records
-    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30, days=0.4)
-    ref_finish_initial(a)
-    make_lateral_records(a, 4)
-    b = a.copy()
-    lib = RefLib(65, 49, 21)
-    lib.put(a)
-    ot = OracleTile(b)
-    for n in range(1, 45):
-        lib.con["iint"][0] = n
-        b.iint = n
-        for r in ("get_time", "surface_forcing", "lateral_bc"):
-            lib.call(r)
-            ot.call(r)
-        lib.advance()
-        ot.call("advance")
-        if n in (1, 2, 19, 20, 21, 40, 41, 44):
-            lib.get(a)
-            assert not _diff(a, b), f"step {n}: {_diff(a, b)}"
