@@ -329,6 +329,61 @@ __global__ void k_halo_unpack(KP P, HaloArgs A, int dir, const double *from_lo, 
     if (from_hi) G3(p, t, P.jm, k) = from_hi[o];
   }
 }
+// ---- single-phase exchange with up to eight neighbours -------------------------------------------------
+// The reference's two phases (east/west, then north/south INCLUDING the fresh ghost columns) put into a
+// corner ghost cell what the diagonal neighbour owns, or -- where one of the two adjacent sides is a
+// physical edge -- the edge cell of the other adjacent neighbour.  The same final ghost values follow from
+// ONE round: columns 2 / imm1 to W / E, rows 2 / jmm1 to S / N, the four cells (2,2), (imm1,2), (2,jmm1),
+// (imm1,jmm1) to SW, SE, NW, NE; the receiver writes a column only over the rows that no N/S neighbour's row
+// will own (1 or 2 .. jm or jmm1), a row over i = 1 or 2 .. im or imm1, corners from the diagonal tiles.
+// Direction order of the buffer tables: W E S N SW SE NW NE.  Layout per buffer: arrays concatenated, each
+// nz x len, level-major (len = jm, jm, im, im, 1, 1, 1, 1).
+struct Halo8 { double *b[8]; };
+__global__ void k_halo_pack8(KP P, HaloArgs A, Halo8 to) {
+  const int t = TID_I, k = (int)blockIdx.y + 1, a = (int)blockIdx.z;
+  if (k > A.nz[a]) return;
+  const double *p = A.ptr[a];
+  if (t <= P.jm) {
+    const size_t o = A.off[a] * (size_t)P.jm + (size_t)(k - 1) * P.jm + (size_t)(t - 1);
+    if (to.b[0]) to.b[0][o] = G3(p, 2, t, k);
+    if (to.b[1]) to.b[1][o] = G3(p, P.imm1, t, k);
+  }
+  if (t <= P.im) {
+    const size_t o = A.off[a] * (size_t)P.im + (size_t)(k - 1) * P.im + (size_t)(t - 1);
+    if (to.b[2]) to.b[2][o] = G3(p, t, 2, k);
+    if (to.b[3]) to.b[3][o] = G3(p, t, P.jmm1, k);
+  }
+  if (t == 1) {
+    const size_t o = A.off[a] + (size_t)(k - 1);
+    if (to.b[4]) to.b[4][o] = G3(p, 2, 2, k);
+    if (to.b[5]) to.b[5][o] = G3(p, P.imm1, 2, k);
+    if (to.b[6]) to.b[6][o] = G3(p, 2, P.jmm1, k);
+    if (to.b[7]) to.b[7][o] = G3(p, P.imm1, P.jmm1, k);
+  }
+}
+__global__ void k_halo_unpack8(KP P, HaloArgs A, Halo8 from) {
+  const int t = TID_I, k = (int)blockIdx.y + 1, a = (int)blockIdx.z;
+  if (k > A.nz[a]) return;
+  double *p = A.ptr[a];
+  const int jlo = P.S ? 1 : 2, jhi = P.N ? P.jm : P.jmm1, ilo = P.W ? 1 : 2, ihi = P.E ? P.im : P.imm1;
+  if (t >= jlo && t <= jhi) {
+    const size_t o = A.off[a] * (size_t)P.jm + (size_t)(k - 1) * P.jm + (size_t)(t - 1);
+    if (from.b[0]) G3(p, 1, t, k) = from.b[0][o];
+    if (from.b[1]) G3(p, P.im, t, k) = from.b[1][o];
+  }
+  if (t >= ilo && t <= ihi) {
+    const size_t o = A.off[a] * (size_t)P.im + (size_t)(k - 1) * P.im + (size_t)(t - 1);
+    if (from.b[2]) G3(p, t, 1, k) = from.b[2][o];
+    if (from.b[3]) G3(p, t, P.jm, k) = from.b[3][o];
+  }
+  if (t == 1) {
+    const size_t o = A.off[a] + (size_t)(k - 1);
+    if (from.b[4]) G3(p, 1, 1, k) = from.b[4][o];
+    if (from.b[5]) G3(p, P.im, 1, k) = from.b[5][o];
+    if (from.b[6]) G3(p, 1, P.jm, k) = from.b[6][o];
+    if (from.b[7]) G3(p, P.im, P.jm, k) = from.b[7][o];
+  }
+}
 static int halo_args(pomgpu_ctx *c, double *const *dev, const int *nz, int count, HaloArgs &A, int &nzmax) {
   if (count < 1 || count > 8) return -1;
   size_t off = 0;
@@ -355,5 +410,23 @@ int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int cou
   if (halo_args(c, dev, nz, count, A, nzmax)) return -1;
   const int len = dir == 0 ? c->P.jm : c->P.im;
   LAUNCH(c, k_halo_unpack, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, dir, from_lo, from_hi);
+  return 0;
+}
+int launch_halo_pack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *to) {
+  HaloArgs A; int nzmax;
+  if (halo_args(c, dev, nz, count, A, nzmax)) return -1;
+  Halo8 H;
+  for (int d = 0; d < 8; d++) H.b[d] = to[d];
+  const int len = c->P.im > c->P.jm ? c->P.im : c->P.jm;
+  LAUNCH(c, k_halo_pack8, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, H);
+  return 0;
+}
+int launch_halo_unpack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, const double *const *from) {
+  HaloArgs A; int nzmax;
+  if (halo_args(c, dev, nz, count, A, nzmax)) return -1;
+  Halo8 H;
+  for (int d = 0; d < 8; d++) H.b[d] = const_cast<double *>(from[d]);
+  const int len = c->P.im > c->P.jm ? c->P.im : c->P.jm;
+  LAUNCH(c, k_halo_unpack8, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, H);
   return 0;
 }

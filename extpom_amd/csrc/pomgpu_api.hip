@@ -425,6 +425,14 @@ extern "C" int pomgpu_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *
   if (!c || !dev || !nz || (dir != 0 && dir != 1)) return POMGPU_EINVAL;
   return launch_halo_unpack(c, dev, nz, count, dir, from_lo, from_hi) ? fail(c, POMGPU_EINVAL, "halo_unpack: bad array list") : POMGPU_OK;
 }
+extern "C" int pomgpu_halo_pack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *to) {
+  if (!c || !dev || !nz || !to) return POMGPU_EINVAL;
+  return launch_halo_pack8(c, dev, nz, count, to) ? fail(c, POMGPU_EINVAL, "halo_pack8: bad array list") : POMGPU_OK;
+}
+extern "C" int pomgpu_halo_unpack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, const double *const *from) {
+  if (!c || !dev || !nz || !from) return POMGPU_EINVAL;
+  return launch_halo_unpack8(c, dev, nz, count, from) ? fail(c, POMGPU_EINVAL, "halo_unpack8: bad array list") : POMGPU_OK;
+}
 
 // host address of a COMMON array -> device mirror (Fortran passes array actuals by reference)
 static double *dev3(pomgpu_ctx *c, const double *host) {

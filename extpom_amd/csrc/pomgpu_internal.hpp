@@ -335,6 +335,8 @@ void launch_bcond4_edges(pomgpu_ctx *c);
 void launch_bcond6_edges(pomgpu_ctx *c);
 void launch_bcondorl3(pomgpu_ctx *c);
 int launch_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi);
+int launch_halo_pack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *to);
+int launch_halo_unpack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, const double *const *from);
 int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo, const double *from_hi);
 // k_reduce.hip
 void launch_check_velocity(pomgpu_ctx *c);

@@ -32,6 +32,12 @@ class Tile:
     n_east: int
     n_south: int
     n_north: int
+    # diagonal neighbours (the reference reaches them through its two exchange phases; the single-phase
+    # device exchange sends them their corner cell directly)
+    n_sw: int = -1
+    n_se: int = -1
+    n_nw: int = -1
+    n_ne: int = -1
 
 
 def tile_grid(im_global: int, jm_global: int, im_local: int, jm_local: int) -> tuple[int, int]:
@@ -60,8 +66,9 @@ def make_tile(rank: int, im_global: int, jm_global: int, im_local: int, jm_local
     n_west = rank - 1 if px > 0 else -1
     n_north = rank + nproc_x if py + 1 < nproc_y else -1
     n_south = rank - nproc_x if py > 0 else -1
+    diag = lambda dx, dy: rank + dx + dy * nproc_x if 0 <= px + dx < nproc_x and 0 <= py + dy < nproc_y else -1
     return Tile(rank, nproc_x, nproc_y, px, py, im_local, jm_local, im, jm, i_off, j_off,
-                n_west, n_east, n_south, n_north)
+                n_west, n_east, n_south, n_north, diag(-1, -1), diag(1, -1), diag(-1, 1), diag(1, 1))
 
 
 def choose_tile_grid(n: int, im_global: int, jm_global: int) -> tuple[int, int]:

@@ -14,6 +14,8 @@ is latency-bound (~370 exchange points per internal step), not bandw
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -157,16 +159,69 @@ class Halo:
 class DeviceHalo:
     """The exchange hook for the HIP path: `Halo`'s semantics with the packing done by the library.
 
-    Per program point and phase: ONE pack launch (pomgpu_halo_pack: every array's edge into one
-    contiguous buffer per neighbour), ONE batch_isend_irecv (a grouped ncclSend/ncclRecv over xGMI),
-    ONE unpack launch -- all on the stream the kernels run on; no per-array torch ops, no
-    host-device synchronisation (RCCL path).  Buffers are allocated once.
+    Per program point ONE round: one pack launch (pomgpu_halo_pack8: every array's two edge columns, two edge
+    rows and four corner cells into one contiguous buffer per neighbour), ONE batch_isend_irecv with up to eight
+    neighbours (a grouped ncclSend/ncclRecv over xGMI), one unpack launch -- all on the stream the kernels run
+    on; no per-array torch ops, no host-device synchronisation (RCCL path).  The ghost cells end up exactly as
+    after the reference's two phases (pomgpu.h); `two_phase=True` keeps the reference's E/W-then-N/S rounds.
+    Buffers are allocated once.
     """
 
-    def __init__(self, gpu, tile, device, group=None, staged=False):
-        import ctypes
+    DIRS = ("w", "e", "s", "n", "sw", "se", "nw", "ne")
+
+    def __init__(self, gpu, tile, device, group=None, staged=False, two_phase=False):
         self.g, self.t, self.group, self.staged = gpu, tile, group, staged
         self.count = 0
+        self._vp = ctypes.c_void_p
+        L = gpu.L
+        kb = gpu.st.kb
+        if two_phase:
+            self._init_two_phase(gpu, tile, device, group, staged)
+            return
+        nb = dict(w=tile.n_west, e=tile.n_east, s=tile.n_south, n=tile.n_north, sw=tile.n_sw, se=tile.n_se, nw=tile.n_nw, ne=tile.n_ne)
+        length = dict(w=tile.jm, e=tile.jm, s=tile.im, n=tile.im, sw=1, se=1, nw=1, ne=1)
+        mk = lambda d: torch.empty(8 * kb * length[d], dtype=torch.float64, device=device)
+        self.send = {d: mk(d) for d in self.DIRS if nb[d] >= 0}
+        self.recv = {d: mk(d) for d in self.DIRS if nb[d] >= 0}
+        tab = lambda bufs: (ctypes.c_void_p * 8)(*[bufs[d].data_ptr() if d in bufs else None for d in self.DIRS])
+        to_tab, from_tab = tab(self.send), tab(self.recv)
+
+        def hook(user, ptrs, nz, count):
+            self.count += 1
+            if not self.send:
+                return
+            total = 0
+            for a in range(count):
+                total += nz[a]
+            if L.pomgpu_halo_pack8(gpu.h, ptrs, nz, count, to_tab):
+                raise RuntimeError("pomgpu_halo_pack8 failed")
+            ops, staged_recv = [], []
+            for d in self.DIRS:
+                if d not in self.send:
+                    continue
+                m = total * length[d]
+                snd, rcv = self.send[d][:m], self.recv[d][:m]
+                if staged:
+                    snd = snd.cpu()
+                    host = torch.empty_like(snd)
+                    staged_recv.append((host, rcv))
+                    rcv = host
+                ops.append(dist.P2POp(dist.isend, snd, nb[d], group=group))
+                ops.append(dist.P2POp(dist.irecv, rcv, nb[d], group=group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for host, dev in staged_recv:
+                dev.copy_(host)
+            if L.pomgpu_halo_unpack8(gpu.h, ptrs, nz, count, from_tab):
+                raise RuntimeError("pomgpu_halo_unpack8 failed")
+
+        from .lib import EXCHANGE_FN
+        self._cb = EXCHANGE_FN(hook)
+        self._tabs = (to_tab, from_tab)
+        gpu._chk(L.pomgpu_set_exchange(gpu.h, self._cb, None), "set_exchange")
+
+    def _init_two_phase(self, gpu, tile, device, group, staged):
+        L = gpu.L
         n = 8 * gpu.st.kb * max(tile.im, tile.jm)
         mk = lambda: torch.empty(n, dtype=torch.float64, device=device)
         self.buf = {(d, w, side): mk() for d in (0, 1) for w in ("s", "r") for side in ("lo", "hi")}

@@ -53,6 +53,8 @@ _SIGS = {
     "pomgpu_set_order_exchange": (_I, [_P, ORDER_FN, _P]),
     "pomgpu_halo_pack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
+    "pomgpu_halo_pack8": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, ctypes.POINTER(ctypes.c_void_p)]),
+    "pomgpu_halo_unpack8": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, ctypes.POINTER(ctypes.c_void_p)]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pomgpu_run": (_I, [_P, _I]),
     "pomgpu_domain_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double), _I]),

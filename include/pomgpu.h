@@ -129,6 +129,14 @@ int pomgpu_lateral_bc(pomgpu_ctx *ctx);
 int pomgpu_halo_pack(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, int dir, double *to_lo, double *to_hi);
 int pomgpu_halo_unpack(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, int dir, const double *from_lo,
                        const double *from_hi);
+/* The same exchange in ONE round with up to eight neighbours (half the message rounds per exchange point):
+ * buffer tables in the order W E S N SW SE NW NE, NULL = no such neighbour.  pack8: column 2 / im-1 (jm values
+ * per level) to W / E, row 2 / jm-1 (im values) to S / N, the cells (2,2), (im-1,2), (2,jm-1), (im-1,jm-1) to
+ * SW, SE, NW, NE.  unpack8: what W / E sent lands in column 1 / im over the rows no N/S neighbour's row owns,
+ * what S / N sent in row 1 / jm over the columns no W/E neighbour's column owns, the diagonal cells in the
+ * four corners -- the ghost cells end up exactly as after the reference's two phases. */
+int pomgpu_halo_pack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, double *const *to);
+int pomgpu_halo_unpack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, const double *const *from);
 
 /* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
 int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */

@@ -62,6 +62,32 @@ def exchange(board, tile, arrays):
         board.barrier.wait()
 
 
+OPPOSITE = dict(w="e", e="w", s="n", n="s", sw="ne", ne="sw", se="nw", nw="se")
+DIRS = ("w", "e", "s", "n", "sw", "se", "nw", "ne")
+
+
+def exchange8(board, tile, g, ptrs, nzs):
+    """the library's single-round exchange (pomgpu_halo_pack8 / unpack8) with up to eight neighbours"""
+    me = tile.rank
+    nb = dict(w=tile.n_west, e=tile.n_east, s=tile.n_south, n=tile.n_north, sw=tile.n_sw, se=tile.n_se, nw=tile.n_nw, ne=tile.n_ne)
+    length = dict(w=tile.jm, e=tile.jm, s=tile.im, n=tile.im, sw=1, se=1, nw=1, ne=1)
+    total = sum(nzs)
+    count = len(ptrs)
+    cp = (ctypes.c_void_p * count)(*ptrs)
+    cn = (ctypes.c_int * count)(*nzs)
+    send = {d: np.zeros(total * length[d]) for d in DIRS if nb[d] >= 0}
+    recv = {d: np.zeros(total * length[d]) for d in DIRS if nb[d] >= 0}
+    tab = lambda bufs: (ctypes.c_void_p * 8)(*[bufs[d].ctypes.data if d in bufs else None for d in DIRS])
+    assert g.L.pomgpu_halo_pack8(g.h, cp, cn, count, tab(send)) == 0
+    for d in send:
+        board.box[(me, nb[d], d)] = send[d]
+    board.barrier.wait()
+    for d in recv:                                    # what arrives from direction d left the neighbour towards OPPOSITE[d]
+        recv[d][:] = board.box[(nb[d], me, OPPOSITE[d])]
+    assert g.L.pomgpu_halo_unpack8(g.h, cp, cn, count, tab(recv)) == 0
+    board.barrier.wait()
+
+
 def order(board, tile, send_e, n_e, send_n, n_n, recv_w, recv_s):
     """parallel_mpi.f:353-480: one-way, eastward and northward"""
     me = tile.rank
@@ -78,7 +104,7 @@ def order(board, tile, send_e, n_e, send_n, n_n, recv_w, recv_s):
     board.barrier.wait()
 
 
-def run_tiles(nx, ny, nml):
+def run_tiles(nx, ny, nml, single_round=False):
     world = nx * ny
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     board, out, errs = Board(world), {}, []
@@ -92,7 +118,10 @@ def run_tiles(nx, ny, nml):
 
             def hook(ptrs, nzs):
                 count[0] += 1
-                exchange(board, tile, [view(p, nz, tile) for p, nz in zip(ptrs, nzs)])
+                if single_round:
+                    exchange8(board, tile, g, ptrs, nzs)
+                else:
+                    exchange(board, tile, [view(p, nz, tile) for p, nz in zip(ptrs, nzs)])
 
             g.set_exchange(hook)
             g.set_order_exchange(lambda *a: order(board, tile, *a))
@@ -121,9 +150,12 @@ def run_tiles(nx, ny, nml):
     return out
 
 
-@pytest.mark.parametrize("nx,ny,nml", [(2, 1, {}), (1, 2, {}), (2, 2, {}), (2, 2, dict(npg=2)), (2, 1, dict(nadv=1, mode=3))])
-def test_tiles_match_single_tile_oracle(nx, ny, nml):
-    out = run_tiles(nx, ny, nml)
+@pytest.mark.parametrize("nx,ny,nml,single_round", [(2, 1, {}, False), (1, 2, {}, False), (2, 2, {}, False), (2, 2, dict(npg=2), False),
+                                                    (2, 1, dict(nadv=1, mode=3), False),
+                                                    (2, 2, {}, True), (3, 2, dict(npg=2), True), (1, 3, {}, True)])
+def test_tiles_match_single_tile_oracle(nx, ny, nml, single_round):
+    """single_round: the library's one-round exchange with eight neighbours instead of the reference's two phases"""
+    out = run_tiles(nx, ny, nml, single_round)
     g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
