@@ -20,7 +20,7 @@ static ProfState *PS(pomgpu_ctx *c) { return (ProfState *)c->prof_state; }
 #define D2(c, name) SLOT2(c, P2_##name)
 #define D3(c, name) SLOT3(c, P3_##name)
 
-static int fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
+int pomgpu_fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
   if (c) {
     va_list ap;
     va_start(ap, fmt);
@@ -31,6 +31,7 @@ static int fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
   }
   return code;
 }
+#define fail pomgpu_fail
 #define HIPCHK(c, call)                                                                  \
   do {                                                                                   \
     hipError_t _e = (call);                                                              \

@@ -210,6 +210,7 @@ struct pomgpu_ctx {
 int pomgpu_prof_slot(pomgpu_ctx *c, const char *name);
 void pomgpu_prof_pre(pomgpu_ctx *c);
 void pomgpu_prof_post(pomgpu_ctx *c, int slot);
+int pomgpu_fail(pomgpu_ctx *c, int code, const char *fmt, ...);   // sets error_status, fills last_error, prints; returns code
 void pomgpu_launch_check(pomgpu_ctx *c, const char *name);   // a refused launch sets error_status, fills last_error, prints
 
 #define LAUNCH(c, kern, grid, block, ...)                                        \

@@ -8,6 +8,11 @@ module pomgpu_iface
     integer(c_int) :: im, jm, kb, im_local, jm_local, n_west, n_east, n_south, n_north
   end type
   type(c_ptr), save :: pom_ctx = c_null_ptr
+  type, bind(C) :: pomgpu_file_meta               ! include/pomgpu.h
+    type(c_ptr) :: title, time_start
+    integer(c_int) :: im_global, jm_global, i0, j0, create
+    type(c_ptr) :: stats
+  end type
   interface
     integer(c_int) function pomgpu_create(ctx, dims, device, stream) bind(C, name='pomgpu_create')
       import; type(c_ptr) :: ctx; type(pomgpu_dims) :: dims; integer(c_int), value :: device; type(c_ptr), value :: stream
@@ -44,6 +49,12 @@ module pomgpu_iface
     end function
     integer(c_int) function pomgpu_set_lateral_record(ctx, n, arrays) bind(C, name='pomgpu_set_lateral_record')
       import; type(c_ptr), value :: ctx; integer(c_int), value :: n; type(c_ptr) :: arrays(20)
+    end function
+    integer(c_int) function pomgpu_write_output(ctx, path, meta) bind(C, name='pomgpu_write_output')
+      import; type(c_ptr), value :: ctx, path; type(pomgpu_file_meta) :: meta
+    end function
+    integer(c_int) function pomgpu_write_restart(ctx, path, meta) bind(C, name='pomgpu_write_restart')
+      import; type(c_ptr), value :: ctx, path; type(pomgpu_file_meta) :: meta
     end function
     integer(c_int) function pomgpu_domain_stats(ctx, out, sums_only) bind(C, name='pomgpu_domain_stats')
       import; type(c_ptr), value :: ctx; real(c_double) :: out(8); integer(c_int), value :: sums_only

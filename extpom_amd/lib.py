@@ -16,6 +16,12 @@ class PomGpuError(RuntimeError):
     pass
 
 
+class FileMeta(ctypes.Structure):
+    """pomgpu_file_meta (include/pomgpu.h)"""
+    _fields_ = [("title", ctypes.c_char_p), ("time_start", ctypes.c_char_p), ("im_global", ctypes.c_int), ("jm_global", ctypes.c_int),
+                ("i0", ctypes.c_int), ("j0", ctypes.c_int), ("create", ctypes.c_int), ("stats", ctypes.POINTER(ctypes.c_double))]
+
+
 class Dims(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ("im", "jm", "kb", "im_local", "jm_local", "n_west", "n_east", "n_south", "n_north")]
@@ -57,6 +63,8 @@ _SIGS = {
     "pomgpu_halo_unpack8": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, ctypes.POINTER(ctypes.c_void_p)]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pomgpu_run": (_I, [_P, _I]),
+    "pomgpu_write_output": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(FileMeta)]),
+    "pomgpu_write_restart": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(FileMeta)]),
     "pomgpu_domain_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double), _I]),
     "pomgpu_advq": (_I, [_P, _P, _P, _P]),
     "pomgpu_advt1": (_I, [_P, _P, _P, _P, _P]),

@@ -117,6 +117,15 @@ class PomGpu:
         self._chk(self.L.pomgpu_domain_stats(self.h, out, 1 if sums_only else 0), "domain_stats")
         return tuple(out)
 
+    def write_file(self, kind, path, title="", time_start="", im_global=None, jm_global=None, create=True, stats=None):
+        """kind = "output" | "restart": the reference's NetCDF (CDF-2) files without PnetCDF (io_pnetcdf.F:57-410,
+        :1661-2083); this tile's patch at (i_off+1, j_off+1) of the global grid"""
+        st = self.st
+        m = _lib.FileMeta(title.encode(), time_start.encode(), im_global or st.im, jm_global or st.jm, st.i_off + 1, st.j_off + 1,
+                          1 if create else 0, (ctypes.c_double * 8)(*stats) if stats is not None else None)
+        fn = self.L.pomgpu_write_output if kind == "output" else self.L.pomgpu_write_restart
+        self._chk(fn(self.h, str(path).encode(), ctypes.byref(m)), "write_" + kind)
+
     def set_order_exchange(self, fn):
         """fn(send_east, n_east, send_north, n_north, recv_west, recv_south): device addresses (baropg_mcc's
         order2d_mpi / order3d_mpi, packed by the library) -- see extpom_amd.halo.Halo.device_order_hook"""

@@ -152,6 +152,23 @@ int pomgpu_check_velocity(pomgpu_ctx *ctx, double *vamax, int *imax, int *jmax);
  * sum(tb*dvol), out[6] = sum(et*darea), out[5] = 0) -- the caller reduces over ranks and forms the averages
  * exactly as the reference does on my_task 0; sums_only == 0: the single-task result. */
 int pomgpu_domain_stats(pomgpu_ctx *ctx, double *out, int sums_only);
+/* ---- output and restart files without PnetCDF (io_pnetcdf.F:57-410, :1661-2083) -----------------------------
+ * NetCDF "64-bit offset" (CDF-2) files with the reference's dimensions, variables, order, types and attribute
+ * texts, written directly.  Every rank writes its (im,jm) patch at (i0,j0) = (i_global(1), j_global(1)) of the
+ * global grid; the rank with create = 1 lays the file out first (the caller puts a barrier between it and the
+ * others).  stats: the eight domain_stats values after the rank reduction (NULL: this tile's own).  The file
+ * names are the caller's (the reference builds them from wrk_pth, netcdf_file / write_rst_file and the counter). */
+typedef struct pomgpu_file_meta {
+  const char *title;          /* blkchar title */
+  const char *time_start;     /* blkchar time_start: "days since <time_start>" */
+  int im_global, jm_global;
+  int i0, j0;                 /* 1-based global indices of the tile's (1,1) */
+  int create;                 /* 1: create the file and write header + scalars + own patch; 0: own patch only */
+  const double *stats;        /* vtot atot mtot stot tavg savg eavg ekin, or NULL */
+} pomgpu_file_meta;
+int pomgpu_write_output(pomgpu_ctx *ctx, const char *path, const pomgpu_file_meta *meta);    /* write_output_pnetcdf */
+int pomgpu_write_restart(pomgpu_ctx *ctx, const char *path, const pomgpu_file_meta *meta);   /* write_restart_pnetcdf */
+
 /* One internal step for the current blkcon.iint: get_time, [surface_forcing, lateral_bc -- once the host has
  * supplied forcing / lateral records, see below; skipped otherwise: constant forcing], lateral_viscosity,
  * mode_interaction, isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus print and

@@ -5,7 +5,7 @@ HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
 OUT=$ROOT/tests/_emu; mkdir -p "$OUT"
 SRC=$ROOT/extpom_amd/csrc
 FLAGS="-x c++ -std=c++17 -O2 -ffp-contract=off -fno-fast-math -fPIC -w -I$HERE -I$ROOT/include -I$SRC"
-for f in k_ext k_adv k_vert k_tile k_bc pomgpu_api; do
+for f in k_ext k_adv k_vert k_tile k_bc pomgpu_api cdf_out; do
   g++ $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &
 done
 g++ $FLAGS -c "$HERE/emu_support.cpp" -o "$OUT/emu_support.o" &

@@ -47,6 +47,13 @@ def worker(rank, world, split, port, out, nml):
     finish_initial(st, dens, baropg)
     g.upload(st)
     g.run(STEPS)
+    # the output file of the reference, every rank its patch (rank 0 lays the file out first)
+    if rank == 0:
+        g.write_file("output", os.path.join(out, "out.nc"), title="tiles", time_start="t0", im_global=IM, jm_global=JM, create=True)
+    dist.barrier()
+    if rank != 0:
+        g.write_file("output", os.path.join(out, "out.nc"), title="tiles", time_start="t0", im_global=IM, jm_global=JM, create=False)
+    dist.barrier()
     g.download()
     np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
              n=halo.count, **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
@@ -79,6 +86,16 @@ def main(split, nml):
             got = z[n][..., :jm, :im][..., sl_j, sl_i]
             if not np.array_equal(ref, got):
                 bad.append((r, n, float(np.abs(ref - got).max())))
+    from scipy.io import netcdf_file
+    with netcdf_file(os.path.join(out, "out.nc"), "r", mmap=False) as f:     # one file, written by all ranks
+        for n in ("t", "s", "u", "v", "rho"):
+            if not np.array_equal(f.variables[n][0], g.field(n)[:KB - 1]):
+                bad.append(("file", n, 0.0))
+        for n in ("elb", "uab", "vab"):
+            if not np.array_equal(f.variables[n][0], g.field(n)):
+                bad.append(("file", n, 0.0))
+        if not np.array_equal(f.variables["h"][:], g.field("h")):
+            bad.append(("file", "h", 0.0))
     if bad:
         print("MISMATCH", bad[:20])
         sys.exit(1)

@@ -173,6 +173,56 @@ def test_surface_and_lateral_forcing_on_device_across_record_changes():
     g.close()
 
 
+def test_output_and_restart_files_without_pnetcdf(tmp_path):
+    """write_output_pnetcdf / write_restart_pnetcdf (io_pnetcdf.F:57-410, :1661-2083) as plain CDF-2 files: read back
+    with scipy's NetCDF reader -- dimensions, variable names, order, dimensions per variable and attribute texts as
+    the reference defines them, values equal to the state on the device"""
+    from scipy.io import netcdf_file
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    g = _gpu(a)
+    g.run(3)
+    g.write_file("output", tmp_path / "out.nc", title="seamount test", time_start="2000-01-01 00:00:00 +00:00")
+    g.write_file("restart", tmp_path / "rst.nc", title="seamount test", time_start="2000-01-01 00:00:00 +00:00")
+    stats = g.domain_stats()
+    g.download()
+    g.close()
+    kb = 21
+    with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
+        assert f.version_byte == 2 and f.title == b"seamount test" and f.description == b"output file"
+        assert {k: v for k, v in f.dimensions.items()} == dict(time=1, z=kb, zz=kb - 1, y=49, x=65)
+        assert list(f.variables) == ["time", "vtot", "mtot", "tavg", "savg", "eavg", "ekin", "z", "zz", "dx", "dy", "east_u", "east_v",
+                                     "east_e", "east_c", "north_u", "north_v", "north_e", "north_c", "rot", "h", "fsm", "dum", "dvm", "uab",
+                                     "vab", "elb", "u", "v", "t", "s", "rho", "w"]
+        v = f.variables
+        assert v["u"].dimensions == ("time", "zz", "y", "x") and v["w"].dimensions == ("time", "z", "y", "x")
+        assert v["elb"].dimensions == ("time", "y", "x") and v["h"].dimensions == ("y", "x") and v["zz"].dimensions == ("zz",)
+        assert v["u"].long_name == b"x-velocity" and v["u"].units == b"metre/sec" and v["u"].coordinates == b"east_u north_u zz"
+        assert v["time"].units == b"days since 2000-01-01 00:00:00 +00:00" and v["z"].formula_terms == b"sigma: z eta: elb depth: h"
+        assert v["t"].data.dtype == np.dtype(">f8")
+        assert float(v["time"][0]) == a.time
+        assert [float(v[n][0]) for n in ("vtot", "mtot", "tavg", "savg", "eavg", "ekin")] == [stats[0], stats[2], stats[4], stats[5], stats[6], stats[7]]
+        assert np.array_equal(v["z"][:], a.z) and np.array_equal(v["zz"][:], a.zz[:kb - 1])
+        for n in ("dx", "east_c", "rot", "h", "fsm", "dvm"):
+            assert np.array_equal(v[n][:], a.field(n)), n
+        for n in ("uab", "vab", "elb"):
+            assert np.array_equal(v[n][0], a.field(n)), n
+        for n in ("u", "v", "t", "s", "rho"):
+            assert np.array_equal(v[n][0], a.field(n)[:kb - 1]), n
+        assert np.array_equal(v["w"][0], a.w)
+    with netcdf_file(str(tmp_path / "rst.nc"), "r", mmap=False) as f:
+        assert f.version_byte == 2 and f.description == b"restart file"
+        assert {k: v for k, v in f.dimensions.items()} == dict(time=1, z=kb, y=49, x=65)
+        from extpom_amd.layout import RESTART_2D, RESTART_3D
+        names = list(f.variables)
+        assert names[:2] == ["iint", "time"] and sorted(names[2:]) == sorted(RESTART_2D + RESTART_3D)
+        assert f.variables["iint"].dimensions == () and float(f.variables["iint"].getValue()) == 3.0
+        assert f.variables["q2l"].long_name == b"q2 x l" and f.variables["advua"].long_name == b"sum of 2nd, 3rd and 4th terms in eq (18)"
+        for n in RESTART_2D + RESTART_3D:
+            assert np.array_equal(f.variables[n][:], a.field(n)), n
+
+
 def test_domain_stats_on_device():
     """print_section's sums (advance.f:644-756) reduced on the device: equal to the oracle to rounding,
     and the same bits every time (fixed reduction tree, no atomics)"""

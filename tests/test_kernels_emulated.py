@@ -92,6 +92,30 @@ def test_surface_and_lateral_forcing_across_record_changes():
             assert not diff(a, b) and np.array_equal(a.bdry, b.bdry), f"step {n}: {diff(a, b)}"
 
 
+def test_output_and_restart_files_read_back(tmp_path):
+    """the CDF-2 writer (host code of the library, io_pnetcdf.F:57-410, :1661-2083) through the emulated build:
+    scipy's NetCDF reader sees the reference's dimensions, variables and attribute texts and the state's values"""
+    from scipy.io import netcdf_file
+    from extpom_amd.layout import RESTART_2D, RESTART_3D
+    a = make_case("island", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    g = PomGpu(a, libpath=EMU)
+    g.run(2)
+    g.write_file("output", tmp_path / "out.nc", title="island", time_start="2000-01-01 00:00:00 +00:00")
+    g.write_file("restart", tmp_path / "rst.nc", title="island", time_start="2000-01-01 00:00:00 +00:00")
+    g.download()
+    with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
+        assert f.version_byte == 2 and f.description == b"output file"
+        assert dict(f.dimensions) == dict(time=1, z=21, zz=20, y=49, x=65)
+        assert list(f.variables)[:9] == ["time", "vtot", "mtot", "tavg", "savg", "eavg", "ekin", "z", "zz"] and list(f.variables)[-6:] == ["u", "v", "t", "s", "rho", "w"]
+        assert f.variables["rho"].dimensions == ("time", "zz", "y", "x") and f.variables["rho"].units == b"dimensionless"
+        assert np.array_equal(f.variables["t"][0], a.t[:20]) and np.array_equal(f.variables["w"][0], a.w) and np.array_equal(f.variables["elb"][0], a.elb)
+    with netcdf_file(str(tmp_path / "rst.nc"), "r", mmap=False) as f:
+        assert list(f.variables)[:2] == ["iint", "time"] and sorted(list(f.variables)[2:]) == sorted(RESTART_2D + RESTART_3D)
+        for n in RESTART_2D + RESTART_3D:
+            assert np.array_equal(f.variables[n][:], a.field(n)), n
+
+
 def test_kb_above_the_register_kernels_bound():
     """kb = 70 > 64: the column kernels with private work vectors take over from the unrolled ones"""
     a = make_case("basin", 64, 48, 70, dte=6.0, isplit=30)
