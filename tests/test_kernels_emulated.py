@@ -116,6 +116,20 @@ def test_output_and_restart_files_read_back(tmp_path):
             assert np.array_equal(f.variables[n][:], a.field(n)), n
 
 
+def test_ramped_forcing_steps():
+    """lramp = .true.: ramp = time/period changes every step (advance.f:66-72)"""
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    a.lramp = True
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    ot.run(5)
+    g.run(5)
+    g.download()
+    assert 0.0 < a.ramp < 1.0 and a.ramp == b.ramp and not diff(a, b), diff(a, b)
+
+
 def test_kb_above_the_register_kernels_bound():
     """kb = 70 > 64: the column kernels with private work vectors take over from the unrolled ones"""
     a = make_case("basin", 64, 48, 70, dte=6.0, isplit=30)

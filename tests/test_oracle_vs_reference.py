@@ -121,3 +121,21 @@ def test_forcing_bit_identical_across_record_changes():
             lib.get(a)
             assert not _diff(a, b), f"step {n}: {_diff(a, b)}"
     assert float(np.abs(a.tsurf).max()) > 0 and not np.array_equal(a.wusurfb, a.wusurff)
+
+
+def test_ramped_forcing_bit_identical():
+    """lramp = .true.: ramp = time/period grows every step (advance.f:66-72) and scales the open-boundary
+    velocities and the pressure gradient"""
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    a.lramp = True
+    ref_finish_initial(a)
+    b = a.copy()
+    lib = RefLib(65, 49, 21)
+    lib.put(a)
+    ot = OracleTile(b)
+    for n in range(1, 7):
+        lib.con["iint"][0] = n
+        lib.advance()
+        ot.run(1)
+    lib.get(a)
+    assert 0.0 < a.ramp < 1.0 and not _diff(a, b), _diff(a, b)
