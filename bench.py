@@ -162,11 +162,29 @@ def main():
         torch.cuda.set_stream(ts)
         stream = ts.cuda_stream
     g = gpu_initialise(st, local, stream)
+    exchange = "none"
     if world > 1:
-        from extpom_amd.halo import DeviceHalo
-        halo = DeviceHalo(g, tile, torch.device("cuda", local), staged=rehearse)
-        from extpom_amd.halo import Halo
-        g.set_order_exchange(Halo(tile, staged=rehearse).device_order_hook(torch.device("cuda", local)))   # npg = 2 only
+        # The library serves every exchange point itself: pack -> one grouped ncclSend/ncclRecv round (RCCL over
+        # xGMI, enqueued on the kernels' stream by the library, no Python in the loop) -> unpack; and the 2-D
+        # external mode runs on a wide-halo copy of the tile (one exchange per internal step instead of ~180).
+        from extpom_amd import halo as H
+        dev = torch.device("cuda", local)
+        if rehearse:
+            g.set_transport(tile, H.StagedMover(g, tile, dev))
+            exchange = "library exchange, host-staged mover (rehearsal)"
+        else:
+            try:
+                H.connect_rccl(g, tile, rank, world)
+                exchange = "library exchange, native RCCL send/recv on the kernels' stream"
+            except Exception as e:       # e.g. librccl cannot be opened: torch.distributed's RCCL P2P carries the same messages
+                print(f"bench[{rank}]: native RCCL transport unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
+                H.DeviceHalo(g, tile, dev)
+                g.set_order_exchange(H.Halo(tile).device_order_hook(dev))   # npg = 2 only
+                exchange = "torch.distributed batch_isend_irecv (RCCL) per exchange point"
+        if exchange.startswith("library") and os.environ.get("POM_BENCH_WIDE", "1") != "0":
+            tiles = [pdist.tile_for_rank(r, world, im, jm) for r in range(world)]
+            if g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles)):
+                exchange += "; wide-halo external mode"
 
     def barrier():
         g.sync()
@@ -187,6 +205,7 @@ def main():
     # the timed region: exactly K steps, only the dominant kernel bracketed by events
     g.prof_begin(only=None if args.profile_all else dom)
     barrier()
+    rounds0 = g.exchange_rounds()
     t0 = time.perf_counter()
     g.run(args.steps)
     g.sync()
@@ -233,7 +252,8 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
-                       "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells},
+                       "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
+                       "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0},
             "roofline": roof,
             "step_algorithmic_GBps": round(step_gbs, 1), "step_frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "internal_mode": {"device_ms_per_step": round(int_ms, 3), "cell_updates_per_s": (tile_cells / (int_ms * 1e-3)) if int_ms else None,

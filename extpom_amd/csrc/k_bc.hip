@@ -430,3 +430,19 @@ int launch_halo_unpack8(pomgpu_ctx *c, double *const *dev, const int *nz, int co
   LAUNCH(c, k_halo_unpack8, dim3((len + 63) / 64, nzmax, count), dim3(64, 1, 1), c->P, A, H);
   return 0;
 }
+
+// ---- rectangular block copies (wide-halo external mode: gather into / scatter from the extended tile) ------
+// One launch serves a whole table of jobs (blockIdx.z = job); a job narrower / shorter than the launch's
+// extent leaves its surplus threads idle.  i runs along threadIdx.x: rows are read and written contiguously.
+__global__ void k_rect_copy(const RectJob *jobs, int njobs) {
+  const int q = (int)blockIdx.z;
+  if (q >= njobs) return;
+  const RectJob J = jobs[q];
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), j = (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  if (i >= J.ni || j >= J.nj) return;
+  J.dst[(size_t)j * J.ld_d + i] = J.src[(size_t)j * J.ld_s + i];
+}
+void launch_rect_jobs(pomgpu_ctx *c, const RectJob *jobs_dev, int njobs, int max_ni, int max_nj) {
+  if (njobs <= 0 || max_ni <= 0 || max_nj <= 0) return;
+  LAUNCH(c, k_rect_copy, dim3((max_ni + 63) / 64, (max_nj + 3) / 4, njobs), dim3(64, 4, 1), jobs_dev, njobs);
+}

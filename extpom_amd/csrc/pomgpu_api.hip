@@ -21,6 +21,7 @@ static ProfState *PS(pomgpu_ctx *c) { return (ProfState *)c->prof_state; }
 #define D3(c, name) SLOT3(c, P3_##name)
 
 int pomgpu_fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
+  if (c && c->parent) c = c->parent;
   if (c) {
     va_list ap;
     va_start(ap, fmt);
@@ -40,6 +41,7 @@ int pomgpu_fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
 
 void pomgpu_launch_check(pomgpu_ctx *c, const char *name) {
   const hipError_t e = hipGetLastError();
+  if (c->parent) c = c->parent;
   if (e == hipSuccess || c->launch_err) return;
   c->launch_err = (int)e;
   (void)fail(c, POMGPU_EHIP, "launch of %s refused: %s", name, hipGetErrorString(e));
@@ -47,6 +49,7 @@ void pomgpu_launch_check(pomgpu_ctx *c, const char *name) {
 
 // ---- profiling ---------------------------------------------------------------------------------
 int pomgpu_prof_slot(pomgpu_ctx *c, const char *name) {
+  if (c->parent) c = c->parent;
   ProfState *ps = PS(c);
   if (ps->filter[0] && strcmp(ps->filter, name) != 0) return -1;
   for (int k = 0; k < c->nprof; k++)
@@ -58,6 +61,7 @@ int pomgpu_prof_slot(pomgpu_ctx *c, const char *name) {
   return c->nprof++;
 }
 void pomgpu_prof_pre(pomgpu_ctx *c) {
+  if (c->parent) c = c->parent;
   ProfState *ps = PS(c);
   ProfPair p;
   if (!ps->free_.empty()) { p = ps->free_.back(); ps->free_.pop_back(); }
@@ -67,6 +71,7 @@ void pomgpu_prof_pre(pomgpu_ctx *c) {
   ps->pending.push_back(p);
 }
 void pomgpu_prof_post(pomgpu_ctx *c, int slot) {
+  if (c->parent) c = c->parent;
   ProfState *ps = PS(c);
   ProfPair &p = ps->pending.back();
   p.slot = slot;
@@ -90,6 +95,7 @@ extern "C" int pomgpu_prof_begin(pomgpu_ctx *c) {
   if (!c) return POMGPU_EINVAL;
   c->nprof = 0;
   c->prof_on = true;
+  if (c->wide.x) c->wide.x->prof_on = true;
   return POMGPU_OK;
 }
 // restrict event bracketing to one kernel (by name, e.g. "k_profq"); NULL or "" = every kernel
@@ -103,6 +109,7 @@ extern "C" int pomgpu_prof_end(pomgpu_ctx *c) {
   if (!c) return POMGPU_EINVAL;
   prof_drain(c);
   c->prof_on = false;
+  if (c->wide.x) c->wide.x->prof_on = false;
   return POMGPU_OK;
 }
 extern "C" int pomgpu_prof_count(pomgpu_ctx *c) { return c ? c->nprof : 0; }
@@ -158,7 +165,11 @@ static void ext_canonical(pomgpu_ctx *c) {
   c->ext_parity = 0;
   ext_buffers(c);
 }
+static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *stream, int flags);
 extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *stream) {
+  return ctx_create(out, d, device, stream, 0);
+}
+static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *stream, int flags) {
   if (!out || !d) return POMGPU_EINVAL;
   *out = NULL;
   if (d->kb < 4 || d->kb > POMGPU_KBMAX || d->im < 5 || d->jm < 5 || d->im > d->im_local || d->jm > d->jm_local) {
@@ -175,6 +186,7 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   pomgpu_ctx *c = (pomgpu_ctx *)calloc(1, sizeof(pomgpu_ctx));
   if (!c) return POMGPU_ENOMEM;
   c->device = device;
+  c->flags = flags;
   if (hipSetDevice(device) != hipSuccess) { free(c); return POMGPU_EHIP; }
   KP &P = c->P;
   P.im = d->im; P.jm = d->jm; P.kb = d->kb; P.imm1 = d->im - 1; P.jmm1 = d->jm - 1; P.kbm1 = d->kb - 1; P.kbm2 = d->kb - 2;
@@ -207,9 +219,10 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   };
   alloc(&P.b1, (size_t)POM_NBLK1D * P.kb);
   alloc(&P.b2, (size_t)POM_NBLK2D * P.n2);
-  alloc(&P.b3, (size_t)POM_NBLK3D * P.n3);
+  const bool only2d = (flags & POMGPU_CTX_2D) != 0;
+  if (!only2d) alloc(&P.b3, (size_t)POM_NBLK3D * P.n3);
   alloc(&P.bd, nbd);
-  for (int n = 0; n < POMGPU_NSCR3; n++) alloc(&P.s3[n], P.n3);
+  for (int n = 0; n < POMGPU_NSCR3 && !only2d; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
   for (int n = 0; n < 5; n++) alloc(&c->alt2[n], P.n2);
@@ -236,10 +249,13 @@ extern "C" int pomgpu_create(pomgpu_ctx **out, const pomgpu_dims *d, int device,
   return POMGPU_OK;
 }
 
+static void wide_free(pomgpu_ctx *c);
 extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  wide_free(c);
+  pomgpu_tp_free(c);
   KP &P = c->P;
   (void)hipFree(P.b1); (void)hipFree(P.b2); (void)hipFree(P.b3); (void)hipFree(P.bd);
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
@@ -311,6 +327,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   HIPCHK(c, hipSetDevice(c->device));
   ext_canonical(c);
   restore_materialize(c);
+  c->wide.static_done = 0;                                    // the extended tile's copy of the grid metrics is stale
   if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
@@ -355,6 +372,7 @@ extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->wide.static_done = 0;
   refresh_coefs(c);
   return POMGPU_OK;
 }
@@ -661,6 +679,278 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
   return POMGPU_OK;
 }
+// ---- the library's own exchange (include/pomgpu.h "transport") -----------------------------------------------
+// every exchange point: pack8 -> one message round -> unpack8, all on the stream (parallel_mpi.f:154-351)
+static void tp_exchange(void *user, double *const *dev, const int *nz, int count) {
+  pomgpu_ctx *c = (pomgpu_ctx *)user;
+  const KP &P = c->P;
+  pomgpu_transport &T = c->tp;
+  size_t total = 0;
+  for (int a = 0; a < count; a++) total += (size_t)nz[a];
+  const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
+  size_t cnt[8];
+  for (int d = 0; d < 8; d++) {
+    cnt[d] = T.nbr[d] >= 0 ? total * len[d] : 0;
+    if (cnt[d] > T.cap[d]) { (void)fail(c, POMGPU_EINVAL, "exchange: %zu doubles exceed the staging buffer", cnt[d]); return; }
+  }
+  if (launch_halo_pack8(c, dev, nz, count, T.send)) { (void)fail(c, POMGPU_EINVAL, "exchange: bad array list"); return; }
+  if (pomgpu_tp_move(c, cnt, cnt)) return;
+  (void)launch_halo_unpack8(c, dev, nz, count, T.recv);
+}
+// order2d_mpi / order3d_mpi (parallel_mpi.f:353-480): eastward and northward only
+static void tp_order(void *user, const double *send_e, int n_e, const double *send_n, int n_n, double *recv_w, double *recv_s) {
+  pomgpu_ctx *c = (pomgpu_ctx *)user;
+  const pomgpu_transport &T = c->tp;
+  const double *snd[8] = {NULL, send_e, NULL, send_n, NULL, NULL, NULL, NULL};
+  double *rcv[8] = {recv_w, NULL, recv_s, NULL, NULL, NULL, NULL, NULL};
+  size_t sc[8] = {0, T.nbr[1] >= 0 ? (size_t)n_e : 0, 0, T.nbr[3] >= 0 ? (size_t)n_n : 0, 0, 0, 0, 0};
+  size_t rc[8] = {T.nbr[0] >= 0 ? (size_t)n_e : 0, 0, T.nbr[2] >= 0 ? (size_t)n_n : 0, 0, 0, 0, 0, 0};
+  (void)pomgpu_tp_move_ptr(c, snd, sc, rcv, rc);
+}
+static int tp_install(pomgpu_ctx *c, const int *nbr8) {
+  int rc = pomgpu_tp_setup(c, nbr8);
+  if (rc) return rc;
+  bool any = false;
+  for (int d = 0; d < 8; d++) any = any || c->tp.nbr[d] >= 0;
+  // a tile without neighbours keeps the single-tile (fused) kernels: every exchange is a no-op (parallel_mpi.f:171)
+  c->exch = any ? tp_exchange : NULL; c->exch_user = c;
+  c->order = any ? tp_order : NULL; c->order_user = c;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_transport_fn fn, void *user) {
+  NEED_RAW(c);
+  if (!fn) return fail(c, POMGPU_EINVAL, "set_transport: no mover");
+  pomgpu_tp_free(c);
+  c->tp.fn = fn; c->tp.user = user;
+  return tp_install(c, nbr8);
+}
+extern "C" int pomgpu_rccl_init(pomgpu_ctx *c, const void *id128, int rank, int nranks, const int *nbr8, const char *librccl_path) {
+  NEED_RAW(c);
+  pomgpu_tp_free(c);
+  int rc = pomgpu_tp_rccl(c, id128, rank, nranks, librccl_path);
+  if (rc) return rc;
+  return tp_install(c, nbr8);
+}
+
+// ---- wide-halo external mode (include/pomgpu.h: pomgpu_set_wide_external) --------------------------------------
+// How far stale cells spread (advance.f:211-347, solver.f:16-121).  The outermost line of the extended tile is
+// never computed (in the reference it comes from an exchange).  uaf(i) reads ua(i-1..i+1), el(i-1) and, through
+// fluxua(i-1) inside advua, d(i-2); elf(i) reads ua(i..i+1), d(i-1..i+1).  If ua is wrong up to column a and el, d
+// up to column b, the next substep leaves ua wrong up to max(a+1, b+2) and el up to a: starting from a=2, b=1 the
+// front moves ONE column per substep (ua wrong up to n+1, el up to n after n substeps; the other three sides
+// alike).  advave and the tail of mode_interaction, run once before the loop on the same extended tile, add two
+// columns at most.  With w = isplit + 4 extra cells the tile and its ghost cells are never reached
+// (tests/test_kernels_emulated_tiles.py shows exact ghost cells with this w and owned cells going wrong below
+// isplit - 1).
+// Arrays that travel.  HALO: read by the 2-D part of the step with a stencil or by a substep's pointwise formulas
+// in cells beyond the tile -- they need the neighbours' cells.  LOCAL: written by the 2-D part; the extended tile
+// starts from the tile's own values so that cells no kernel writes (e.g. utf(1,j) on a physical edge) stay what they
+// are.  BACK: what the 2-D part writes -- copied back, ghost cells included.
+static const int WIDE_HALO[] = {P2_adx2d, P2_ady2d, P2_drx2d, P2_dry2d, P2_aam2d, P2_ua, P2_va, P2_uab, P2_vab, P2_el, P2_elb,
+                                P2_d, P2_vfluxf, P2_e_atmos, P2_wusurf, P2_wvsurf, P2_wubot, P2_wvbot};
+static const int WIDE_LOCAL[] = {P2_advua, P2_advva, P2_elf, P2_uaf, P2_vaf, P2_egf, P2_utf, P2_vtf, P2_etf};
+static const int WIDE_BACK[] = {P2_adx2d, P2_ady2d, P2_advua, P2_advva, P2_elf, P2_uaf, P2_vaf, P2_ua, P2_va, P2_el, P2_elb, P2_d,
+                                P2_uab, P2_vab, P2_egf, P2_utf, P2_vtf, P2_etf, P2_wubot, P2_wvbot};
+// open-boundary values bcond(2) reads (bounds_forcing.f:43-83): indexed by j on the west / east edge, by i on the
+// south / north edge; a tile on such an edge continues them from its neighbours along the edge
+static const int WIDE_BD_J[] = {PB_uabw, PB_elw, PB_vabw, PB_uabe, PB_ele, PB_vabe};
+static const int WIDE_BD_I[] = {PB_vabs, PB_els, PB_uabs, PB_vabn, PB_eln, PB_uabn};
+#define NEL(a) ((int)(sizeof(a) / sizeof((a)[0])))
+
+struct JobList {
+  std::vector<RectJob> jobs;
+  std::vector<RectGroup> groups;
+  void begin() { RectGroup g = {(int)jobs.size(), 0, 0, 0}; groups.push_back(g); }
+  void add(const double *src, int ld_s, double *dst, int ld_d, int ni, int nj) {
+    if (ni <= 0 || nj <= 0) return;
+    RectJob j = {src, dst, ld_s, ld_d, ni, nj};
+    jobs.push_back(j);
+    RectGroup &g = groups.back();
+    g.count++;
+    if (ni > g.mni) g.mni = ni;
+    if (nj > g.mnj) g.mnj = nj;
+  }
+};
+static int table_upload(pomgpu_ctx *c, const JobList &L, RectTable &T) {
+  T.dev = NULL; T.ngroups = 0;
+  if (L.jobs.empty()) return POMGPU_OK;
+  if (hipMalloc((void **)&T.dev, L.jobs.size() * sizeof(RectJob)) != hipSuccess) return fail(c, POMGPU_ENOMEM, "wide: job table");
+  HIPCHK(c, hipMemcpyAsync(T.dev, L.jobs.data(), L.jobs.size() * sizeof(RectJob), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));                 // L.jobs is the caller's temporary
+  for (size_t n = 0; n < L.groups.size() && T.ngroups < 8; n++)
+    if (L.groups[n].count) T.g[T.ngroups++] = L.groups[n];
+  return POMGPU_OK;
+}
+static void table_run(pomgpu_ctx *c, const RectTable &T) {
+  for (int n = 0; n < T.ngroups; n++) launch_rect_jobs(c, T.dev + T.g[n].first, T.g[n].count, T.g[n].mni, T.g[n].mnj);
+}
+static void table_free(RectTable &T) { (void)hipFree(T.dev); T.dev = NULL; T.ngroups = 0; }
+static void wide_free(pomgpu_ctx *c) {
+  pomgpu_wide &Wd = c->wide;
+  table_free(Wd.gather_pack); table_free(Wd.gather_unpack); table_free(Wd.scatter);
+  if (Wd.x) { pomgpu_destroy(Wd.x); Wd.x = NULL; }
+  Wd.on = 0;
+}
+// the block of the tile that neighbour d needs (sx,sy: its first cell, tile indices) and where the block that
+// neighbour d sends lands in the extended tile (rx,ry: tile indices, i.e. before + ox / + oy); both ni x nj
+static void wide_rect(const KP &P, int w, int d, int &sx, int &sy, int &rx, int &ry, int &ni, int &nj) {
+  static const int DX[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, DY[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+  const int lox = P.W ? 1 : 2, hix = P.E ? P.im : P.imm1, loy = P.S ? 1 : 2, hiy = P.N ? P.jm : P.jmm1;
+  if (DX[d] < 0) { sx = 2; rx = 1 - w; ni = w + 1; }
+  else if (DX[d] > 0) { sx = P.im - 1 - w; rx = P.im; ni = w + 1; }
+  else { sx = rx = lox; ni = hix - lox + 1; }
+  if (DY[d] < 0) { sy = 2; ry = 1 - w; nj = w + 1; }
+  else if (DY[d] > 0) { sy = P.jm - 1 - w; ry = P.jm; nj = w + 1; }
+  else { sy = ry = loy; nj = hiy - loy + 1; }
+}
+// Job lists for one set of arrays: `halo` slots get the tile's own cells and the neighbours' blocks, `local` slots
+// the tile's own cells only; with_bd adds the open-boundary lines.  pack/unpack go around one message round.
+static void wide_jobs(pomgpu_ctx *c, const int *halo, int nhalo, const int *local, int nlocal, bool with_bd, JobList &pack,
+                      JobList &unpack, size_t *scount, size_t *rcount) {
+  const KP &P = c->P;
+  const pomgpu_wide &Wd = c->wide;
+  const KP &X = Wd.x->P;
+  const pomgpu_transport &T = c->tp;
+  auto tile = [&](int s, int i, int j) { return P.b2 + (size_t)s * P.n2 + (size_t)(j - 1) * P.iml + (size_t)(i - 1); };
+  auto ext = [&](int s, int i, int j) { return X.b2 + (size_t)s * X.n2 + (size_t)(j + Wd.oy - 1) * X.iml + (size_t)(i + Wd.ox - 1); };
+  pack.begin();                                               // own cells, ghost cells included
+  for (int n = 0; n < nhalo; n++) pack.add(tile(halo[n], 1, 1), P.iml, ext(halo[n], 1, 1), X.iml, P.im, P.jm);
+  for (int n = 0; n < nlocal; n++) pack.add(tile(local[n], 1, 1), P.iml, ext(local[n], 1, 1), X.iml, P.im, P.jm);
+  if (with_bd) {
+    pack.begin();
+    for (int n = 0; n < NEL(WIDE_BD_J); n++) pack.add(P.bd + P.bdoff[WIDE_BD_J[n]], P.jml, X.bd + X.bdoff[WIDE_BD_J[n]] + Wd.oy, X.jml, P.jm, 1);
+    for (int n = 0; n < NEL(WIDE_BD_I); n++) pack.add(P.bd + P.bdoff[WIDE_BD_I[n]], P.iml, X.bd + X.bdoff[WIDE_BD_I[n]] + Wd.ox, X.iml, P.im, 1);
+  }
+  for (int cls = 0; cls < 3; cls++) {                         // W/E blocks, S/N blocks, corners: one launch each
+    pack.begin(); unpack.begin();
+    for (int d = (cls == 0 ? 0 : (cls == 1 ? 2 : 4)); d < (cls == 0 ? 2 : (cls == 1 ? 4 : 8)); d++) {
+      scount[d] = rcount[d] = 0;
+      if (T.nbr[d] < 0) continue;
+      int sx, sy, rx, ry, ni, nj;
+      wide_rect(P, Wd.w, d, sx, sy, rx, ry, ni, nj);
+      size_t o = 0;
+      for (int n = 0; n < nhalo; n++) {
+        pack.add(tile(halo[n], sx, sy), P.iml, T.send[d] + o, ni, ni, nj);
+        unpack.add(T.recv[d] + o, ni, ext(halo[n], rx, ry), X.iml, ni, nj);
+        o += (size_t)ni * nj;
+      }
+      if (with_bd && cls == 1)                                // from S / N: the continuation of the west / east edge lines
+        for (int n = 0; n < NEL(WIDE_BD_J); n++) {
+          pack.add(P.bd + P.bdoff[WIDE_BD_J[n]] + (sy - 1), nj, T.send[d] + o, nj, nj, 1);
+          unpack.add(T.recv[d] + o, nj, X.bd + X.bdoff[WIDE_BD_J[n]] + (ry + Wd.oy - 1), nj, nj, 1);
+          o += (size_t)nj;
+        }
+      if (with_bd && cls == 0)                                // from W / E: the continuation of the south / north edge lines
+        for (int n = 0; n < NEL(WIDE_BD_I); n++) {
+          pack.add(P.bd + P.bdoff[WIDE_BD_I[n]] + (sx - 1), ni, T.send[d] + o, ni, ni, 1);
+          unpack.add(T.recv[d] + o, ni, X.bd + X.bdoff[WIDE_BD_I[n]] + (rx + Wd.ox - 1), ni, ni, 1);
+          o += (size_t)ni;
+        }
+      scount[d] = rcount[d] = o;
+    }
+  }
+}
+static void refresh_coefs(pomgpu_ctx *c);
+// grid metrics, masks, Coriolis ... : every blk2d array once (and again after an upload), in chunks that fit
+// the staging buffers
+static int wide_static(pomgpu_ctx *c) {
+  pomgpu_wide &Wd = c->wide;
+  const int chunk = NEL(WIDE_HALO);
+  for (int s0 = 0; s0 < POM_NBLK2D; s0 += chunk) {
+    int slots[64], n = 0;
+    for (int s = s0; s < POM_NBLK2D && n < chunk; s++) slots[n++] = s;
+    JobList pk, up;
+    size_t sc[8], rc[8];
+    wide_jobs(c, slots, n, NULL, 0, false, pk, up, sc, rc);
+    RectTable tp_, tu_;
+    int e;
+    if ((e = table_upload(c, pk, tp_)) || (e = table_upload(c, up, tu_))) return e;
+    table_run(c, tp_);
+    if ((e = pomgpu_tp_move(c, sc, rc))) return e;
+    table_run(c, tu_);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    table_free(tp_); table_free(tu_);
+  }
+  HIPCHK(c, hipMemcpyAsync(Wd.x->P.b1, c->P.b1, (size_t)POM_NBLK1D * c->P.kb * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  refresh_coefs(Wd.x);
+  Wd.static_done = 1;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int min_jm) {
+  NEED_HOT(c);
+  wide_free(c);
+  if (!on) return POMGPU_OK;
+  pomgpu_transport &T = c->tp;
+  if (!T.on) return fail(c, POMGPU_EINVAL, "wide external mode: set a transport first");
+  const KP &P = c->P;
+  int w = c->con.isplit + 4;
+  if (getenv("POMGPU_WIDE_W")) w = atoi(getenv("POMGPU_WIDE_W"));   // developer switch: shows that fewer cells are not enough
+  if (w < 1 || min_im < w + 3 || min_jm < w + 3 || P.im < w + 3 || P.jm < w + 3) {
+    snprintf(c->err, sizeof c->err, "wide external mode: tiles of %d x %d cells are narrower than w + 3 = %d", min_im, min_jm, w + 3);
+    return POMGPU_EINVAL;                                     // not an error of the run: the per-point exchanges stay in use
+  }
+  bool any = false;
+  for (int d = 0; d < 8; d++) any = any || T.nbr[d] >= 0;
+  if (!any) return POMGPU_OK;                                 // one tile: nothing to widen
+  pomgpu_wide &Wd = c->wide;
+  Wd.w = w;
+  Wd.ox = T.nbr[0] >= 0 ? w : 0;
+  Wd.oy = T.nbr[2] >= 0 ? w : 0;
+  pomgpu_dims d;
+  d.im = P.im + Wd.ox + (T.nbr[1] >= 0 ? w : 0);
+  d.jm = P.jm + Wd.oy + (T.nbr[3] >= 0 ? w : 0);
+  d.kb = P.kb;
+  d.im_local = d.im + (d.im & 1);                             // even: the two-columns-per-lane advave kernel applies
+  d.jm_local = d.jm;
+  d.n_west = T.nbr[0]; d.n_east = T.nbr[1]; d.n_south = T.nbr[2]; d.n_north = T.nbr[3];
+  int rc = ctx_create(&Wd.x, &d, c->device, (void *)c->stream, POMGPU_CTX_2D);
+  if (rc) return fail(c, rc, "wide external mode: cannot create the %d x %d extended tile", d.im, d.jm);
+  Wd.x->parent = c;
+  // staging buffers: the per-step arrays of one neighbour block (w+1 lines of the tile's edge; corners (w+1)^2)
+  size_t need[8];
+  const size_t per = (size_t)NEL(WIDE_HALO) * (w + 1), edge = (size_t)NEL(WIDE_BD_J) * (w + 1);
+  need[0] = need[1] = per * P.jm + edge;
+  need[2] = need[3] = per * P.im + edge;
+  need[4] = need[5] = need[6] = need[7] = per * (w + 1);
+  if ((rc = pomgpu_tp_reserve(c, need))) { wide_free(c); return rc; }
+  JobList pk, up, sc;
+  wide_jobs(c, WIDE_HALO, NEL(WIDE_HALO), WIDE_LOCAL, NEL(WIDE_LOCAL), true, pk, up, Wd.scount, Wd.rcount);
+  const KP &X = Wd.x->P;
+  sc.begin();
+  for (int n = 0; n < NEL(WIDE_BACK); n++)
+    sc.add(X.b2 + (size_t)WIDE_BACK[n] * X.n2 + (size_t)Wd.oy * X.iml + Wd.ox, X.iml, P.b2 + (size_t)WIDE_BACK[n] * P.n2, P.iml, P.im, P.jm);
+  if ((rc = table_upload(c, pk, Wd.gather_pack)) || (rc = table_upload(c, up, Wd.gather_unpack)) || (rc = table_upload(c, sc, Wd.scatter))) {
+    wide_free(c);
+    return rc;
+  }
+  Wd.static_done = 0;
+  Wd.on = 1;
+  return POMGPU_OK;
+}
+// The 2-D part of one internal step on the extended tile: the rest of mode_interaction after the vertical
+// integrals (advance.f:170-199) and the isplit external substeps (advance.f:205-353, pom.f / advance.f:26-29).
+static int wide_external(pomgpu_ctx *c) {
+  pomgpu_wide &Wd = c->wide;
+  pomgpu_ctx *x = Wd.x;
+  int rc;
+  ext_canonical(c);
+  if (!Wd.static_done && (rc = wide_static(c))) return rc;
+  table_run(c, Wd.gather_pack);
+  if ((rc = pomgpu_tp_move(c, Wd.scount, Wd.rcount))) return rc;
+  table_run(c, Wd.gather_unpack);
+  x->con = c->con; x->lramp = c->lramp;
+  sync_scalars(x);
+  if (x->P.mode != 2) seq_advave(x);                          // advance.f:170 (the extended tile has no exchange: fused kernels)
+  launch_modeint_tail(x);                                     // :172-196; the exchange of utf, vtf (:198-199) is not needed
+  for (int iext = 1; iext <= c->con.isplit; iext++) {
+    c->con.iext = x->con.iext = iext;
+    if ((rc = mode_external(x, iext == c->con.isplit))) return rc;
+  }
+  ext_canonical(x);
+  table_run(c, Wd.scatter);
+  return POMGPU_OK;
+}
+
 extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) { return mode_interaction(c, 0); }
 extern "C" int pomgpu_mode_external(pomgpu_ctx *c) { return mode_external(c, 1); }
 extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
@@ -888,10 +1178,15 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;
   const int sum2d = (!c->exch && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   if ((rc = lateral_viscosity(c, sum2d))) return rc;
-  if ((rc = mode_interaction(c, sum2d))) return rc;
-  for (int iext = 1; iext <= c->con.isplit; iext++) {
-    c->con.iext = iext;
-    if ((rc = mode_external(c, 0))) return rc;
+  if (c->wide.on) {                                           // one wide exchange instead of ~180 narrow ones
+    if (c->P.mode != 2) launch_vint(c, 0);                    // advance.f:152-168
+    if ((rc = wide_external(c))) return rc;
+  } else {
+    if ((rc = mode_interaction(c, sum2d))) return rc;
+    for (int iext = 1; iext <= c->con.isplit; iext++) {
+      c->con.iext = iext;
+      if ((rc = mode_external(c, 0))) return rc;
+    }
   }
   c->con.iext = c->con.isplit + 1;
   if ((rc = pomgpu_mode_internal(c))) return rc;

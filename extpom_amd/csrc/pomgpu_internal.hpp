@@ -15,6 +15,7 @@
 #define POMGPU_NCOEF2 24   // derived 2-D coefficient arrays
 #define POMGPU_MAXREC 8
 #define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
+#define POMGPU_CTX_2D 1
 
 // Kernel parameters, passed by value with every launch.
 struct KP {
@@ -170,6 +171,36 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
 
 // ---- host side ---------------------------------------------------------------------------------
 struct ProfEntry { const char *name; long launches; double ms; };
+struct pomgpu_ctx;
+
+// Direction order of everything that talks to up to eight neighbours: W E S N SW SE NW NE.  What a tile sends
+// towards direction d arrives at the neighbour as coming from POMGPU_OPP[d].
+static const int POMGPU_OPP[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+// The library's own transport (pomgpu_set_transport / pomgpu_rccl_init): staging buffers per direction and the
+// mover -- a host callback (tests) or grouped ncclSend/ncclRecv on the kernels' stream (transport.hip).
+struct pomgpu_transport {
+  int on;
+  int nbr[8];                // neighbour ranks, -1 = none
+  void (*fn)(void *, const double *const *, const size_t *, double *const *, const size_t *);   // pomgpu_transport_fn
+  void *user;
+  void *rccl;                // RcclComm* (transport.hip), NULL with a callback transport
+  double *send[8], *recv[8];
+  size_t cap[8];             // capacity of each staging buffer, doubles
+  long rounds;               // message rounds served so far
+};
+// One rectangular block copy: ni x nj doubles from src (row stride ld_s) to dst (row stride ld_d).
+struct RectJob { const double *src; double *dst; int ld_s, ld_d, ni, nj; };
+// The wide-halo external mode (pomgpu_set_wide_external): a 2-D-only context `x` of the tile extended by `w`
+// cells towards every neighbour; index i of the tile is index i + ox of the extended tile.
+struct RectGroup { int first, count, mni, mnj; };   // jobs of similar extent share one launch
+struct RectTable { RectJob *dev; int ngroups; RectGroup g[8]; };
+struct pomgpu_wide {
+  int on, w, ox, oy;
+  pomgpu_ctx *x;
+  RectTable gather_pack, gather_unpack, scatter;   // per internal step
+  size_t scount[8], rcount[8];
+  int static_done;           // every blk2d array (grid metrics, masks ...) has been widened since the last upload
+};
 
 struct pomgpu_ctx {
   KP P;
@@ -202,6 +233,10 @@ struct pomgpu_ctx {
   ProfEntry prof[96];
   int nprof;
   void *prof_state;
+  pomgpu_transport tp;
+  pomgpu_wide wide;
+  pomgpu_ctx *parent;        // the tile's context, for the extended tile (errors and profile entries go there)
+  int flags;                 // POMGPU_CTX_2D: no 3-D arrays (the extended tile of the wide-halo external mode)
   int launch_err;            // first hipError_t a kernel launch returned (0 = none); reported by the next sync / get_con
   char err[512];
 };
@@ -339,6 +374,14 @@ int launch_halo_pack(pomgpu_ctx *c, double *const *dev, const int *nz, int count
 int launch_halo_pack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *to);
 int launch_halo_unpack8(pomgpu_ctx *c, double *const *dev, const int *nz, int count, const double *const *from);
 int launch_halo_unpack(pomgpu_ctx *c, double *const *dev, const int *nz, int count, int dir, const double *from_lo, const double *from_hi);
+void launch_rect_jobs(pomgpu_ctx *c, const RectJob *jobs_dev, int njobs, int max_ni, int max_nj);
+// transport.hip
+int pomgpu_tp_move(pomgpu_ctx *c, const size_t *scount, const size_t *rcount);   // send[d] -> neighbour d, recv[d] <- neighbour d
+int pomgpu_tp_move_ptr(pomgpu_ctx *c, const double *const *send, const size_t *scount, double *const *recv, const size_t *rcount);
+int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8);
+int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const char *librccl_path);
+void pomgpu_tp_free(pomgpu_ctx *c);
+int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need);                       // grow the staging buffers
 // k_reduce.hip
 void launch_check_velocity(pomgpu_ctx *c);
 void launch_domain_stats(pomgpu_ctx *c, double *out_dev);

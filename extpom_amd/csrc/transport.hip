@@ -1,0 +1,191 @@
+// transport.hip -- the library's own message transport under the exchange points (include/pomgpu.h,
+// "transport"): what the reference does with MPI_SEND / MPI_RECV inside exchange2d_mpi / exchange3d_mpi /
+// order2d_mpi / order3d_mpi (parallel_mpi.f:154-480) and with MPI_INIT / MPI_COMM_RANK / MPI_COMM_SIZE in
+// initialize_mpi (parallel_mpi.f:124-151).
+//
+// Production mover: RCCL.  One message round = ONE ncclGroupStart .. ncclGroupEnd with an ncclSend and an
+// ncclRecv per neighbour (up to eight), enqueued on the stream the kernels run on, so that pack kernel ->
+// messages -> unpack kernel need no event and no host synchronisation.  Between the GPUs of one node the
+// messages travel over xGMI (point-to-point links: each neighbour has its own link, a round with four
+// neighbours uses four links at once).  librccl is opened with dlopen at run time: a process that never asks
+// for the RCCL transport (one tile; tests) does not load it, and a Python host passes the path of the
+// librccl that torch already mapped so that one process never holds two copies.
+//
+// Test mover: a host callback (pomgpu_set_transport) -- ranks that share one GPU cannot talk RCCL to each
+// other (it refuses two ranks on one device), host threads driving the CPU build of the kernels have no GPU.
+#include <stdio.h>
+#include <string.h>
+#include "pomgpu.h"
+#include "pomgpu_internal.hpp"
+
+#ifndef POMGPU_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enumerators only; no symbol of librccl is linked
+
+struct RcclApi {
+  void *lib;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+struct RcclComm { ncclComm_t comm; int rank, nranks; };
+
+static int rccl_load(const char *path) {
+  if (g_rccl.lib) return 0;
+  const char *p = (path && path[0]) ? path : "librccl.so";
+  void *h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+  if (!h && !(path && path[0])) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "pomgpu: cannot open %s: %s\n", p, dlerror()); return -1; }
+  RcclApi a;
+  memset(&a, 0, sizeof a);
+  a.lib = h;
+#define SYM(field, name)                                                                  \
+  *(void **)(&a.field) = dlsym(h, name);                                                  \
+  if (!a.field) { fprintf(stderr, "pomgpu: %s lacks %s\n", p, name); dlclose(h); return -1; }
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd")
+  SYM(Send, "ncclSend")
+  SYM(Recv, "ncclRecv")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl = a;
+  return 0;
+}
+#endif
+
+void pomgpu_tp_free(pomgpu_ctx *c) {
+  pomgpu_transport &T = c->tp;
+#ifndef POMGPU_EMU
+  if (T.rccl) {
+    RcclComm *r = (RcclComm *)T.rccl;
+    if (g_rccl.lib && r->comm) (void)g_rccl.CommDestroy(r->comm);
+    delete r;
+    T.rccl = NULL;
+  }
+#endif
+  for (int d = 0; d < 8; d++) {
+    (void)hipFree(T.send[d]); (void)hipFree(T.recv[d]);
+    T.send[d] = T.recv[d] = NULL; T.cap[d] = 0;
+  }
+  T.on = 0;
+}
+
+// grow the staging buffers to at least need[d] doubles (directions without a neighbour stay empty)
+int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need) {
+  pomgpu_transport &T = c->tp;
+  for (int d = 0; d < 8; d++) {
+    if (T.nbr[d] < 0 || need[d] <= T.cap[d]) continue;
+    if (T.cap[d]) (void)hipStreamSynchronize(c->stream);      // the old buffers may still be in flight
+    (void)hipFree(T.send[d]); (void)hipFree(T.recv[d]);
+    T.send[d] = T.recv[d] = NULL; T.cap[d] = 0;
+    if (hipMalloc((void **)&T.send[d], need[d] * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&T.recv[d], need[d] * sizeof(double)) != hipSuccess)
+      return pomgpu_fail(c, POMGPU_ENOMEM, "transport: cannot allocate %zu-byte staging buffers", need[d] * sizeof(double));
+    T.cap[d] = need[d];
+  }
+  return POMGPU_OK;
+}
+
+// One message round.  send[d] / recv[d]: device buffers (any, not only the staging buffers); counts in doubles.
+int pomgpu_tp_move_ptr(pomgpu_ctx *c, const double *const *send, const size_t *scount, double *const *recv, const size_t *rcount) {
+  pomgpu_transport &T = c->tp;
+  if (!T.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport: none set");
+  T.rounds++;
+  if (T.fn) { T.fn(T.user, send, scount, recv, rcount); return POMGPU_OK; }
+#ifndef POMGPU_EMU
+  RcclComm *r = (RcclComm *)T.rccl;
+  if (!r) return pomgpu_fail(c, POMGPU_EINVAL, "transport: no mover");
+  ncclResult_t e = g_rccl.GroupStart();
+  // Messages between one pair of ranks are matched in the order they are posted.  A pair normally meets in one
+  // direction only; where a rank is its own neighbour in two directions (a periodic single-rank test) the
+  // receives must be posted in the order of the directions they were SENT towards: d ascending on the sending
+  // side is POMGPU_OPP[d] ascending in d on the receiving side.
+  for (int d = 0; d < 8 && e == ncclSuccess; d++)
+    if (T.nbr[d] >= 0 && scount[d]) e = g_rccl.Send(send[d], scount[d], ncclDouble, T.nbr[d], r->comm, c->stream);
+  for (int d = 0; d < 8 && e == ncclSuccess; d++) {
+    const int f = POMGPU_OPP[d];
+    if (T.nbr[f] >= 0 && rcount[f]) e = g_rccl.Recv(recv[f], rcount[f], ncclDouble, T.nbr[f], r->comm, c->stream);
+  }
+  const ncclResult_t e2 = g_rccl.GroupEnd();
+  if (e == ncclSuccess) e = e2;
+  if (e != ncclSuccess) return pomgpu_fail(c, POMGPU_EHIP, "transport: RCCL round failed: %s", g_rccl.GetErrorString(e));
+  return POMGPU_OK;
+#else
+  return pomgpu_fail(c, POMGPU_ENODEV, "transport: no mover in the host build");
+#endif
+}
+int pomgpu_tp_move(pomgpu_ctx *c, const size_t *scount, const size_t *rcount) {
+  return pomgpu_tp_move_ptr(c, c->tp.send, scount, c->tp.recv, rcount);
+}
+
+extern "C" int pomgpu_rccl_unique_id(void *id128, const char *librccl_path) {
+#ifndef POMGPU_EMU
+  if (!id128) return POMGPU_EINVAL;
+  if (rccl_load(librccl_path)) return POMGPU_ENODEV;
+  ncclUniqueId id;
+  const ncclResult_t e = g_rccl.GetUniqueId(&id);
+  if (e != ncclSuccess) { fprintf(stderr, "pomgpu: ncclGetUniqueId: %s\n", g_rccl.GetErrorString(e)); return POMGPU_EHIP; }
+  static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, sizeof id);
+  return POMGPU_OK;
+#else
+  (void)id128; (void)librccl_path;
+  return POMGPU_ENODEV;
+#endif
+}
+
+// common part of pomgpu_set_transport / pomgpu_rccl_init: neighbour table, staging buffers for the ordinary
+// exchange points (up to 8 arrays x kb levels of one edge line; corners one cell) and baropg_mcc's order messages
+int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8) {
+  pomgpu_transport &T = c->tp;
+  const KP &P = c->P;
+  if (!nbr8) return pomgpu_fail(c, POMGPU_EINVAL, "transport: no neighbour table");
+  if ((nbr8[0] < 0) != (P.W != 0) || (nbr8[1] < 0) != (P.E != 0) || (nbr8[2] < 0) != (P.S != 0) || (nbr8[3] < 0) != (P.N != 0))
+    return pomgpu_fail(c, POMGPU_EINVAL, "transport: W E S N neighbours disagree with the tile's pomgpu_dims");
+  for (int d = 0; d < 8; d++) T.nbr[d] = nbr8[d];
+  size_t need[8];
+  const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
+  for (int d = 0; d < 8; d++) need[d] = 8 * (size_t)P.kb * len[d];
+  const size_t ord[2] = {(size_t)(P.kb + 1) * P.jml, (size_t)(P.kb + 1) * P.iml};
+  if (need[0] < ord[0]) need[0] = ord[0];
+  if (need[1] < ord[0]) need[1] = ord[0];
+  if (need[2] < ord[1]) need[2] = ord[1];
+  if (need[3] < ord[1]) need[3] = ord[1];
+  T.on = 1;
+  T.rounds = 0;
+  return pomgpu_tp_reserve(c, need);
+}
+
+extern "C" long pomgpu_exchange_rounds(pomgpu_ctx *c) { return c ? c->tp.rounds : 0; }
+
+int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const char *librccl_path) {
+#ifndef POMGPU_EMU
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return pomgpu_fail(c, POMGPU_EINVAL, "rccl_init: bad rank / size");
+  if (rccl_load(librccl_path)) return pomgpu_fail(c, POMGPU_ENODEV, "rccl_init: librccl could not be opened");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  RcclComm *r = new RcclComm();
+  r->rank = rank; r->nranks = nranks; r->comm = NULL;
+  const ncclResult_t e = g_rccl.CommInitRank(&r->comm, nranks, id, rank);
+  if (e != ncclSuccess) {
+    delete r;
+    return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: ncclCommInitRank: %s", g_rccl.GetErrorString(e));
+  }
+  c->tp.rccl = r;
+  c->tp.fn = NULL;
+  c->tp.user = NULL;
+  return POMGPU_OK;
+#else
+  (void)id128; (void)rank; (void)nranks; (void)librccl_path;
+  return pomgpu_fail(c, POMGPU_ENODEV, "rccl_init: the host build has no RCCL");
+#endif
+}

@@ -266,3 +266,47 @@ class DeviceHalo:
         from .lib import EXCHANGE_FN
         self._cb = EXCHANGE_FN(hook)
         gpu._chk(L.pomgpu_set_exchange(gpu.h, self._cb, None), "set_exchange")
+
+
+class StagedMover:
+    """A mover for pomgpu_set_transport on hosts where RCCL cannot connect the ranks (tests: several ranks on ONE
+    GPU): the staging buffers travel through host memory over a gloo group.  Synchronises the kernels' stream on
+    every round -- test infrastructure, not the production path (that is pomgpu_rccl_init)."""
+
+    def __init__(self, gpu, tile, device, group=None):
+        self.g, self.nb, self.device, self.group = gpu, gpu.neighbours8(tile), device, group
+
+    def __call__(self, send, scount, recv, rcount):
+        from .lib import OPP  # noqa: F401
+        w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=self.device)
+        torch.cuda.current_stream().synchronize()
+        ops, staged = [], []
+        for d in range(8):
+            if self.nb[d] >= 0 and scount[d]:
+                ops.append(dist.P2POp(dist.isend, w(send[d], scount[d]).cpu(), self.nb[d], group=self.group, tag=d))
+        for d in range(8):
+            if self.nb[d] >= 0 and rcount[d]:
+                host = torch.empty(rcount[d], dtype=torch.float64)
+                staged.append((host, w(recv[d], rcount[d])))
+                ops.append(dist.P2POp(dist.irecv, host, self.nb[d], group=self.group, tag=OPP[d]))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for host, dev in staged:
+            dev.copy_(host)
+        torch.cuda.current_stream().synchronize()
+
+
+def rccl_library_path():
+    """the librccl torch has already mapped (one copy per process), else the system one"""
+    import os
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+def connect_rccl(gpu, tile, rank, world, group=None):
+    """pomgpu_rccl_init on every rank: rank 0 draws the unique id, torch.distributed (any backend) carries it"""
+    lib = rccl_library_path()
+    box = [gpu.rccl_unique_id(lib) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    gpu.rccl_init(tile, box[0], rank, world, lib)

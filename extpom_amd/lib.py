@@ -33,6 +33,13 @@ EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_vo
 ORDER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                             ctypes.c_void_p, ctypes.c_void_p)
 
+# pomgpu_transport_fn: (user, send[8], scount[8], recv[8], rcount[8]) -- device addresses, counts in doubles
+TRANSPORT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t))
+# direction order of every eight-neighbour table of the C ABI, and the direction a message arrives from
+DIRS = ("w", "e", "s", "n", "sw", "se", "nw", "ne")
+OPP = (1, 0, 3, 2, 7, 6, 5, 4)
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _SIGS = {
@@ -57,6 +64,11 @@ _SIGS = {
     "pomgpu_device_3d": (_P, [_P, _I]),
     "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
     "pomgpu_set_order_exchange": (_I, [_P, ORDER_FN, _P]),
+    "pomgpu_set_transport": (_I, [_P, ctypes.POINTER(_I), TRANSPORT_FN, _P]),
+    "pomgpu_rccl_unique_id": (_I, [_P, ctypes.c_char_p]),
+    "pomgpu_rccl_init": (_I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.c_char_p]),
+    "pomgpu_exchange_rounds": (ctypes.c_long, [_P]),
+    "pomgpu_set_wide_external": (_I, [_P, _I, _I, _I]),
     "pomgpu_halo_pack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_halo_pack8": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, ctypes.POINTER(ctypes.c_void_p)]),

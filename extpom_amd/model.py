@@ -111,6 +111,44 @@ class PomGpu:
         self._exch_cb = _lib.EXCHANGE_FN(cb)
         self._chk(self.L.pomgpu_set_exchange(self.h, self._exch_cb, None), "set_exchange")
 
+    # ---- the library's own exchange (pomgpu.h "transport") ------------------------------------
+    @staticmethod
+    def neighbours8(tile):
+        """ranks in the C ABI's direction order W E S N SW SE NW NE"""
+        return [tile.n_west, tile.n_east, tile.n_south, tile.n_north, tile.n_sw, tile.n_se, tile.n_nw, tile.n_ne]
+
+    def set_transport(self, tile, fn):
+        """callback mover (tests): fn(send, scount, recv, rcount), each a list of eight (device address, doubles)"""
+        def cb(user, send, scount, recv, rcount):
+            fn([send[d] for d in range(8)], [scount[d] for d in range(8)], [recv[d] for d in range(8)], [rcount[d] for d in range(8)])
+        self._tp_cb = _lib.TRANSPORT_FN(cb)
+        nb = (ctypes.c_int * 8)(*self.neighbours8(tile))
+        self._chk(self.L.pomgpu_set_transport(self.h, nb, self._tp_cb, None), "set_transport")
+
+    def rccl_init(self, tile, id128: bytes, rank: int, nranks: int, librccl: str | None = None):
+        """production mover: grouped ncclSend / ncclRecv on the library's stream"""
+        nb = (ctypes.c_int * 8)(*self.neighbours8(tile))
+        buf = ctypes.create_string_buffer(bytes(id128), 128)
+        self._chk(self.L.pomgpu_rccl_init(self.h, buf, rank, nranks, nb, librccl.encode() if librccl else None), "rccl_init")
+
+    def rccl_unique_id(self, librccl: str | None = None) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = self.L.pomgpu_rccl_unique_id(buf, librccl.encode() if librccl else None)
+        if rc != 0:
+            raise PomGpuError(f"pomgpu_rccl_unique_id failed with status {rc}")
+        return buf.raw
+
+    def exchange_rounds(self) -> int:
+        return int(self.L.pomgpu_exchange_rounds(self.h))
+
+    def set_wide_external(self, on: bool, min_im: int, min_jm: int) -> bool:
+        """collective; False when the tiles are too narrow (the per-point exchanges stay in use)"""
+        rc = self.L.pomgpu_set_wide_external(self.h, 1 if on else 0, int(min_im), int(min_jm))
+        if rc == -1 and on and self.L.pomgpu_last_error(self.h).decode().startswith("wide external mode: tiles"):
+            return False
+        self._chk(rc, "set_wide_external")
+        return bool(on)
+
     def domain_stats(self, sums_only=False):
         """(vtot, atot, mtot, stot, tavg, savg, eavg, ekin) of advance.f:644-756, reduced on the device"""
         out = (ctypes.c_double * 8)()

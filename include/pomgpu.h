@@ -138,6 +138,44 @@ int pomgpu_halo_unpack(pomgpu_ctx *ctx, double *const *dev, const int *nz, int c
 int pomgpu_halo_pack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, double *const *to);
 int pomgpu_halo_unpack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int count, const double *const *from);
 
+/* ---- the library's own exchange: transport (replaces the MPI layer under exchange2d/3d_mpi, order2d/3d_mpi) --
+ * With a transport the library serves every exchange point itself -- pack8, ONE message round with up to eight
+ * neighbours, unpack8, all on its stream, no host code in between -- and the hooks above are not needed.
+ * neighbours8: ranks in the order W E S N SW SE NW NE, -1 = none (W E S N must agree with pomgpu_dims).
+ *
+ * pomgpu_rccl_init: the production transport, grouped ncclSend / ncclRecv (RCCL, xGMI between the GPUs of a node)
+ * enqueued on the library's stream.  The reference side is parallel_mpi.f:124-151 (initialize_mpi: communicator,
+ * rank, size): one rank obtains `id128` (128 bytes) from pomgpu_rccl_unique_id and distributes it with whatever
+ * the host has (MPI_Bcast in the Fortran driver), then every rank calls pomgpu_rccl_init.  librccl is opened at
+ * run time (`librccl_path`, NULL = "librccl.so"), so the library has no link-time dependency on it.
+ *
+ * pomgpu_set_transport: a callback mover for hosts without RCCL between the ranks (tests: ranks sharing one GPU,
+ * host threads).  It must deliver send[d][0..scount[d]) to neighbour d -- which receives it as recv[OPP(d)] --
+ * and fill recv[d][0..rcount[d]) with what neighbour d sent towards OPP(d); buffers are device memory, the work
+ * must be ordered after what is already enqueued on pomgpu_stream() and before what follows. */
+typedef void (*pomgpu_transport_fn)(void *user, const double *const *send, const size_t *scount, double *const *recv,
+                                    const size_t *rcount);
+int pomgpu_set_transport(pomgpu_ctx *ctx, const int *neighbours8, pomgpu_transport_fn fn, void *user);
+int pomgpu_rccl_unique_id(void *id128, const char *librccl_path);
+int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, const int *neighbours8,
+                     const char *librccl_path);
+/* message rounds served by the transport since it was set (measurement) */
+long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
+
+/* Wide-halo external mode (needs a transport; affects pomgpu_advance / pomgpu_run only).  The reference exchanges
+ * 1-cell halos six times per external substep (advance.f:233,292-293,348-349; solver.f:60-61,70,111-112,121) --
+ * ~180 of the ~200 message rounds of an internal step, each a few microseconds of data.  With on != 0 the 2-D part
+ * of the step (advave and the tail of mode_interaction, all isplit substeps of mode_external) runs on a copy of
+ * the tile extended by w = isplit + 4 cells towards every neighbour: ONE wide exchange per internal step brings
+ * the neighbours' cells, the substeps run without any exchange (the band of stale cells at the rim of the extended
+ * tile grows by one cell per substep, so after isplit substeps the tile and its ghost cells are still exact),
+ * and the result is copied back -- the tile's arrays,
+ * ghost cells included, hold bit for bit what the reference's exchanges would have left there.
+ * Collective: every rank calls it with the same `on` and the smallest active extents (im, jm) over ALL tiles of
+ * the decomposition; when a tile could be narrower than w + 3 cells every rank gets POMGPU_EINVAL and the
+ * per-point exchanges stay in use. */
+int pomgpu_set_wide_external(pomgpu_ctx *ctx, int on, int min_im, int min_jm);
+
 /* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
 int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
 int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */

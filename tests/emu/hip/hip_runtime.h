@@ -30,7 +30,7 @@ extern thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 typedef int hipError_t;
 typedef struct emu_stream_ *hipStream_t;
 typedef struct emu_event_ *hipEvent_t;
-enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipStreamNonBlocking = 1 };
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipStreamNonBlocking = 1 };
 
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }

@@ -1,0 +1,72 @@
+"""Launched by tests/test_gpu_multitile.py: ONE rank, its tile its own western and eastern neighbour (periodic
+channel).  Run A moves the staging buffers with a device-to-device copy callback, run B with RCCL (communicator of
+size 1: ncclSend / ncclRecv to self inside one group, enqueued on the kernels' stream).  Both with the per-point
+exchanges and with the wide-halo external mode; all four results must be bit-identical."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dataclasses
+
+import numpy as np
+import torch
+
+from extpom_amd import decomp
+from extpom_amd.cases import make_case
+from extpom_amd.halo import _DevPtr, rccl_library_path
+from extpom_amd.layout import BLK2D, BLK3D
+from extpom_amd.lib import OPP
+from extpom_amd.model import PomGpu, gpu_finish_initial
+
+IM, JM, KB, STEPS, ISPLIT = 128, 64, 12, 3, 6
+SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
+
+
+def run(mover, wide):
+    tile = decomp.make_tile(0, IM, JM, IM, JM, n_proc=1)
+    tile = dataclasses.replace(tile, n_west=0, n_east=0)          # its own neighbour in x
+    st = make_case("island", IM, JM, KB, dte=6.0, isplit=ISPLIT)
+    gpu_finish_initial(st, device=0)
+    st.n_west = st.n_east = 0
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    g = PomGpu(st, device=0, stream=ts.cuda_stream)
+    dev = torch.device("cuda", 0)
+    if mover == "copy":
+        w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
+
+        def fn(send, scount, recv, rcount):
+            for d in range(8):
+                if tile_nb[d] >= 0 and rcount[d]:
+                    w(recv[d], rcount[d]).copy_(w(send[OPP[d]], scount[OPP[d]]))
+        tile_nb = PomGpu.neighbours8(tile)
+        g.set_transport(tile, fn)
+    else:
+        lib = rccl_library_path()
+        g.rccl_init(tile, g.rccl_unique_id(lib), 0, 1, lib)
+    if wide:
+        assert g.set_wide_external(True, IM, JM)
+    g.run(STEPS)
+    g.download()
+    n = g.exchange_rounds()
+    out = {f: st.field(f).copy() for f in BLK2D + BLK3D if f not in SCRATCH}
+    err = int(st.error_status)
+    g.close()
+    return out, n, err
+
+
+def main():
+    ref, n_ref, err = run("copy", False)
+    assert err == 0 and n_ref > 100, (err, n_ref)
+    assert np.isfinite(ref["u"]).all() and np.abs(ref["u"]).max() > 0
+    for mover, wide in (("rccl", False), ("copy", True), ("rccl", True)):
+        got, n, err = run(mover, wide)
+        bad = [f for f in ref if not np.array_equal(ref[f], got[f])]
+        assert err == 0 and not bad, (mover, wide, err, bad[:10])
+        print(f"{mover} wide={wide}: {n} message rounds (per-point, copy mover: {n_ref}), fields identical")
+    print("RCCL-SELF-OK")
+
+
+if __name__ == "__main__":
+    main()

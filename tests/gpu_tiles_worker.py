@@ -21,6 +21,8 @@ SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
 
 
 def worker(rank, world, split, port, out, nml):
+    nml = dict(nml)
+    mode = nml.pop("_exchange", "hook")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,8 +37,15 @@ def worker(rank, world, split, port, out, nml):
     ts = torch.cuda.Stream()
     torch.cuda.set_stream(ts)
     g = PomGpu(st, device=0, stream=ts.cuda_stream)
-    halo = DeviceHalo(g, tile, torch.device("cuda", 0), staged=True)
-    g.set_order_exchange(Halo(tile, staged=True).device_order_hook(torch.device("cuda", 0)))   # baropg_mcc (npg = 2)
+    if mode == "hook":
+        halo = DeviceHalo(g, tile, torch.device("cuda", 0), staged=True)
+        g.set_order_exchange(Halo(tile, staged=True).device_order_hook(torch.device("cuda", 0)))   # baropg_mcc (npg = 2)
+    else:                                        # the library serves the exchange points itself (pomgpu_set_transport)
+        from extpom_amd.halo import StagedMover
+        g.set_transport(tile, StagedMover(g, tile, torch.device("cuda", 0)))
+        if mode == "wide":
+            tiles = [decomp.make_tile(r, IM, JM, iml, jml, n_proc=world) for r in range(world)]
+            assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
 
     def dens(s, a, b, c):
         g.upload(s); g.call("dens", a, b, c); g.download(s)
@@ -56,19 +65,19 @@ def worker(rank, world, split, port, out, nml):
     dist.barrier()
     g.download()
     np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
-             n=halo.count, **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
+             n=(halo.count if mode == "hook" else g.exchange_rounds()), **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
     g.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def main(split, nml):
+def main(split, nml, exchange="hook"):
     import tempfile
     from oracle.pyoracle import OracleTile, oracle_finish_initial
     out = tempfile.mkdtemp()
     port = 29700 + (os.getpid() % 200)
     world = 4 if split == "xy" else 2
-    mp.spawn(worker, args=(world, split, port, out, nml), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, split, port, out, dict(nml, _exchange=exchange)), nprocs=world, join=True)
     g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
@@ -76,7 +85,9 @@ def main(split, nml):
     for r in range(world):
         z = np.load(os.path.join(out, f"tile{r}.npz"))
         io, jo, im, jm = int(z["i_off"]), int(z["j_off"]), int(z["im"]), int(z["jm"])
-        assert int(z["n"]) > 100
+        assert int(z["n"]) > (30 if exchange == "wide" else 100), int(z["n"])
+        if r == 0:
+            print("message rounds on rank 0:", int(z["n"]))
         sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)
         sl_i = slice(0 if io == 0 else 1, im if io + im == IM else im - 1)
         for n in BLK2D + BLK3D:
@@ -103,4 +114,5 @@ def main(split, nml):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "x", dict(npg=2) if "npg2" in sys.argv[2:] else {})
+    main(sys.argv[1] if len(sys.argv) > 1 else "x", dict(npg=2) if "npg2" in sys.argv[2:] else {},
+         "wide" if "wide" in sys.argv[2:] else ("transport" if "transport" in sys.argv[2:] else "hook"))

@@ -26,3 +26,24 @@ def test_four_tiles_with_the_4th_order_pressure_gradient():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py"), "xy", "npg2"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["xy", "transport"], ["xy", "npg2", "transport"], ["xy", "wide"], ["x", "wide"], ["y", "npg2", "wide"]])
+def test_library_exchange_and_wide_halo_external_mode(args):
+    """pomgpu_set_transport (the library packs / moves / unpacks at every exchange point; the mover here stages
+    through the host because the ranks share one GPU) and pomgpu_set_wide_external (one wide exchange per internal
+    step instead of six narrow ones per external substep): owned cells equal the single-tile oracle bit for bit"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py")] + args, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_a_periodic_single_rank():
+    """The RCCL mover itself, as far as one GPU allows: a communicator of one rank whose tile is its own western
+    and eastern neighbour (a periodic channel), so every exchange point and the wide exchange send and receive real
+    ncclSend / ncclRecv messages on the kernels' stream.  The same configuration with a device-copy callback mover
+    must give bit-identical fields."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_rccl_self.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL-SELF-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

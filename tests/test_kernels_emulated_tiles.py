@@ -104,15 +104,37 @@ def order(board, tile, send_e, n_e, send_n, n_n, recv_w, recv_s):
     board.barrier.wait()
 
 
-def run_tiles(nx, ny, nml, single_round=False):
+def transport(board, tile, send, scount, recv, rcount):
+    """the mover behind pomgpu_set_transport: what leaves towards direction d arrives at the neighbour from OPP[d]"""
+    me = tile.rank
+    nb = PomGpu.neighbours8(tile)
+    buf = lambda p, n: np.ctypeslib.as_array((ctypes.c_double * n).from_address(p))
+    for d in range(8):
+        if nb[d] >= 0 and scount[d]:
+            board.box[(me, nb[d], d)] = buf(send[d], scount[d]).copy()
+    board.barrier.wait()
+    for d in range(8):
+        if nb[d] >= 0 and rcount[d]:
+            msg = board.box[(nb[d], me, OPP8[d])]
+            assert msg.size == rcount[d], (me, d, msg.size, rcount[d])
+            buf(recv[d], rcount[d])[:] = msg
+    board.barrier.wait()
+
+
+OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
+
+
+def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None):
     world = nx * ny
-    iml, jml = decomp.local_size(IM, JM, nx, ny)
+    IMg, JMg = grid or (IM, JM)
+    iml, jml = decomp.local_size(IMg, JMg, nx, ny)
     board, out, errs = Board(world), {}, []
+    tiles = [decomp.make_tile(r, IMg, JMg, iml, jml, n_proc=world) for r in range(world)]
 
     def rank(r):
         try:
-            tile = decomp.make_tile(r, IM, JM, iml, jml, n_proc=world)
-            st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10, **nml)
+            tile = tiles[r]
+            st = make_case(case, IMg, JMg, KB, tile=tile, dte=6.0, isplit=isplit, **nml)
             g = PomGpu(st, libpath=EMU)
             count = [0]
 
@@ -123,8 +145,13 @@ def run_tiles(nx, ny, nml, single_round=False):
                 else:
                     exchange(board, tile, [view(p, nz, tile) for p, nz in zip(ptrs, nzs)])
 
-            g.set_exchange(hook)
-            g.set_order_exchange(lambda *a: order(board, tile, *a))
+            if library_exchange:                     # the library packs, moves and unpacks by itself
+                g.set_transport(tile, lambda *a: transport(board, tile, *a))
+                if wide:
+                    assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
+            else:
+                g.set_exchange(hook)
+                g.set_order_exchange(lambda *a: order(board, tile, *a))
 
             def dens(s, a, b, c):
                 g.upload(s); g.call("dens", a, b, c); g.download(s)
@@ -134,9 +161,9 @@ def run_tiles(nx, ny, nml, single_round=False):
 
             finish_initial(st, dens, baropg)
             g.upload(st)
-            g.run(STEPS)
+            g.run(steps or STEPS)
             g.download()
-            out[r] = (tile, st, count[0])
+            out[r] = (tile, st, g.exchange_rounds() if library_exchange else count[0])
         except Exception as e:                      # a dead rank must not leave the others at the barrier
             errs.append(e)
             board.barrier.abort()
@@ -156,15 +183,22 @@ def run_tiles(nx, ny, nml, single_round=False):
 def test_tiles_match_single_tile_oracle(nx, ny, nml, single_round):
     """single_round: the library's one-round exchange with eight neighbours instead of the reference's two phases"""
     out = run_tiles(nx, ny, nml, single_round)
-    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
+    compare_with_single_tile(out, nml)
+
+
+def compare_with_single_tile(out, nml, grid=None, isplit=10, case="island", steps=None, min_rounds=100, ghosts=False):
+    IMg, JMg = grid or (IM, JM)
+    g = make_case(case, IMg, JMg, KB, dte=6.0, isplit=isplit, **nml)
     oracle_finish_initial(g)
-    OracleTile(g).run(STEPS)
+    OracleTile(g).run(steps or STEPS)
     bad = []
     for r, (tile, st, count) in out.items():
-        assert count > 100
+        assert count > min_rounds, count
         io, jo, im, jm = tile.i_off, tile.j_off, tile.im, tile.jm
-        sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)       # the cells the tile owns
-        sl_i = slice(0 if io == 0 else 1, im if io + im == IM else im - 1)
+        sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JMg else jm - 1)       # the cells the tile owns
+        sl_i = slice(0 if io == 0 else 1, im if io + im == IMg else im - 1)
+        if ghosts:
+            sl_i = sl_j = slice(None)
         for n in BLK2D + BLK3D:
             if n in SCRATCH:
                 continue
@@ -173,3 +207,43 @@ def test_tiles_match_single_tile_oracle(nx, ny, nml, single_round):
             if not np.array_equal(ref, got):
                 bad.append((r, n))
     assert not bad, bad
+    return {r: v[2] for r, v in out.items()}
+
+
+@pytest.mark.parametrize("nx,ny,nml", [(2, 2, {}), (3, 2, dict(npg=2)), (1, 2, dict(nadv=1))])
+def test_library_transport_serves_every_exchange_point(nx, ny, nml):
+    """pomgpu_set_transport: pack8 / message round / unpack8 inside the library, baropg_mcc's order messages too"""
+    out = run_tiles(nx, ny, nml, library_exchange=True)
+    compare_with_single_tile(out, nml)
+
+
+WIDE_GRID, WIDE_ISPLIT = (67, 59), 7        # w = 7 + 4 = 11 extra cells; 2x2 tiles of ~35 x 31
+
+
+@pytest.mark.parametrize("nx,ny,case,nml", [(2, 2, "island", {}), (2, 1, "seamount", {}), (1, 2, "seamount", dict(npg=2)), (3, 2, "island", dict(nadv=1))])
+def test_wide_halo_external_mode(nx, ny, case, nml):
+    """pomgpu_set_wide_external: ONE wide exchange per internal step instead of six narrow ones per external substep;
+    owned cells equal the single-tile oracle bit for bit, with a fraction of the message rounds"""
+    if nx == 3:
+        grid = (97, 59)
+    else:
+        grid = WIDE_GRID
+    narrow = run_tiles(nx, ny, nml, library_exchange=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
+    n_narrow = compare_with_single_tile(narrow, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=50)
+    wide = run_tiles(nx, ny, nml, library_exchange=True, wide=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
+    n_wide = compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=10)
+    assert n_wide[0] < n_narrow[0] - 6 * WIDE_ISPLIT * STEPS + 3 * STEPS + 8, (n_wide, n_narrow)
+    # ghost cells too: the tile's arrays are what the per-point exchanges leave there
+    for r in wide:
+        for n in ("ua", "va", "el", "elb", "d", "uab", "vab", "etf", "egf", "utf", "vtf", "adx2d", "ady2d", "advua", "advva", "elf", "uaf", "vaf"):
+            t = wide[r][0]
+            assert np.array_equal(wide[r][1].field(n)[:t.jm, :t.im], narrow[r][1].field(n)[:t.jm, :t.im]), (r, n)
+
+
+def test_wide_halo_too_narrow_shows_up(monkeypatch):
+    """the stale rim of the extended tile grows by one cell per substep: with fewer than isplit - 1 extra cells it
+    reaches owned cells and the comparison with the single-tile oracle must fail"""
+    monkeypatch.setenv("POMGPU_WIDE_W", str(WIDE_ISPLIT - 2))
+    out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT)
+    with pytest.raises(AssertionError):
+        compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10)
