@@ -314,6 +314,66 @@ __device__ double advct_xg_mem(const KP &P, int i, int j, int k) {              
   xg = xg - dtaam * ((F3(ub, i, j, k) - F3(ub, i, j - 1, k)) / dy4 + (F3(vb, i, j, k) - F3(vb, i - 1, j, k)) / K2(DX4, i, j));
   return .25 * dy4 * xg;
 }
+__device__ double advct_yf_mem(const KP &P, int i, int j, int k) {                 // x-eq. yflux at corner (i,j), 2<=i<=imm1, 2<=j
+  double yf = .125 * (K2(DTSY, i, j) * F3(v, i, j, k) + K2(DTSY, i - 1, j) * F3(v, i - 1, j, k)) * (F3(u, i, j, k) + F3(u, i, j - 1, k));
+  const double dtaam = .25 * K2(DT4, i, j) * (F3(aam, i, j, k) + F3(aam, i - 1, j, k) + F3(aam, i, j - 1, k) + F3(aam, i - 1, j - 1, k));
+  const double dx4 = K2(DX4, i, j);
+  yf = yf - dtaam * ((F3(ub, i, j, k) - F3(ub, i, j - 1, k)) / K2(DY4, i, j) + (F3(vb, i, j, k) - F3(vb, i - 1, j, k)) / dx4);
+  return .25 * dx4 * yf;
+}
+__device__ double advct_yg_mem(const KP &P, int i, int j, int k) {                 // y-eq. yflux at the centre of (i,j), 2<=i, 2<=j<=jmm1
+  double yg = .125 * (K2(DTSY, i, j + 1) * F3(v, i, j + 1, k) + K2(DTSY, i, j) * F3(v, i, j, k)) * (F3(v, i, j + 1, k) + F3(v, i, j, k));
+  yg = yg - F2(dt, i, j) * F3(aam, i, j, k) * 2. * (F3(vb, i, j + 1, k) - F3(vb, i, j, k)) / F2(dy, i, j);
+  return F2(dx, i, j) * yg;
+}
+// advct on tiles without exchanging whole intermediate arrays.  What a tile cannot form itself is little: advx(2,j)
+// needs xflux(1,j) and curv(1,j) (solver.f:284-301), advy(i,2) needs the y-equation's yflux(i,1) and curv(i,1)
+// (:374-391) -- in the reference they arrive with the exchanges of curv, xflux, yflux (:229, :279, :369).  Here the
+// neighbour evaluates just those lines (k_advct_edge: its column imm1 / row jmm1, the same formulas on the same
+// operands) and sends them east / north in one small message; k_advct_col then runs as on a single tile and
+// k_advct_fix redoes advx(2,:) and advy(:,2) with the received values.  Message layout: curv, then the flux,
+// each kbm1 x jm (east) or kbm1 x im (north), level-major.
+__global__ void k_advct_edge(KP P, double *to_e, double *to_n) {
+  const int t = TID_I, k = (int)blockIdx.y + 1;
+  if (k > P.kbm1) return;
+  if (to_e && t <= P.jm) {
+    const size_t o = (size_t)(k - 1) * P.jm + (size_t)(t - 1);
+    to_e[o] = advct_curv_mem(P, P.imm1, t, k);
+    to_e[(size_t)P.kbm1 * P.jm + o] = t >= 2 ? advct_xf_mem(P, P.imm1, t, k) : 0.;
+  }
+  if (to_n && t <= P.im) {
+    const size_t o = (size_t)(k - 1) * P.im + (size_t)(t - 1);
+    to_n[o] = advct_curv_mem(P, t, P.jmm1, k);
+    to_n[(size_t)P.kbm1 * P.im + o] = t >= 2 ? advct_yg_mem(P, t, P.jmm1, k) : 0.;
+  }
+}
+__global__ void k_advct_fix(KP P, const double *from_w, const double *from_s) {
+  const int t = TID_I, k = (int)blockIdx.y + 1;
+  if (k > P.kbm1) return;
+  if (from_w && t >= 2 && t <= P.jmm1) {                     // advx(2,j,k), j = t
+    const int j = t;
+    const size_t o = (size_t)(k - 1) * P.jm + (size_t)(j - 1);
+    const double cv_w = from_w[o], xf_w = from_w[(size_t)P.kbm1 * P.jm + o];
+    const double xf = advct_xf_mem(P, 2, j, k), yf_n = advct_yf_mem(P, 2, j + 1, k), yf_c = advct_yf_mem(P, 2, j, k);
+    const double cv = advct_curv_mem(P, 2, j, k);
+    const double ctx = cv * F2(dt, 2, j) * (F3(v, 2, j + 1, k) + F3(v, 2, j, k));
+    const double ctx_w = cv_w * F2(dt, 1, j) * (F3(v, 1, j + 1, k) + F3(v, 1, j, k));
+    double ax = xf - xf_w + yf_n - yf_c;                                                         // :284-288
+    ax = ax - F2(aru, 2, j) * .25 * (ctx + ctx_w);                                               // :291-301
+    F3(advx, 2, j, k) = ax;
+  }
+  if (from_s && t >= 2 && t <= P.imm1) {                     // advy(i,2,k), i = t
+    const int i = t;
+    const size_t o = (size_t)(k - 1) * P.im + (size_t)(i - 1);
+    const double cv_s = from_s[o], yg_s = from_s[(size_t)P.kbm1 * P.im + o];
+    const double xg_e = advct_xg_mem(P, i + 1, 2, k), xg = advct_xg_mem(P, i, 2, k), yg_c = advct_yg_mem(P, i, 2, k);
+    const double cv = advct_curv_mem(P, i, 2, k);
+    double ay = xg_e - xg + yg_c - yg_s;                                                         // :374-378
+    ay = ay + F2(arv, i, 2) * .25 * (cv * F2(dt, i, 2) * (F3(u, i + 1, 2, k) + F3(u, i, 2, k)) +
+                                     cv_s * F2(dt, i, 1) * (F3(u, i + 1, 1, k) + F3(u, i, 1, k)));     // :381-391
+    F3(advy, i, 2, k) = ay;
+  }
+}
 // sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
 __global__ void __launch_bounds__(64 * COL_ROWS) k_advct_col(KP P, int sum2d) {
   HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
@@ -514,6 +574,16 @@ void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *
 }
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
   LAUNCH(c, k_advct_col, grid1_halo(c->P), blk_col(), c->P, sum2d);
+}
+void launch_advct_edge(pomgpu_ctx *c, double *to_e, double *to_n) {
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_advct_edge, dim3((len + 63) / 64, P.kbm1, 1), dim3(64, 1, 1), c->P, to_e, to_n);
+}
+void launch_advct_fix(pomgpu_ctx *c, const double *from_w, const double *from_s) {
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_advct_fix, dim3((len + 63) / 64, P.kbm1, 1), dim3(64, 1, 1), c->P, from_w, from_s);
 }
 void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk_col(), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {

@@ -495,9 +495,21 @@ static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
     launch_advave_m2b(c);
   }
 }
-static void seq_advct(pomgpu_ctx *c, int sum2d = 0) {         // solver.f:201-408
+static void seq_advct(pomgpu_ctx *c, int sum2d = 0, int defer_xch = 0) {   // solver.f:201-408
   KP &P = c->P;
   if (!c->exch) { launch_advct_col(c, sum2d); return; }       // one tile: nothing to exchange, fluxes stay in registers
+  if (c->tp.on && !getenv("POMGPU_ADVCT_SPLIT")) {            // tiles, the library's own exchange: see k_advct_edge
+    pomgpu_transport &T = c->tp;
+    const size_t ne = 2 * (size_t)P.kbm1 * P.jm, nn = 2 * (size_t)P.kbm1 * P.im;
+    launch_advct_edge(c, T.nbr[1] >= 0 ? T.send[1] : NULL, T.nbr[3] >= 0 ? T.send[3] : NULL);
+    const size_t sc[8] = {0, T.nbr[1] >= 0 ? ne : 0, 0, T.nbr[3] >= 0 ? nn : 0, 0, 0, 0, 0};
+    const size_t rc[8] = {T.nbr[0] >= 0 ? ne : 0, 0, T.nbr[2] >= 0 ? nn : 0, 0, 0, 0, 0, 0};
+    if (pomgpu_tp_move(c, sc, rc)) return;
+    launch_advct_col(c, 0);
+    launch_advct_fix(c, T.nbr[0] >= 0 ? T.recv[0] : NULL, T.nbr[2] >= 0 ? T.recv[2] : NULL);
+    if (!defer_xch) xch(c, 2, D3(c, advx), P.kb, D3(c, advy), P.kb);   // :315, :405
+    return;
+  }
   launch_advct_a(c);
   xch(c, 2, P.s3[0], P.kbm1, P.s3[1], P.kbm1);                // :229, :279
   launch_advct_b(c);
@@ -526,10 +538,11 @@ static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair,
   xch(c, 2, xf, P.kbm1, yf, P.kbm1);                          // :458-459
   launch_advq_step(c, q, qb, qf, xf, yf, zero_else);
 }
-static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0) {   // solver.f:1212-1538
+static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   // solver.f:1212-1538
   KP &P = c->P;
   launch_profq_bc(c);
-  xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
+  if (with_w) xch(c, 3, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
+  else xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
   if (!c->exch) { launch_profq(c, 1, fuse_filter); return; }  // one tile: prod is formed inside the solve kernel
   launch_profq_prod(c);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
@@ -631,7 +644,8 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-14
   NEED_HOT(c);
   KP &P = c->P;
   if (P.mode != 2) {
-    seq_advct(c, sum2d);
+    const bool lib_x = c->tp.on && c->exch && !getenv("POMGPU_ADVCT_SPLIT");
+    seq_advct(c, sum2d, lib_x);                               // lib_x: advx, advy travel with aam below
     if (P.npg == 1) seq_baropg(c, sum2d);
     else if (P.npg == 2) seq_baropg_mcc(c, sum2d);
     else {                                                    // advance.f:117-120
@@ -639,7 +653,8 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-14
       c->con.error_status = 1;
     }
     launch_aam(c);
-    xch(c, 1, D3(c, aam), P.kbm1);                            // :137
+    if (lib_x) xch(c, 3, D3(c, advx), P.kb, D3(c, advy), P.kb, D3(c, aam), P.kbm1);   // solver.f:315,405 + :137 in one round
+    else xch(c, 1, D3(c, aam), P.kbm1);                       // :137
   }
   return POMGPU_OK;
 }
@@ -960,10 +975,17 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
   if ((k.iint != 1 || k.time0 != 0.) && k.mode != 2) {
     launch_int_uvmean(c);                                     // :365-393
     launch_vertvl(c, 1);                                      // :396-398
-    xch(c, 1, D3(c, w), P.kb);                                // :400
+    // :400 exchange3d_mpi(w): nothing reads w's ghost cells before advt / advu (advq takes w at the cell's own
+    // column only), so on tiles it travels with profq's bottom-boundary exchange below -- one round less
+    const bool lib_x = c->tp.on && c->exch;                   // the library's own exchange: rounds may be merged
+    if (!lib_x) xch(c, 1, D3(c, w), P.kb);
     // :403-409 (uf = vf = 0 is folded into the advq step kernels)
     launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
-    if (!c->exch) {                                           // one tile: flux and step halves fuse (no exchange between them)
+    // advq's exchange of xflux, yflux (solver.f:458-459) hands a tile the neighbour's xflux(2,j) as its
+    // xflux(im,j): the same formula on the same operands the tile holds in its own ghost cells (q, qb, u, dt, aam
+    // have all been exchanged), i.e. the value it computes itself.  The fused flux+step kernel therefore serves
+    // tiles as well, without that exchange.  (pomgpu_advq, the stand-alone entry point, keeps the reference's form.)
+    if (!c->exch || !getenv("POMGPU_ADVQ_EXCHANGE")) {
       if (getenv("POMGPU_ADVQ_SINGLE")) {
         launch_advq_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), 1);
         launch_advq_col(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);
@@ -979,7 +1001,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       launch_advq_step(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), x1, y1, 1);
     }
     const int qfuse = !getenv("POMGPU_QFILTER_SPLIT");
-    seq_profq(c, qfuse);                                      // with the interior's Asselin filter (:416-421) on its way up
+    seq_profq(c, qfuse, lib_x);                               // with the interior's Asselin filter (:416-421) on its way up
     xch(c, 2, D3(c, uf) + P.n2, P.kbm2, D3(c, vf) + P.n2, P.kbm2);   // :411-412
     launch_bcond6_edges(c);                                   // :414
     if (qfuse) launch_q_filter_rim(c);                        // :416-421, edge lines
@@ -992,9 +1014,11 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         if (P.nitera == 1 && !getenv("POMGPU_ADVT2_SINGLE")) {   // T and S in one pass
           launch_coef_eta(c);
           launch_advt2x2_col(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
-          xch(c, 1, D3(c, uf), P.kbm1);                         // solver.f:728 (T)
+          // solver.f:728 exchanges T, then S; advance.f:436-437 below exchanges both again with nothing written
+          // in between: the library's own exchange serves the three points in that one round
+          if (!lib_x) xch(c, 1, D3(c, uf), P.kbm1);             // solver.f:728 (T)
           launch_copy_kb(c, D3(c, tb));                         // :618
-          xch(c, 1, D3(c, vf), P.kbm1);                         // :728 (S)
+          if (!lib_x) xch(c, 1, D3(c, vf), P.kbm1);             // :728 (S)
           launch_copy_kb(c, D3(c, sb));
         } else {
           seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), true);
@@ -1020,9 +1044,10 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       launch_advu_profu(c, 1, 1);                             // :459-462
       launch_advv_profv(c, 1, 1);
     }
-    xch(c, 2, D2(c, wubot), 1, D2(c, wvbot), 1);              // solver.f:1777, :1874
-    launch_bcondorl3(c);                                      // :464
-    xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);          // :466-467
+    if (!lib_x) xch(c, 2, D2(c, wubot), 1, D2(c, wvbot), 1);  // solver.f:1777, :1874
+    launch_bcondorl3(c);                                      // :464 (does not read wubot, wvbot)
+    if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
+    else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);     // :466-467
     launch_uv_filter(c);                                      // :469-514
     xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
   }

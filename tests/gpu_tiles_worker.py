@@ -85,7 +85,7 @@ def main(split, nml, exchange="hook"):
     for r in range(world):
         z = np.load(os.path.join(out, f"tile{r}.npz"))
         io, jo, im, jm = int(z["i_off"]), int(z["j_off"]), int(z["im"]), int(z["jm"])
-        assert int(z["n"]) > (30 if exchange == "wide" else 100), int(z["n"])
+        assert int(z["n"]) > (15 if exchange == "wide" else 100), int(z["n"])
         if r == 0:
             print("message rounds on rank 0:", int(z["n"]))
         sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Developer measurement (not the bench contract): ONE tile of an N-tile decomposition of a bench workload on one
+GPU, through the multi-tile code path (split kernels, library exchange, wide-halo external mode) with a mover that
+copies the tile's own staging buffers back to it (a periodic stand-in for the neighbours: the arithmetic is not
+the real run's, the kernels, launches and message rounds are).  Prints per-kernel device time and the wall time per
+step, i.e. what a rank of the N-GPU run spends outside the xGMI transfers.
+
+    python tools/tile_probe.py --tiles 8 --rank 5 [--workload basin2048] [--steps 5] [--no-wide]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=5)
+    ap.add_argument("--workload", default="basin2048")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--no-wide", action="store_true")
+    a = ap.parse_args()
+    import torch
+    import bench
+    from extpom_amd import dist as pdist
+    from extpom_amd.halo import _DevPtr
+    from extpom_amd.lib import OPP
+    from extpom_amd.model import PomGpu
+    case, im, jm, kb, desc = bench.WORKLOADS[a.workload]
+    tile = pdist.tile_for_rank(a.rank, a.tiles, im, jm)
+    st = bench.build_state(a.workload, tile)
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    g = bench.gpu_initialise(st, 0, ts.cuda_stream)
+    dev = torch.device("cuda", 0)
+    nb = PomGpu.neighbours8(tile)
+    w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
+
+    def mover(send, scount, recv, rcount):
+        for d in range(8):
+            o = OPP[d]
+            if nb[d] >= 0 and rcount[d]:
+                if nb[o] >= 0 and scount[o] == rcount[d]:
+                    w(recv[d], rcount[d]).copy_(w(send[o], scount[o]))
+                elif scount[d] == rcount[d]:
+                    w(recv[d], rcount[d]).copy_(w(send[d], scount[d]))
+                else:                                   # one-way message without a matching buffer of the tile's own
+                    w(recv[d], rcount[d]).zero_()
+
+    g.set_transport(tile, mover)
+    wide = False
+    if not a.no_wide:
+        tiles = [pdist.tile_for_rank(r, a.tiles, im, jm) for r in range(a.tiles)]
+        wide = g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
+    g.run(2)
+    g.sync()
+    g.prof_begin()
+    g.run(1)
+    prof = g.prof_end()
+    r0 = g.exchange_rounds()
+    t0 = time.perf_counter()
+    g.run(a.steps)
+    g.sync()
+    dt = (time.perf_counter() - t0) / a.steps
+    rounds = (g.exchange_rounds() - r0) / a.steps
+    share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
+    print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
+                      "wide": bool(wide), "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
+                      "kernel_ms_sum": round(sum(v[2] for v in share), 3),
+                      "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
