@@ -173,12 +173,11 @@ def main():
             g.set_transport(tile, H.StagedMover(g, tile, dev))
             exchange = "library exchange, host-staged mover (rehearsal)"
         else:
-            try:
-                H.connect_rccl(g, tile, rank, world)
+            if H.connect_rccl(g, tile, rank, world):
                 exchange = "library exchange, native RCCL send/recv on the kernels' stream"
-            except Exception as e:       # e.g. librccl cannot be opened: torch.distributed's RCCL P2P carries the same messages
-                print(f"bench[{rank}]: native RCCL transport unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
-                H.DeviceHalo(g, tile, dev)
+            else:       # e.g. librccl cannot be opened: torch.distributed's RCCL P2P carries the same messages
+                print(f"bench[{rank}]: native RCCL transport unavailable; using torch.distributed P2P", file=sys.stderr)
+                bench_halo = H.DeviceHalo(g, tile, dev)
                 g.set_order_exchange(H.Halo(tile).device_order_hook(dev))   # npg = 2 only
                 exchange = "torch.distributed batch_isend_irecv (RCCL) per exchange point"
         if exchange.startswith("library") and os.environ.get("POM_BENCH_WIDE", "1") != "0":

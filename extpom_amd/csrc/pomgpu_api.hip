@@ -733,14 +733,19 @@ static int tp_install(pomgpu_ctx *c, const int *nbr8) {
   return POMGPU_OK;
 }
 extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_transport_fn fn, void *user) {
-  NEED_RAW(c);
-  if (!fn) return fail(c, POMGPU_EINVAL, "set_transport: no mover");
+  NEED_HOT(c);
+  wide_free(c);
   pomgpu_tp_free(c);
+  if (!fn) {                                                  // no mover: back to the hooks / a single tile
+    c->exch = NULL; c->order = NULL;
+    return POMGPU_OK;
+  }
   c->tp.fn = fn; c->tp.user = user;
   return tp_install(c, nbr8);
 }
 extern "C" int pomgpu_rccl_init(pomgpu_ctx *c, const void *id128, int rank, int nranks, const int *nbr8, const char *librccl_path) {
-  NEED_RAW(c);
+  NEED_HOT(c);
+  wide_free(c);
   pomgpu_tp_free(c);
   int rc = pomgpu_tp_rccl(c, id128, rank, nranks, librccl_path);
   if (rc) return rc;

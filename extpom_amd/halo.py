@@ -304,9 +304,28 @@ def rccl_library_path():
     return p if os.path.exists(p) else None
 
 
-def connect_rccl(gpu, tile, rank, world, group=None):
-    """pomgpu_rccl_init on every rank: rank 0 draws the unique id, torch.distributed (any backend) carries it"""
+def connect_rccl(gpu, tile, rank, world, group=None) -> bool:
+    """pomgpu_rccl_init on every rank: rank 0 draws the unique id, torch.distributed (any backend) carries it.
+    Collective and all-or-nothing: returns False on EVERY rank if any rank could not open librccl or join the
+    communicator (the caller then installs another exchange), so that no rank waits for one that gave up."""
     lib = rccl_library_path()
-    box = [gpu.rccl_unique_id(lib) if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = gpu.rccl_unique_id(lib)
+        except Exception as e:               # noqa: BLE001 -- reported, then every rank falls back together
+            print(f"connect_rccl: {e}", flush=True)
     dist.broadcast_object_list(box, src=0, group=group)
-    gpu.rccl_init(tile, box[0], rank, world, lib)
+    ok = box[0] is not None
+    if ok:
+        try:
+            gpu.rccl_init(tile, box[0], rank, world, lib)
+        except Exception as e:               # noqa: BLE001
+            print(f"connect_rccl[{rank}]: {e}", flush=True)
+            ok = False
+    oks = [None] * world
+    dist.all_gather_object(oks, ok, group=group)
+    if not all(oks):
+        gpu.clear_transport()
+        return False
+    return True

@@ -131,6 +131,10 @@ class PomGpu:
         buf = ctypes.create_string_buffer(bytes(id128), 128)
         self._chk(self.L.pomgpu_rccl_init(self.h, buf, rank, nranks, nb, librccl.encode() if librccl else None), "rccl_init")
 
+    def clear_transport(self):
+        """back to a single tile's behaviour (or to the hooks installed afterwards)"""
+        self._chk(self.L.pomgpu_set_transport(self.h, None, _lib.TRANSPORT_FN(), None), "clear_transport")
+
     def rccl_unique_id(self, librccl: str | None = None) -> bytes:
         buf = ctypes.create_string_buffer(128)
         rc = self.L.pomgpu_rccl_unique_id(buf, librccl.encode() if librccl else None)

@@ -152,7 +152,8 @@ int pomgpu_halo_unpack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int 
  * pomgpu_set_transport: a callback mover for hosts without RCCL between the ranks (tests: ranks sharing one GPU,
  * host threads).  It must deliver send[d][0..scount[d]) to neighbour d -- which receives it as recv[OPP(d)] --
  * and fill recv[d][0..rcount[d]) with what neighbour d sent towards OPP(d); buffers are device memory, the work
- * must be ordered after what is already enqueued on pomgpu_stream() and before what follows. */
+ * must be ordered after what is already enqueued on pomgpu_stream() and before what follows.  fn == NULL removes
+ * the transport (and the wide-halo external mode with it). */
 typedef void (*pomgpu_transport_fn)(void *user, const double *const *send, const size_t *scount, double *const *recv,
                                     const size_t *rcount);
 int pomgpu_set_transport(pomgpu_ctx *ctx, const int *neighbours8, pomgpu_transport_fn fn, void *user);
