@@ -229,6 +229,14 @@ __device__ __forceinline__ double profq_cc(const KP &P, int i, int j, int k) {
   cc = cc / sqrt((1. - .01642 * p / cc) * (1. - 0.40 * p / sq(cc)));
   return cc;
 }
+__device__ __forceinline__ double profq_cc_v(const KP &P, double t, double s_, double hij, int k) {   // profq_cc on loaded operands
+  const double tp = t + P.tbias;
+  const double sp = s_ + P.sbias;
+  const double p = P.grav * P.rhoref * (-F1(zz, k) * hij) * 1.e-4;
+  double cc = 1449.1 + .00821 * p + 4.55 * tp - .045 * sq(tp) + 1.34 * (sp - 35.0);
+  cc = cc / sqrt((1. - .01642 * p / cc) * (1. - 0.40 * p / sq(cc)));
+  return cc;
+}
 __device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, double ccm, double cck) {   // :1327-1330
   return P.grav * (F3(rho, i, j, k - 1) - F3(rho, i, j, k)) / (F1(dzz, k - 1) * h_(i, j)) +
          sq(P.grav) * 2. / (sq(ccm) + sq(cck));
@@ -275,7 +283,12 @@ __global__ void k_profq_prod(KP P) {
 // memory there (only their level-kb left-overs do, see k_q_filter); the two outermost lines of columns
 // keep the plain path (bcond(6), which also reads their old q2/q2l, and on several tiles the exchange
 // come between the solve and their filter).
-__global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
+// operands of one level of the forward walk, requested one level ahead
+struct LevQ { double t, s, rho, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn; };
+// __launch_bounds__: without it the compiler plans for 1024-thread workgroups, caps the kernel at 128 VGPRs and
+// spills 22 of them (11.2 ms per launch at 2048x1536x50; 10.3 with the bound, 9.95 with the operands of level
+// k+1 requested during level k: 215 VGPRs, two waves per SIMD)
+__global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_filter) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
@@ -314,23 +327,45 @@ __global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
   const bool ffil = fuse_filter && (i >= 3 && i <= P.imm1 - 1 && j >= 3 && j <= P.jmm1 - 1);
   const int ie = i < P.iml ? i + 1 : i, jn = j < P.jml ? j + 1 : j;
   double ucm = 0., uem = 0., vcm = 0., vnm = 0.;                   // u(i), u(i+1), v(j), v(j+1) of level k-1
+  // every operand of level k is requested while level k-1 is being worked on: the walk is a chain of dependent
+  // divides and square roots per level, and a level's ~14 loads issued only when it starts leave the memory
+  // pipeline idle for most of it
+  const double hij = h_(i, j);
+  auto lev = [&](int k) {
+    LevQ L;
+    const bool m = (k >= 2 && k <= kbm1);
+    L.t = L.s = L.rho = L.q2lb = L.uf = L.vf = L.uc = L.ue = L.vc = L.vn = L.km = L.kh = L.q2 = 0.;
+    if (k <= kbm1) { L.t = F3(t, i, j, k); L.s = F3(s, i, j, k); L.rho = F3(rho, i, j, k); }
+    L.q2b = F3(q2b, i, j, k);
+    if (pin && k <= kbm1) { L.uc = u_(i, j, k); L.ue = u_(ie, j, k); L.vc = v_(i, j, k); L.vn = v_(i, jn, k); }
+    if (m) {
+      L.q2lb = F3(q2lb, i, j, k);
+      L.uf = F3(uf, i, j, k);
+      if (k >= 3 && k != kbm1) L.vf = F3(vf, i, j, k);
+    }
+    if (!repl || (pin && m)) { L.km = F3(km, i, j, k); L.kh = F3(kh, i, j, k); }
+    if (!repl || k == 2) L.q2 = F3(q2, i, j, k);
+    return L;
+  };
+  LevQ cur = lev(1), nxt = cur;
   for (int k = 1; k <= kb; k++) {
     const bool mid = (k >= 2 && k <= kbm1);
+    if (k + 1 <= kb) nxt = lev(k + 1);
     // ---- level-local quantities
     double cck = 0., rhok = 0.;
-    if (k <= kbm1) { cck = profq_cc(P, i, j, k); rhok = F3(rho, i, j, k); }
-    double q2b = F3(q2b, i, j, k);
+    if (k <= kbm1) { cck = profq_cc_v(P, cur.t, cur.s, hij, k); rhok = cur.rho; }
+    double q2b = cur.q2b;
     double l, gh = 0.;
     double uck = 0., uek = 0., vck = 0., vnk = 0., bg = 0.;
-    if (pin && k <= kbm1) { uck = u_(i, j, k); uek = u_(ie, j, k); vck = v_(i, j, k); vnk = v_(i, jn, k); }
+    if (pin && k <= kbm1) { uck = cur.uc; uek = cur.ue; vck = cur.vc; vnk = cur.vn; }
     if (mid) {
       q2b = fabs(q2b);                                                                      // :1325-1326
-      const double q2lb = fabs(F3(q2lb, i, j, k));
+      const double q2lb = fabs(cur.q2lb);
       if (!ffil) {                                           // with the fused filter q2b, q2lb are rewritten on the way up
         F3(q2b, i, j, k) = q2b;
         F3(q2lb, i, j, k) = q2lb;
       }
-      bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * h_(i, j)) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
+      bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * hij) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
       l = fabs(q2lb / q2b);                                                                 // :1338-1344
       if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
       gh = fmin(sq(l) * bg / q2b, .028);
@@ -351,22 +386,22 @@ __global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
         pr = G3(prod, i, j, k);
       } else if (pin) {                                                                     // :1359-1373, as k_profq_prod
         const double sef = 1., shiw = 0.;
-        const double km = F3(km, i, j, k);
+        const double km = cur.km;
         pr = km * .25 * sef * (sq(uck - ucm + uek - uem) + sq(vck - vcm + vnk - vnm)) / sq(F1(dzz, k - 1) * dh) - shiw * km * bg;
-        pr = pr + F3(kh, i, j, k) * bg;
+        pr = pr + cur.kh * bg;
       } else {
         pr = 0.;
       }
       const double g = 1. / (a + c * (1. - e1p) - (2. * P.dti2 * dtef1 + 1.));
       e1p = a * g;
-      g1p = (-2. * P.dti2 * pr + c * g1p - F3(uf, i, j, k)) * g;
+      g1p = (-2. * P.dti2 * pr + c * g1p - cur.uf) * g;
       ee1[k - 1] = e1p;
       gg1[k - 1] = g1p;
       if (k == 2) {
         e2p = 0.;
-        g2p = -P.kappa * F1(z, 2) * dh * F3(q2, i, j, 2);
+        g2p = -P.kappa * F1(z, 2) * dh * cur.q2;
       } else {
-        const double rhs = (k == kbm1) ? vbot : F3(vf, i, j, k);
+        const double rhs = (k == kbm1) ? vbot : cur.vf;
         const double g2 = 1. / (a + c * (1. - e2p) - (P.dti2 * dtef2 + 1.));
         e2p = a * g2;
         g2p = (P.dti2 * (-pr * l * e1) + c * g2p - rhs) * g2;
@@ -379,10 +414,10 @@ __global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
       const double sh = coef1 / (1. - coef2 * gh);
       double sm = coef3 + sh * coef4 * gh;
       sm = sm / (1. - coef5 * gh);
-      const double pl = l * sqrt(fabs(F3(q2, i, j, k)));
+      const double pl = l * sqrt(fabs(cur.q2));
       const double kq = (pl * .41 * sh + kqc) * .5;
-      const double km = (pl * sm + F3(km, i, j, k)) * .5;
-      const double kh = (pl * sh + F3(kh, i, j, k)) * .5;
+      const double km = (pl * sm + cur.km) * .5;
+      const double kh = (pl * sh + cur.kh) * .5;
       // own cell: in place (old kq lives on in kqm/kqc/kqp).  Physical-edge cells that copy this
       // column are written to the staging arrays s3[1..3] (their own threads still read the old
       // kq) and moved by k_profq_rim.
@@ -405,6 +440,7 @@ __global__ void k_profq(KP P, int fuse_prod, int fuse_filter) {
     ucm = uck; uem = uek; vcm = vck; vnm = vnk;
     kqm = kqc; kqc = kqp;
     if (k + 2 <= kb) kqp = F3(kq, i, j, k + 2);
+    cur = nxt;
   }
   // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468
   if (!ffil) {
