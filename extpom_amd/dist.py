@@ -26,5 +26,8 @@ def init(backend: str | None = None):
 
 def tile_for_rank(rank: int, world: int, im_global: int, jm_global: int):
     nx, ny = choose_tile_grid(world, im_global, jm_global)
+    if os.environ.get("POM_TILE_GRID"):          # developer switch: "2x4" forces nproc_x x nproc_y
+        nx, ny = (int(v) for v in os.environ["POM_TILE_GRID"].lower().split("x"))
+        assert nx * ny == world
     iml, jml = local_size(im_global, jm_global, nx, ny)
     return make_tile(rank, im_global, jm_global, iml, jml, n_proc=world)

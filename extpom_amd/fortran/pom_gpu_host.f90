@@ -25,6 +25,39 @@ subroutine pomgpu_host_init(device)
   end if
 end subroutine
 
+! Multi-GPU: what initialize_mpi / distribute_mpi set up for MPI (parallel_mpi.f:124-151, :34-122) is handed to the
+! library once: the RCCL communicator (id128 = the 128 bytes rank 0 got from pomgpu_rccl_unique_id and the caller
+! broadcast with MPI_Bcast over pom_comm) and the eight neighbour ranks.  From then on every exchange point of the hot
+! path is served inside the library (pack, one grouped ncclSend/ncclRecv round, unpack, on its stream), and the 2-D
+! external mode runs on a wide-halo copy of the tile (one exchange per internal step) when the tiles are wide enough.
+subroutine pomgpu_host_connect(id128)
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  character(kind=c_char) :: id128(128)
+  integer(c_int) :: nb(8), rc
+  integer :: px, py, npx, npy, min_im, min_jm
+  npx = (im_global - 2 + im_local - 3) / (im_local - 2)        ! tiles in x, y (parallel_mpi.f:54-65)
+  npy = (jm_global - 2 + jm_local - 3) / (jm_local - 2)
+  px = mod(my_task, npx); py = my_task / npx
+  nb(1) = n_west; nb(2) = n_east; nb(3) = n_south; nb(4) = n_north
+  nb(5) = -1; nb(6) = -1; nb(7) = -1; nb(8) = -1                ! SW SE NW NE: the tiles across the corners
+  if (px > 0 .and. py > 0) nb(5) = my_task - 1 - npx
+  if (px < npx - 1 .and. py > 0) nb(6) = my_task + 1 - npx
+  if (px > 0 .and. py < npy - 1) nb(7) = my_task - 1 + npx
+  if (px < npx - 1 .and. py < npy - 1) nb(8) = my_task + 1 + npx
+  rc = pomgpu_rccl_init(pom_ctx, id128, int(my_task, c_int), int(npx * npy, c_int), nb, c_null_ptr)
+  if (rc /= 0) then
+    error_status = 1
+    write(6,'(/''Error: pomgpu_rccl_init failed'')')
+    return
+  end if
+  ! the east-/north-most tiles are the trimmed ones (parallel_mpi.f:83-87, :98-102)
+  min_im = min(im_local, im_global - (npx - 1) * (im_local - 2))
+  min_jm = min(jm_local, jm_global - (npy - 1) * (jm_local - 2))
+  rc = pomgpu_set_wide_external(pom_ctx, 1_c_int, int(min_im, c_int), int(min_jm, c_int))   ! EINVAL = tiles too narrow: per-point exchanges stay
+end subroutine
+
 subroutine pomgpu_upload_state
   use pomgpu_iface
   implicit none

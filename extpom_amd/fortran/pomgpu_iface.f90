@@ -38,6 +38,20 @@ module pomgpu_iface
     integer(c_int) function pomgpu_set_restore_record(ctx, n, tr, sr) bind(C, name='pomgpu_set_restore_record')
       import; type(c_ptr), value :: ctx, tr, sr; integer(c_int), value :: n
     end function
+    ! the library's own exchange over RCCL (include/pomgpu.h "transport") and the wide-halo external mode
+    integer(c_int) function pomgpu_rccl_unique_id(id128, librccl_path) bind(C, name='pomgpu_rccl_unique_id')
+      import; character(kind=c_char) :: id128(128); type(c_ptr), value :: librccl_path
+    end function
+    integer(c_int) function pomgpu_rccl_init(ctx, id128, rank, nranks, neighbours8, librccl_path) bind(C, name='pomgpu_rccl_init')
+      import; type(c_ptr), value :: ctx, librccl_path; character(kind=c_char) :: id128(128)
+      integer(c_int), value :: rank, nranks; integer(c_int) :: neighbours8(8)
+    end function
+    integer(c_int) function pomgpu_set_wide_external(ctx, on, min_im, min_jm) bind(C, name='pomgpu_set_wide_external')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: on, min_im, min_jm
+    end function
+    integer(c_long) function pomgpu_exchange_rounds(ctx) bind(C, name='pomgpu_exchange_rounds')
+      import; type(c_ptr), value :: ctx
+    end function
     integer(c_int) function pomgpu_sync(ctx) bind(C, name='pomgpu_sync')
       import; type(c_ptr), value :: ctx
     end function
