@@ -105,8 +105,8 @@ def gpu_initialise(st, device, stream):
     return g
 
 
-def cpu_baseline(workload):
-    """oracle on one host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid"""
+def _cpu_sample(workload, seconds=12.0):
+    """oracle on ONE host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid"""
     from extpom_amd.cases import make_case
     from oracle.pyoracle import OracleTile, oracle_finish_initial
     case, im, jm, kb, _ = WORKLOADS[workload]
@@ -117,12 +117,39 @@ def cpu_baseline(workload):
     ot.run(2)
     t0 = time.perf_counter()
     n = 0
-    while n < 4 or (time.perf_counter() - t0 < 12.0 and n < 400):
+    while n < 4 or (time.perf_counter() - t0 < seconds and n < 400):
         ot.run(1)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": sim * sjm * kb * n / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{case} {sim}x{sjm}x{kb}, {n} internal steps of the plain-C oracle (gcc -O2, bit-identical to the flang-built reference), {dt:.1f} s"}
+    return sim * sjm * kb * n / dt, f"{case} {sim}x{sjm}x{kb}", n, dt
+
+
+def cpu_baseline(workload):
+    v, what, n, dt = _cpu_sample(workload)
+    return {"value": v, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{what}, {n} internal steps of the plain-C oracle (gcc -O2, bit-identical to the flang-built reference), {dt:.1f} s"}
+
+
+def cpu_baseline_all_cores(workload):
+    """the same sample on every host core at once (one independent copy per core, as the reference's MPI ranks
+    would each hold a tile): the host's aggregate rate, memory-bandwidth contention included.  The copies are plain
+    child processes of this script (`--cpu-sample`), each bounded by a timeout."""
+    import subprocess
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))        # a 1-GPU box's CPU share
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-sample", "--workload", workload],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=180)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:                                          # noqa: BLE001 -- a lost copy only lowers the sum
+            p.kill()
+    if not res:
+        return None
+    return {"value": sum(r["value"] for r in res), "unit": "cell-updates/s", "cores": len(res), "kind": "port",
+            "sample": f"{len(res)} concurrent copies of {res[0]['what']} (one process per core), "
+                      f"{min(r['n'] for r in res)}-{max(r['n'] for r in res)} internal steps each"}
 
 
 def main():
@@ -132,8 +159,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("POM_BENCH_WORKLOAD", "basin2048"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle sample and print it (no GPU)")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
     args = ap.parse_args()
+    if args.cpu_sample:
+        v, what, n, dt = _cpu_sample(args.workload)
+        print(json.dumps({"value": v, "what": what, "n": n, "seconds": dt}))
+        return
 
     import torch
     from extpom_amd import decomp, dist as pdist
@@ -265,6 +297,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload)
         print(json.dumps(out))
     g.close()
     if world > 1:
