@@ -242,9 +242,13 @@ __device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, 
          sq(P.grav) * 2. / (sq(ccm) + sq(cck));
 }
 // (2) shear + buoyancy production (exchanged before the solves) -- :1359-1373   scratch: s3[0]=prod
-__global__ void k_profq_prod(KP P) {
+// lines_only (tiles, the library's own exchange): just the two outermost lines of columns on every side -- the
+// owned columns form their production term inside k_profq (fuse_prod = 2), and the exchange at :1374 needs the
+// lines it sends (columns 2 / imm1, rows 2 / jmm1) and zeros on the rim where no neighbour will write
+__global__ void k_profq_prod(KP P, int lines_only) {
   COL2
   if (i > P.im || j > P.jm) return;
+  if (lines_only && i > 2 && i < P.imm1 && j > 2 && j < P.jmm1) return;
   double *prod = P.s3[0];
   G3(prod, i, j, 1) = 0.;
   G3(prod, i, j, P.kb) = 0.;
@@ -322,6 +326,8 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
   // fuse_prod (one tile, nothing to exchange at :1374): the shear + buoyancy production of k_profq_prod
   // is formed here from the same sound speed / density / km / kh this walk reads anyway, instead of
   // being written by a kernel of its own and read back
+  // fuse_prod = 2 (tiles): the same for the columns 2..imm1 x 2..jmm1; the rim columns -- ghost cells of a
+  // neighbour's owned column, or a physical edge -- take the exchanged value (or the zero) from s3[0]
   const bool pin = fuse_prod && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
   // not the two outermost lines: bcond(6) reads the OLD q2, q2l of columns 2 / imm1 / jmm1 (bounds_forcing.f:262-318)
   const bool ffil = fuse_filter && (i >= 3 && i <= P.imm1 - 1 && j >= 3 && j <= P.jmm1 - 1);
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
       const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);      // :1261-1264
       const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
       double pr;
-      if (!fuse_prod) {
+      if (!fuse_prod || (fuse_prod == 2 && !pin)) {
         pr = G3(prod, i, j, k);
       } else if (pin) {                                                                     // :1359-1373, as k_profq_prod
         const double sef = 1., shiw = 0.;
@@ -1094,7 +1100,7 @@ void launch_int_uvmean(pomgpu_ctx *c) {
 }
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
-void launch_profq_prod(pomgpu_ctx *c) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); }
+void launch_profq_prod(pomgpu_ctx *c, int lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P, lines_only); }
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter) {
   LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod, fuse_filter);
   const KP &P = c->P;

@@ -544,9 +544,10 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
   if (with_w) xch(c, 3, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
   else xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
   if (!c->exch) { launch_profq(c, 1, fuse_filter); return; }  // one tile: prod is formed inside the solve kernel
-  launch_profq_prod(c);
+  const int lines = c->tp.on && !getenv("POMGPU_PROD_FULL");  // tiles: only the lines the exchange moves, see k_profq_prod
+  launch_profq_prod(c, lines);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
-  launch_profq(c, 0, fuse_filter);
+  launch_profq(c, lines ? 2 : 0, fuse_filter);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
   launch_copy_kb(c, fb);                                      // solver.f:496 / :618

@@ -247,3 +247,24 @@ def test_wide_halo_too_narrow_shows_up(monkeypatch):
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT)
     with pytest.raises(AssertionError):
         compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10)
+
+
+@pytest.mark.parametrize("nx,ny,case,nml", [(3, 2, "seamount", {}), (2, 2, "island", dict(npg=2))])
+def test_library_paths_leave_the_same_ghost_cells_as_the_reference_exchanges(nx, ny, case, nml):
+    """The tile shortcuts of the library's own exchange (advct through edge lines, advq without its redundant flux
+    exchange, profq's production term exchanged on the rim lines only, merged rounds, wide-halo external mode) against
+    the hook path that keeps every exchange point of the reference: EVERY cell of every COMMON array, ghost cells
+    included, must be identical -- what a download, an output file or a restart sees does not depend on the path."""
+    grid = (97, 59)
+    hooks = run_tiles(nx, ny, nml, grid=grid, isplit=WIDE_ISPLIT, case=case)
+    for wide in (False, True):
+        lib = run_tiles(nx, ny, nml, library_exchange=True, wide=wide, grid=grid, isplit=WIDE_ISPLIT, case=case)
+        bad = []
+        for r in hooks:
+            t = hooks[r][0]
+            for n in BLK2D + BLK3D:
+                if n in SCRATCH:
+                    continue
+                if not np.array_equal(hooks[r][1].field(n)[..., :t.jm, :t.im], lib[r][1].field(n)[..., :t.jm, :t.im]):
+                    bad.append((r, n))
+        assert not bad, (wide, bad[:10])
