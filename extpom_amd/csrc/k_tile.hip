@@ -575,6 +575,28 @@ void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
   LAUNCH(c, k_advct_col, grid1_halo(c->P), blk_col(), c->P, sum2d);
 }
+// with sum2d the column kernel has left adx2d, ady2d (advance.f:152-168) from its own advx(2,:), advy(:,2): redo the
+// two lines from the corrected values, in the column kernel's order of summation
+__global__ void k_advct_fix2d(KP P, int west, int south) {
+  const int t = TID_I;
+  if (west && t >= 2 && t <= P.jmm1) {
+    double a = 0.;
+#pragma unroll 8
+    for (int k = 1; k <= P.kbm1; k++) a = a + F3(advx, 2, t, k) * F1(dz, k);
+    F2(adx2d, 2, t) = a;
+  }
+  if (south && t >= 2 && t <= P.imm1) {
+    double a = 0.;
+#pragma unroll 8
+    for (int k = 1; k <= P.kbm1; k++) a = a + F3(advy, t, 2, k) * F1(dz, k);
+    F2(ady2d, t, 2) = a;
+  }
+}
+void launch_advct_fix2d(pomgpu_ctx *c, int west, int south) {
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_advct_fix2d, dim3((len + 63) / 64, 1, 1), dim3(64, 1, 1), c->P, west, south);
+}
 void launch_advct_edge(pomgpu_ctx *c, double *to_e, double *to_n) {
   const KP &P = c->P;
   const int len = P.im > P.jm ? P.im : P.jm;

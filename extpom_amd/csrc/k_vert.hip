@@ -242,13 +242,9 @@ __device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, 
          sq(P.grav) * 2. / (sq(ccm) + sq(cck));
 }
 // (2) shear + buoyancy production (exchanged before the solves) -- :1359-1373   scratch: s3[0]=prod
-// lines_only (tiles, the library's own exchange): just the two outermost lines of columns on every side -- the
-// owned columns form their production term inside k_profq (fuse_prod = 2), and the exchange at :1374 needs the
-// lines it sends (columns 2 / imm1, rows 2 / jmm1) and zeros on the rim where no neighbour will write
-__global__ void k_profq_prod(KP P, int lines_only) {
+__global__ void k_profq_prod(KP P) {
   COL2
   if (i > P.im || j > P.jm) return;
-  if (lines_only && i > 2 && i < P.imm1 && j > 2 && j < P.jmm1) return;
   double *prod = P.s3[0];
   G3(prod, i, j, 1) = 0.;
   G3(prod, i, j, P.kb) = 0.;
@@ -273,6 +269,32 @@ __global__ void k_profq_prod(KP P, int lines_only) {
     G3(prod, i, j, k) = p;
     ccm = cck;
   }
+}
+// (2') tiles, the library's own exchange: the owned columns form their production term inside k_profq
+// (fuse_prod = 2); the exchange at :1374 only needs the lines it sends (columns 2 / imm1, rows 2 / jmm1) and zeros
+// on the rim where no neighbour will write.  One thread per (cell of a line, level): a column walk here would be
+// eight lines of threads each waiting out 50 levels of dependent loads.
+__global__ void k_profq_prod_lines(KP P) {
+  const int t = TID_I, line = (int)blockIdx.y, k = (int)blockIdx.z + 1;        // lines: i = 1, 2, imm1, im, then j = 1, 2, jmm1, jm
+  int i, j;
+  if (line < 4) { if (t > P.jm) return; j = t; i = line == 0 ? 1 : (line == 1 ? 2 : (line == 2 ? P.imm1 : P.im)); }
+  else { if (t > P.im) return; i = t; j = line == 4 ? 1 : (line == 5 ? 2 : (line == 6 ? P.jmm1 : P.jm)); }
+  double *prod = P.s3[0];
+  double p = 0.;
+  if (k >= 2 && k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
+    const double dh = h_(i, j) + F2(etf, i, j);
+    const double sef = 1., shiw = 0.;
+    const double ccm = profq_cc(P, i, j, k - 1), cck = profq_cc(P, i, j, k);
+    const double bg = profq_boygr(P, i, j, k, ccm, cck);
+    const double km = F3(km, i, j, k);
+    p = km * .25 * sef *
+            (sq(u_(i, j, k) - u_(i, j, k - 1) + u_(i + 1, j, k) - u_(i + 1, j, k - 1)) +
+             sq(v_(i, j, k) - v_(i, j, k - 1) + v_(i, j + 1, k) - v_(i, j + 1, k - 1))) /
+            sq(F1(dzz, k - 1) * dh) -
+        shiw * km * bg;
+    p = p + F3(kh, i, j, k) * bg;
+  }
+  G3(prod, i, j, k) = p;
 }
 // (3) everything else: length scale, stability, two Thomas solves, new km/kh/kq.
 //     ONE forward walk over the column does everything that is local to a level -- |q2b|, |q2lb|,
@@ -1100,7 +1122,12 @@ void launch_int_uvmean(pomgpu_ctx *c) {
 }
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
-void launch_profq_prod(pomgpu_ctx *c, int lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P, lines_only); }
+void launch_profq_prod(pomgpu_ctx *c, int lines_only) {
+  if (!lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); return; }
+  const KP &P = c->P;
+  const int len = P.im > P.jm ? P.im : P.jm;
+  LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P);
+}
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter) {
   LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod, fuse_filter);
   const KP &P = c->P;

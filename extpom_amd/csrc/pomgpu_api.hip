@@ -505,8 +505,9 @@ static void seq_advct(pomgpu_ctx *c, int sum2d = 0, int defer_xch = 0) {   // so
     const size_t sc[8] = {0, T.nbr[1] >= 0 ? ne : 0, 0, T.nbr[3] >= 0 ? nn : 0, 0, 0, 0, 0};
     const size_t rc[8] = {T.nbr[0] >= 0 ? ne : 0, 0, T.nbr[2] >= 0 ? nn : 0, 0, 0, 0, 0, 0};
     if (pomgpu_tp_move(c, sc, rc)) return;
-    launch_advct_col(c, 0);
+    launch_advct_col(c, sum2d);
     launch_advct_fix(c, T.nbr[0] >= 0 ? T.recv[0] : NULL, T.nbr[2] >= 0 ? T.recv[2] : NULL);
+    if (sum2d) launch_advct_fix2d(c, T.nbr[0] >= 0, T.nbr[2] >= 0);
     if (!defer_xch) xch(c, 2, D3(c, advx), P.kb, D3(c, advy), P.kb);   // :315, :405
     return;
   }
@@ -1207,10 +1208,13 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   // advance.f:14-18: file-driven in the reference; here they run once the host has supplied records
   if (c->frc_on && (rc = pomgpu_surface_forcing(c))) return rc;
   if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;
-  const int sum2d = (!c->exch && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
+  // the vertical integrals of advx, advy, drhox, drhoy come out of advct / baropg themselves: on one tile, and on
+  // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
+  const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
+  const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   if ((rc = lateral_viscosity(c, sum2d))) return rc;
   if (c->wide.on) {                                           // one wide exchange instead of ~180 narrow ones
-    if (c->P.mode != 2) launch_vint(c, 0);                    // advance.f:152-168
+    if (c->P.mode != 2) launch_vint(c, sum2d);                // advance.f:152-168
     if ((rc = wide_external(c))) return rc;
   } else {
     if ((rc = mode_interaction(c, sum2d))) return rc;

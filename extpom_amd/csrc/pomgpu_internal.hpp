@@ -300,6 +300,7 @@ void launch_advave_fused(pomgpu_ctx *c);
 void launch_advct_col(pomgpu_ctx *c, int sum2d);
 void launch_advct_edge(pomgpu_ctx *c, double *to_e, double *to_n);
 void launch_advct_fix(pomgpu_ctx *c, const double *from_w, const double *from_s);
+void launch_advct_fix2d(pomgpu_ctx *c, int west, int south);
 void launch_advt2x2_col(pomgpu_ctx *c, const double *tb, const double *t, const double *tc, double *tf, const double *sb, const double *s_,
                         const double *sc, double *sf);
 void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *ql, const double *qlb, double *qlf, int zero_else);
