@@ -494,6 +494,24 @@ __global__ void k_ext_update(KP P) {
                   (acc && j >= 2) ? F2(elf, i, j - 1) : 0.);
 }
 
+// the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells
+__device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f) {
+  const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
+  int i, j;
+  if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
+  else {
+    const int q = t - 3 * im;
+    if (ncol <= 0 || q >= 3 * ncol) return;
+    const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
+  }
+  const double ec = elf_at(P, i, j), ew = i >= 2 ? elf_at(P, i - 1, j) : 0., es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
+  double u, v;
+  uvaf_cell(P, i, j, 1, ec, ew, es, u, v);
+  u = u * F2(dum, i, j);
+  v = v * F2(dvm, i, j);
+  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
+  ext_update_cell(P, i, j, true, ec, u, v, ew, es);
+}
 // ---------------------------------------------------------------------------------------------
 // mode_external, single tile: ONE kernel per substep.  With nothing to exchange between the
 // continuity, momentum and filter phases (advance.f:233, :292-293) the three kernels above fuse: elf
@@ -506,8 +524,16 @@ __global__ void k_ext_update(KP P) {
 // Register-operand form: every array row is loaded once per cell (50 loads instead of ~95 through the
 // cell functions above), the (i-1) / (i+1) operands, the two x-fluxes of the east neighbour and the
 // west neighbour's new elevation come from the neighbour lane (halo-lane wavefronts).
-__global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f) {
-  const int lane = HALO_LANE, i0 = HALO_COL, j = TID_J;
+// rim_rows > 0: the first rim_rows block-rows of the grid do the rim cells (ext_rim_cell) instead of a launch of
+// their own -- a few thousand threads on a long chain of dependent loads, ~15 us whatever the grid size, 30 times
+// per internal step; as the FIRST workgroups of this launch they run beside the interior ones.  They read the
+// same generation of ua, va, d, el, elb and write other cells.
+__global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) {
+  if ((int)blockIdx.y < rim_rows) {
+    ext_rim_cell(P, (int)((blockIdx.y * blockDim.y + threadIdx.y) * (gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x), store_f);
+    return;
+  }
+  const int lane = HALO_LANE, i0 = HALO_COL, j = (int)((blockIdx.y - rim_rows) * blockDim.y + threadIdx.y + 1);
   if (j < 3 || j > P.jmm1) return;                         // a whole wavefront (one row)
   const bool out = (lane >= 1 && lane <= 62 && i0 >= 3 && i0 <= P.imm1);
 #ifdef POMGPU_EMU
@@ -583,22 +609,7 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f) {
   }
 }
 __global__ void k_ext_step_rim(KP P, int store_f) {
-  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
-  int i, j;
-  if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
-  else {
-    const int q = t - 3 * im;
-    if (ncol <= 0 || q >= 3 * ncol) return;
-    const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
-  }
-  const double ec = elf_at(P, i, j), ew = i >= 2 ? elf_at(P, i - 1, j) : 0., es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
-  double u, v;
-  uvaf_cell(P, i, j, 1, ec, ew, es, u, v);
-  u = u * F2(dum, i, j);
-  v = v * F2(dvm, i, j);
-  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
-  ext_update_cell(P, i, j, true, ec, u, v, ew, es);
+  ext_rim_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f);
 }
 
 // mode_internal tail: rotate the 2-D time levels -- advance.f:525-531 (whole arrays)
@@ -657,9 +668,16 @@ void launch_ext_uvaf(pomgpu_ctx *c, int interior) { LAUNCH(c, k_ext_uvaf, grid2(
 void launch_ext_update(pomgpu_ctx *c) { LAUNCH(c, k_ext_update, grid2(c->P), blk2(), c->P); }
 // Q: c->P with y2 pointing at the next-generation buffers
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f) {
-  LAUNCH(c, k_ext_step, grid2_halo(Q), blk2(), Q, store_f);
   const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
-  LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
+  dim3 g = grid2_halo(Q);
+  if (getenv("POMGPU_EXT_RIM_KERNEL")) {                      // developer switch: the rim as a launch of its own
+    LAUNCH(c, k_ext_step, g, blk2(), Q, store_f, 0);
+    LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
+    return;
+  }
+  const int per_row = (int)g.x * 256, rim_rows = (n + per_row - 1) / per_row;
+  g.y += rim_rows;
+  LAUNCH(c, k_ext_step, g, blk2(), Q, store_f, rim_rows);
 }
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy2, grid2(c->P), blk2(), c->P, dst, src); }
 void launch_int_tail(pomgpu_ctx *c) { LAUNCH(c, k_int_tail, grid2(c->P), blk2(), c->P); }
