@@ -257,7 +257,9 @@ def main():
         ms = dt / args.steps * 1e3
         value = cells * args.steps / dt
         nl, tms = timed.get(dom, (0, 0.0))
-        passes = KERNEL_PASSES.get(dom + "/tiles" if world > 1 and dom + "/tiles" in KERNEL_PASSES else dom)
+        # on tiles served by the library's own exchange k_profq forms the production term itself, as on one tile
+        split = world > 1 and not exchange.startswith("library") and dom + "/tiles" in KERNEL_PASSES
+        passes = KERNEL_PASSES.get(dom + "/tiles" if split else dom)
         roof = None
         if nl and passes:
             ach = passes * 8.0 * tile_cells / (tms / nl * 1e-3) / 1e9
