@@ -105,23 +105,72 @@ def gpu_initialise(st, device, stream):
     return g
 
 
-def _cpu_sample(workload, seconds=12.0):
-    """oracle on ONE host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid"""
+def _sample_dims(workload):
+    case, im, jm, kb, _ = WORKLOADS[workload]
+    return case, max(65, im // 8), max(49, jm // 8), kb
+
+
+def _cpu_sample(workload, seconds=12.0, reference=False):
+    """ONE host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid.  reference=False: the
+    plain-C oracle; True: the flang-built UNMODIFIED reference (oracle/_ref, built where /root/reference exists and
+    shipped prebuilt), driven subroutine by subroutine in the order of its own `advance` (oracle/refharness.py)."""
     from extpom_amd.cases import make_case
     from oracle.pyoracle import OracleTile, oracle_finish_initial
-    case, im, jm, kb, _ = WORKLOADS[workload]
-    sim, sjm = max(65, im // 8), max(49, jm // 8)
+    case, sim, sjm, kb = _sample_dims(workload)
     st = make_case(case, sim, sjm, kb, **NML)
     oracle_finish_initial(st)
-    ot = OracleTile(st)
-    ot.run(2)
+    if reference:
+        from oracle.refharness import RefLib
+        lib = RefLib(sim, sjm, kb)
+        lib.put(st)
+        it = [0]
+
+        def step():
+            it[0] += 1
+            lib.con["iint"][0] = it[0]
+            lib.advance()
+    else:
+        ot = OracleTile(st)
+        step = lambda: ot.run(1)
+    step(); step()
     t0 = time.perf_counter()
     n = 0
     while n < 4 or (time.perf_counter() - t0 < seconds and n < 400):
-        ot.run(1)
+        step()
         n += 1
     dt = time.perf_counter() - t0
     return sim * sjm * kb * n / dt, f"{case} {sim}x{sjm}x{kb}", n, dt
+
+
+def _reference_sample(workload):
+    """child-process body of cpu_reference: the reference keeps its work arrays on the stack (automatic arrays: 11 x
+    (im,jm,kb) doubles in profq alone, solver.f:1224-1230), so it runs in a thread with a stack to match"""
+    import threading
+    box = {}
+
+    def work():
+        box["r"] = _cpu_sample(workload, reference=True)
+    threading.stack_size(1 << 30)
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    return box["r"]
+
+
+def cpu_reference(workload):
+    """the reference itself on one core, if its build for the sample's size travelled with the repo; in a child
+    process, so that nothing it does can take the bench down"""
+    import subprocess
+    from oracle.refharness import have_ref
+    case, sim, sjm, kb = _sample_dims(workload)
+    if not have_ref(sim, sjm, kb):
+        return None
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sample", "--reference", "--workload", workload],
+                       capture_output=True, text=True, timeout=240)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+            "sample": f"{d['what']}, {d['n']} internal steps of the unmodified reference (solver.f advance.f bounds_forcing.f, "
+                      f"AMD flang -O2), {d['seconds']:.1f} s"}
 
 
 def cpu_baseline(workload):
@@ -159,11 +208,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("POM_BENCH_WORKLOAD", "basin2048"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference", action="store_true", help="internal: with --cpu-sample, time oracle/_ref instead of the oracle")
     ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle sample and print it (no GPU)")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
     args = ap.parse_args()
     if args.cpu_sample:
-        v, what, n, dt = _cpu_sample(args.workload)
+        v, what, n, dt = _reference_sample(args.workload) if args.reference else _cpu_sample(args.workload)
         print(json.dumps({"value": v, "what": what, "n": n, "seconds": dt}))
         return
 
@@ -298,7 +348,15 @@ def main():
             "error_status": err,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            port = cpu_baseline(args.workload)
+            ref = None
+            try:
+                ref = cpu_reference(args.workload)
+            except Exception as e:                                 # noqa: BLE001 -- e.g. the MPI runtime the reference links is absent
+                print(f"bench: reference CPU baseline unavailable ({e})", file=sys.stderr)
+            out["cpu_baseline"] = ref or port                       # the reference itself where its build is present
+            if ref:
+                out["cpu_baseline_port"] = port
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload)
         print(json.dumps(out))
     g.close()
