@@ -627,7 +627,8 @@ static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.
 }
 
 #define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
-#define NEED_HOT(c) NEED_RAW(c); ext_canonical(c)            /* the entry points pomgpu_advance strings together */
+static void wide_flush(pomgpu_ctx *c);
+#define NEED_HOT(c) NEED_RAW(c); ext_canonical(c); wide_flush(c)   /* the entry points pomgpu_advance strings together */
 #define NEED(c) NEED_HOT(c); restore_materialize(c)
 
 extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
@@ -661,8 +662,13 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-14
   return POMGPU_OK;
 }
 extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) { return lateral_viscosity(c, 0); }
+static int wide_begin(pomgpu_ctx *c);
 static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-202
   NEED_HOT(c);
+  if (c->wide.on) {                                           // one wide exchange instead of ~180 narrow ones
+    if (c->P.mode != 2) launch_vint(c, sums_done);            // :152-168
+    return wide_begin(c);                                     // :170-199 on the extended tile
+  }
   if (c->P.mode != 2) {
     launch_vint(c, sums_done);
     seq_advave(c);
@@ -675,6 +681,14 @@ static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-2
 // pomgpu_advance stores them on the last substep only -- nothing reads them in between
 static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-353
   NEED_RAW(c);
+  if (c->wide.on && c->wide.pending) {                        // the substep runs on the extended tile (wide_begin)
+    pomgpu_ctx *x = c->wide.x;
+    x->con.iext = c->con.iext;
+    const int last = c->con.iext == c->con.isplit;
+    const int rc = mode_external(x, store_f || last);
+    if (last) wide_flush(c);                                  // the tile's arrays, ghost cells included, are current again
+    return rc;
+  }
   KP &P = c->P;
   P.iext = c->con.iext;
   if (!c->exch && !getenv("POMGPU_EXT_SPLIT")) {              // one tile: one kernel per substep, two buffer generations
@@ -949,13 +963,14 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
   Wd.on = 1;
   return POMGPU_OK;
 }
-// The 2-D part of one internal step on the extended tile: the rest of mode_interaction after the vertical
-// integrals (advance.f:170-199) and the isplit external substeps (advance.f:205-353, pom.f / advance.f:26-29).
-static int wide_external(pomgpu_ctx *c) {
+// The 2-D part of one internal step on the extended tile.  wide_begin: the rest of mode_interaction after the
+// vertical integrals (advance.f:170-199); the isplit calls of mode_external then work on the extended tile
+// (mode_external above); wide_end after the last one copies the result back.  Any other entry point that finds
+// the 2-D state still out there fetches it first (wide_flush in NEED_HOT).
+static int wide_begin(pomgpu_ctx *c) {
   pomgpu_wide &Wd = c->wide;
   pomgpu_ctx *x = Wd.x;
   int rc;
-  ext_canonical(c);
   if (!Wd.static_done && (rc = wide_static(c))) return rc;
   table_run(c, Wd.gather_pack);
   if ((rc = pomgpu_tp_move(c, Wd.scount, Wd.rcount))) return rc;
@@ -964,13 +979,15 @@ static int wide_external(pomgpu_ctx *c) {
   sync_scalars(x);
   if (x->P.mode != 2) seq_advave(x);                          // advance.f:170 (the extended tile has no exchange: fused kernels)
   launch_modeint_tail(x);                                     // :172-196; the exchange of utf, vtf (:198-199) is not needed
-  for (int iext = 1; iext <= c->con.isplit; iext++) {
-    c->con.iext = x->con.iext = iext;
-    if ((rc = mode_external(x, iext == c->con.isplit))) return rc;
-  }
-  ext_canonical(x);
-  table_run(c, Wd.scatter);
+  Wd.pending = 1;
   return POMGPU_OK;
+}
+static void wide_flush(pomgpu_ctx *c) {
+  pomgpu_wide &Wd = c->wide;
+  if (!Wd.on || !Wd.pending) return;
+  ext_canonical(Wd.x);
+  table_run(c, Wd.scatter);
+  Wd.pending = 0;
 }
 
 extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) { return mode_interaction(c, 0); }
@@ -1213,15 +1230,10 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
   const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   if ((rc = lateral_viscosity(c, sum2d))) return rc;
-  if (c->wide.on) {                                           // one wide exchange instead of ~180 narrow ones
-    if (c->P.mode != 2) launch_vint(c, sum2d);                // advance.f:152-168
-    if ((rc = wide_external(c))) return rc;
-  } else {
-    if ((rc = mode_interaction(c, sum2d))) return rc;
-    for (int iext = 1; iext <= c->con.isplit; iext++) {
-      c->con.iext = iext;
-      if ((rc = mode_external(c, 0))) return rc;
-    }
+  if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
+  for (int iext = 1; iext <= c->con.isplit; iext++) {
+    c->con.iext = iext;
+    if ((rc = mode_external(c, 0))) return rc;                // ... to the last substep
   }
   c->con.iext = c->con.isplit + 1;
   if ((rc = pomgpu_mode_internal(c))) return rc;

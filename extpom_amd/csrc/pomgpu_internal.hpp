@@ -199,6 +199,7 @@ struct pomgpu_wide {
   pomgpu_ctx *x;
   RectTable gather_pack, gather_unpack, scatter;   // per internal step
   size_t scount[8], rcount[8];
+  int pending;               // the 2-D state of the running external loop lives in x (between wide_begin and the last substep)
   int static_done;           // every blk2d array (grid metrics, masks ...) has been widened since the last upload
 };
 

@@ -163,7 +163,10 @@ int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, c
 /* message rounds served by the transport since it was set (measurement) */
 long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
 
-/* Wide-halo external mode (needs a transport; affects pomgpu_advance / pomgpu_run only).  The reference exchanges
+/* Wide-halo external mode (needs a transport).  It starts in pomgpu_mode_interaction and ends with the
+ * pomgpu_mode_external call of the last substep (iext = isplit) -- the reference's own sequence in `advance`, and
+ * pomgpu_advance / pomgpu_run, get it without change; in between the tile's 2-D arrays are not current (any other
+ * entry point or download fetches them first).  The reference exchanges
  * 1-cell halos six times per external substep (advance.f:233,292-293,348-349; solver.f:60-61,70,111-112,121) --
  * ~180 of the ~200 message rounds of an internal step, each a few microseconds of data.  With on != 0 the 2-D part
  * of the step (advave and the tail of mode_interaction, all isplit substeps of mode_external) runs on a copy of

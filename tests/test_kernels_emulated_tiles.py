@@ -124,7 +124,8 @@ def transport(board, tile, send, scount, recv, rcount):
 OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
 
 
-def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None):
+def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None,
+              by_routine=False):
     world = nx * ny
     IMg, JMg = grid or (IM, JM)
     iml, jml = decomp.local_size(IMg, JMg, nx, ny)
@@ -161,7 +162,21 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
 
             finish_initial(st, dens, baropg)
             g.upload(st)
-            g.run(steps or STEPS)
+            if by_routine:                           # the reference's own sequence (advance.f:6-59), one entry point per subroutine,
+                for n in range(1, (steps or STEPS) + 1):   # as the Fortran host drives it
+                    g.set_con(iint=n)
+                    g.call("get_time")
+                    g.get_con()                      # time, ramp: the host's copy of blkcon is what set_con pushes below
+                    g.call("lateral_viscosity")
+                    g.call("mode_interaction")
+                    for iext in range(1, isplit + 1):
+                        g.set_con(iext=iext)
+                        g.call("mode_external")
+                    g.set_con(iext=isplit + 1)
+                    g.call("mode_internal")
+                    g.check_velocity()
+            else:
+                g.run(steps or STEPS)
             g.download()
             out[r] = (tile, st, g.exchange_rounds() if library_exchange else count[0])
         except Exception as e:                      # a dead rank must not leave the others at the barrier
@@ -268,3 +283,12 @@ def test_library_paths_leave_the_same_ghost_cells_as_the_reference_exchanges(nx,
                 if not np.array_equal(hooks[r][1].field(n)[..., :t.jm, :t.im], lib[r][1].field(n)[..., :t.jm, :t.im]):
                     bad.append((r, n))
         assert not bad, (wide, bad[:10])
+
+
+def test_wide_halo_mode_under_the_reference_call_sequence():
+    """the Fortran host calls get_time, lateral_viscosity, mode_interaction, isplit x mode_external, mode_internal,
+    check_velocity one by one (advance.f:6-59): the wide-halo mode starts in mode_interaction and ends with the last
+    mode_external, same results, same few message rounds"""
+    out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, by_routine=True)
+    rounds = compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10)
+    assert rounds[0] < 12 * STEPS, rounds
