@@ -542,13 +542,23 @@ static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair,
 static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   // solver.f:1212-1538
   KP &P = c->P;
   launch_profq_bc(c);
-  if (with_w) xch(c, 3, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
-  else xch(c, 2, P.s2[4], 1, D3(c, uf) + (size_t)(P.kb - 1) * P.n2, 1);   // :1289-1290
+  double *ufkb = D3(c, uf) + (size_t)(P.kb - 1) * P.n2;
+  const int lines = c->exch && c->tp.on && !getenv("POMGPU_PROD_FULL");   // tiles, the library's own exchange
+  if (lines) {
+    // the production term's lines (k_profq_prod_lines) depend on nothing profq_bc or the exchange below delivers:
+    // :1289-1290, :1374 (and advance.f:400 for w) travel in ONE round
+    launch_profq_prod(c, 1);
+    if (with_w) xch(c, 4, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2, D3(c, w), P.kb);
+    else xch(c, 3, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2);
+    launch_profq(c, 2, fuse_filter);                          // owned columns form prod inside the solve
+    return;
+  }
+  if (with_w) xch(c, 3, P.s2[4], 1, ufkb, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
+  else xch(c, 2, P.s2[4], 1, ufkb, 1);                        // :1289-1290
   if (!c->exch) { launch_profq(c, 1, fuse_filter); return; }  // one tile: prod is formed inside the solve kernel
-  const int lines = c->tp.on && !getenv("POMGPU_PROD_FULL");  // tiles: only the lines the exchange moves, see k_profq_prod
-  launch_profq_prod(c, lines);
+  launch_profq_prod(c, 0);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
-  launch_profq(c, lines ? 2 : 0, fuse_filter);
+  launch_profq(c, 0, fuse_filter);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
   launch_copy_kb(c, fb);                                      // solver.f:496 / :618
