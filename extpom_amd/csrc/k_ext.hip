@@ -20,8 +20,8 @@
 #define Y2(name, i, j) P.y2[X2_##name][IX2(i, j)]
 #define dx_(i, j) F2(dx, i, j)
 #define dy_(i, j) F2(dy, i, j)
-#define uab_(i, j) F2(uab, i, j)
-#define vab_(i, j) F2(vab, i, j)
+#define uab_(i, j) P.x2[X2_uab][IX2(i, j)]
+#define vab_(i, j) P.x2[X2_vab][IX2(i, j)]
 #define aam2d_(i, j) F2(aam2d, i, j)
 
 // ---------------------------------------------------------------------------------------------
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) k_advave_pair(KP P) {
     const double2 d_m2 = LD2(P.x2[X2_d], ia, jm2), d_m1 = LD2(P.x2[X2_d], ia, jm1), d_0 = LD2(P.x2[X2_d], ia, j), d_p1 = LD2(P.x2[X2_d], ia, jp1);
     const double2 ua_m1 = LD2(P.x2[X2_ua], ia, jm1), ua_0 = LD2(P.x2[X2_ua], ia, j), ua_p1 = LD2(P.x2[X2_ua], ia, jp1);
     const double2 va_m1 = LD2(P.x2[X2_va], ia, jm1), va_0 = LD2(P.x2[X2_va], ia, j), va_p1 = LD2(P.x2[X2_va], ia, jp1);
-    const double2 uab_m1 = LD2(A2(uab), ia, jm1), uab_0 = LD2(A2(uab), ia, j), uab_p1 = LD2(A2(uab), ia, jp1);
-    const double2 vab_m1 = LD2(A2(vab), ia, jm1), vab_0 = LD2(A2(vab), ia, j), vab_p1 = LD2(A2(vab), ia, jp1);
+    const double2 uab_m1 = LD2(P.x2[X2_uab], ia, jm1), uab_0 = LD2(P.x2[X2_uab], ia, j), uab_p1 = LD2(P.x2[X2_uab], ia, jp1);
+    const double2 vab_m1 = LD2(P.x2[X2_vab], ia, jm1), vab_0 = LD2(P.x2[X2_vab], ia, j), vab_p1 = LD2(P.x2[X2_vab], ia, jp1);
     const double2 am_m1 = LD2(A2(aam2d), ia, jm1), am_0 = LD2(A2(aam2d), ia, j), am_p1 = LD2(A2(aam2d), ia, jp1);
     const double2 dx_m1 = LD2(A2(dx), ia, jm1), dx_0 = LD2(A2(dx), ia, j), dy_m1 = LD2(A2(dy), ia, jm1), dy_0 = LD2(A2(dy), ia, j);
     const double2 DX4_0 = LD2(P.c2[C2_DX4], ia, j), DX4_p1 = LD2(P.c2[C2_DX4], ia, jp1);
@@ -390,8 +390,8 @@ __global__ void k_copy2(KP P, double *dst, const double *src) {
 
 // mode_external, momentum + bcond(2) -- advance.f:237-290, bounds_forcing.f:43-83
 // ec / ew / es: the new elevation elf at (i,j), (i-1,j), (i,j-1)
-__device__ __forceinline__ double uaf_interior(const KP &P, int i, int j, double ec, double ew) {
-  double v = F2(adx2d, i, j) + F2(advua, i, j) -
+__device__ __forceinline__ double uaf_interior(const KP &P, int i, int j, double ec, double ew, double adu) {
+  double v = F2(adx2d, i, j) + adu -
              F2(aru, i, j) * .25 *
                  (F2(cor, i, j) * d_(i, j) * (va_(i, j + 1) + va_(i, j)) +
                   F2(cor, i - 1, j) * d_(i - 1, j) * (va_(i - 1, j + 1) + va_(i - 1, j))) +
@@ -405,8 +405,8 @@ __device__ __forceinline__ double uaf_interior(const KP &P, int i, int j, double
       ((F2(h, i, j) + ec + F2(h, i - 1, j) + ew) * F2(aru, i, j));                            // :256-260
   return v;
 }
-__device__ __forceinline__ double vaf_interior(const KP &P, int i, int j, double ec, double es) {
-  double v = F2(ady2d, i, j) + F2(advva, i, j) +
+__device__ __forceinline__ double vaf_interior(const KP &P, int i, int j, double ec, double es, double adv) {
+  double v = F2(ady2d, i, j) + adv +
              F2(arv, i, j) * .25 *
                  (F2(cor, i, j) * d_(i, j) * (ua_(i + 1, j) + ua_(i, j)) +
                   F2(cor, i, j - 1) * d_(i, j - 1) * (ua_(i + 1, j - 1) + ua_(i, j - 1))) +
@@ -421,12 +421,14 @@ __device__ __forceinline__ double vaf_interior(const KP &P, int i, int j, double
   return v;
 }
 // the open-boundary values of bcond(2); `interior` = 0 skips the advance.f formulas (bcond alone)
-__device__ __forceinline__ void uvaf_cell(const KP &P, int i, int j, int interior, double ec, double ew, double es, double &uo, double &vo) {
+// adu, adv: advua(i,j), advva(i,j)
+__device__ __forceinline__ void uvaf_cell(const KP &P, int i, int j, int interior, double ec, double ew, double es, double adu, double adv,
+                                          double &uo, double &vo) {
   double u = F2(uaf, i, j), v = F2(vaf, i, j);
   const bool jin = (j >= 2 && j <= P.jmm1), iin = (i >= 2 && i <= P.imm1);
   if (interior) {
-    if (i >= 2 && i <= P.im && jin) u = uaf_interior(P, i, j, ec, ew);
-    if (iin && j >= 2 && j <= P.jm) v = vaf_interior(P, i, j, ec, es);
+    if (i >= 2 && i <= P.im && jin) u = uaf_interior(P, i, j, ec, ew, adu);
+    if (iin && j >= 2 && j <= P.jm) v = vaf_interior(P, i, j, ec, es, adv);
   }
   if (P.W && jin && (i == 1 || i == 2)) {                                                 // :47-53
     if (i == 1) v = BD1(vabw, j);
@@ -457,7 +459,7 @@ __global__ void k_ext_uvaf(KP P, int interior) {
   double u, v;
   if (i <= P.im && j <= P.jm) {
     const double ec = F2(elf, i, j), ew = i >= 2 ? F2(elf, i - 1, j) : 0., es = j >= 2 ? F2(elf, i, j - 1) : 0.;
-    uvaf_cell(P, i, j, interior, ec, ew, es, u, v);
+    uvaf_cell(P, i, j, interior, ec, ew, es, F2(advua, i, j), F2(advva, i, j), u, v);
   } else { u = F2(uaf, i, j); v = F2(vaf, i, j); }
   F2(uaf, i, j) = u * F2(dum, i, j);                                                      // :80-81
   F2(vaf, i, j) = v * F2(dvm, i, j);
@@ -472,8 +474,8 @@ __device__ __forceinline__ void ext_update_cell(const KP &P, int i, int j, bool 
     else if (P.iext == P.isplit) F2(etf, i, j) = (F2(etf, i, j) + .5 * elf) * F2(fsm, i, j);
   }
   const double ua = ua_(i, j), va = va_(i, j), el = el_(i, j);
-  F2(uab, i, j) = ua + .5 * P.smoth * (uab_(i, j) - 2. * ua + uaf);                       // :321,327
-  F2(vab, i, j) = va + .5 * P.smoth * (vab_(i, j) - 2. * va + vaf);                       // :322,329
+  Y2(uab, i, j) = ua + .5 * P.smoth * (uab_(i, j) - 2. * ua + uaf);                       // :321,327
+  Y2(vab, i, j) = va + .5 * P.smoth * (vab_(i, j) - 2. * va + vaf);                       // :322,329
   Y2(elb, i, j) = el + .5 * P.smoth * (elb_(i, j) - 2. * el + elf);                       // :323-324
   Y2(el, i, j) = elf;                                                                     // :325
   const double dn = F2(h, i, j) + elf;
@@ -494,8 +496,18 @@ __global__ void k_ext_update(KP P) {
                   (acc && j >= 2) ? F2(elf, i, j - 1) : 0.);
 }
 
-// the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells
-__device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f) {
+// advua(i,j), advva(i,j) of solver.f:16-121 from memory, any cell of the tile (zero outside 2..imm1 x 2..jmm1) -- as k_advave_fused
+__device__ __forceinline__ void advave_at(const KP &P, int i, int j, double &au, double &av) {
+  au = av = 0.;
+  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
+  const double tps = advave_tps(P, i, j);
+  au = advave_fu(P, i, j) - advave_fu(P, i - 1, j) + advave_fv(P, i, j + 1, advave_tps(P, i, j + 1)) - advave_fv(P, i, j, tps);   // :65-66
+  const double gu_e = (i + 1 <= P.im) ? advave_gu(P, i + 1, j, advave_tps(P, i + 1, j)) : 0.;
+  av = gu_e - advave_gu(P, i, j, tps) + advave_gv(P, i, j) - advave_gv(P, i, j - 1);                                          // :116-117
+}
+// the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells.
+// fuse_adv: advua, advva are formed here (advave is part of this substep's kernel) instead of read
+__device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, int fuse_adv) {
   const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
   int i, j;
   if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
@@ -505,11 +517,16 @@ __device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f) {
     const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
   }
   const double ec = elf_at(P, i, j), ew = i >= 2 ? elf_at(P, i - 1, j) : 0., es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
-  double u, v;
-  uvaf_cell(P, i, j, 1, ec, ew, es, u, v);
+  double u, v, adu, adv;
+  if (fuse_adv) advave_at(P, i, j, adu, adv);
+  else { adu = F2(advua, i, j); adv = F2(advva, i, j); }
+  uvaf_cell(P, i, j, 1, ec, ew, es, adu, adv, u, v);
   u = u * F2(dum, i, j);
   v = v * F2(dvm, i, j);
-  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
+  if (store_f) {
+    F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v;
+    if (fuse_adv) { F2(advua, i, j) = adu; F2(advva, i, j) = adv; }
+  }
   ext_update_cell(P, i, j, true, ec, u, v, ew, es);
 }
 // ---------------------------------------------------------------------------------------------
@@ -528,9 +545,15 @@ __device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f) {
 // their own -- a few thousand threads on a long chain of dependent loads, ~15 us whatever the grid size, 30 times
 // per internal step; as the FIRST workgroups of this launch they run beside the interior ones.  They read the
 // same generation of ua, va, d, el, elb and write other cells.
+// FUSE_ADV: advave (solver.f:16-121, re-evaluated every substep, advance.f:235 with ispadv = 1) rides along: its
+// fluxes need the same rows of d, ua, va this kernel holds already, plus uab, vab, aam2d and four metric arrays --
+// one launch and ~9 of 54 array passes per substep less than k_advave_pair + this kernel.  advua, advva reach memory
+// on the last substep only.  uab, vab are then read at neighbour cells while this kernel rewrites them: they are
+// double-buffered like ua, va, d, el, elb.
+template <int FUSE_ADV>
 __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) {
   if ((int)blockIdx.y < rim_rows) {
-    ext_rim_cell(P, (int)((blockIdx.y * blockDim.y + threadIdx.y) * (gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x), store_f);
+    ext_rim_cell(P, (int)((blockIdx.y * blockDim.y + threadIdx.y) * (gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x), store_f, FUSE_ADV);
     return;
   }
   const int lane = HALO_LANE, i0 = HALO_COL, j = (int)((blockIdx.y - rim_rows) * blockDim.y + threadIdx.y + 1);
@@ -554,9 +577,11 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
   const double fsm_m1 = F2(fsm, i, j - 1), fsm_0 = F2(fsm, i, j);
   const double ea_m1 = F2(e_atmos, i, j - 1), ea_0 = F2(e_atmos, i, j), h_m1 = F2(h, i, j - 1), h_0 = F2(h, i, j);
   const double cor_m1 = F2(cor, i, j - 1), cor_0 = F2(cor, i, j);
-  const double adx2d = F2(adx2d, i, j), advua = F2(advua, i, j), aru = F2(aru, i, j), drx2d = F2(drx2d, i, j);
+  const double adx2d = F2(adx2d, i, j), aru = F2(aru, i, j), drx2d = F2(drx2d, i, j);
   const double wusurf = F2(wusurf, i, j), wubot = F2(wubot, i, j), uab = uab_(i, j);
-  const double ady2d = F2(ady2d, i, j), advva = F2(advva, i, j), arv = F2(arv, i, j), dry2d = F2(dry2d, i, j);
+  const double ady2d = F2(ady2d, i, j), arv = F2(arv, i, j), dry2d = F2(dry2d, i, j);
+  double advua = 0., advva = 0.;
+  if (!FUSE_ADV) { advua = F2(advua, i, j); advva = F2(advva, i, j); }
   const double wvsurf = F2(wvsurf, i, j), wvbot = F2(wvbot, i, j), vab = vab_(i, j);
   // ---- neighbour-lane operands
   // d(i-1) feeds this lane's own x-flux and through it ec, which the east neighbour takes as its ew:
@@ -573,6 +598,26 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
   const double ec = (elb_0 + P.dte2 * (-(fuaE_0 - fua_0 + fva_p1 - fva_0) / art_0 - vfl_0)) * fsm_0;
   const double es = (elb_m1 + P.dte2 * (-(fuaE_m1 - fua_m1 + fva_0 - fva_m1) / art_m1 - vfl_m1)) * fsm_m1;
   const double ew = WS(ec, elf_at(P, iw, j));
+  if (FUSE_ADV) {                                          // advave on register operands, as k_advave_pair (advave_cell)
+    AdvaveCell a;
+    a.d_m2 = d_m2; a.d_m1 = d_m1; a.d_0 = d_0; a.d_p1 = d_p1;
+    a.dW_m1 = dW_m1; a.dW_0 = dW_0; a.dW_p1 = WS(d_p1, d_(iw, j + 1)); a.dE_0 = ES(d_0, d_(ie, j));
+    a.ua_m1 = ua_m1; a.ua_0 = ua_0; a.ua_p1 = ua_(i, j + 1); a.uaE_0 = uaE_0;
+    a.va_m1 = va_m1; a.va_0 = va_0; a.va_p1 = va_p1; a.vaW_0 = vaW_0; a.vaW_p1 = vaW_p1;
+    a.uab_m1 = uab_(i, j - 1); a.uab_0 = uab; a.uab_p1 = uab_(i, j + 1); a.uabE_0 = ES(uab, uab_(ie, j));
+    a.vab_m1 = vab_(i, j - 1); a.vab_0 = vab; a.vab_p1 = vab_(i, j + 1);
+    a.vabW_0 = WS(a.vab_0, vab_(iw, j)); a.vabW_p1 = WS(a.vab_p1, vab_(iw, j + 1));
+    a.am_m1 = aam2d_(i, j - 1); a.am_0 = aam2d_(i, j); a.am_p1 = aam2d_(i, j + 1);
+    a.amW_m1 = WS(a.am_m1, aam2d_(iw, j - 1)); a.amW_0 = WS(a.am_0, aam2d_(iw, j)); a.amW_p1 = WS(a.am_p1, aam2d_(iw, j + 1));
+    a.dx_0 = dx_(i, j); a.dx_m1 = dx_(i, j - 1); a.dy_0 = dy_(i, j); a.dy_m1 = dy_(i, j - 1);
+    a.DX4_0 = K2(DX4, i, j); a.DX4_p1 = K2(DX4, i, j + 1); a.DY4_0 = K2(DY4, i, j); a.DY4_p1 = K2(DY4, i, j + 1);
+    // the flux ranges of the reference: fluxua 2..imm1, the corner quantities 2..im; row j-1 >= 2 here
+    const AdvaveOut f = advave_cell(a, i0 >= 2 && i0 <= P.imm1, i0 >= 2 && i0 <= P.im, true);
+    const double fu_w = WS(f.fu, advave_fu(P, i - 1, j));
+    const double gu_e = ES(f.gu, (i + 1 <= P.im) ? advave_gu(P, i + 1, j, advave_tps(P, i + 1, j)) : 0.);
+    advua = f.fu - fu_w + f.fvP - f.fv0;                   // :65-66
+    advva = gu_e - f.gu + f.gv0 - f.gvM;                   // :116-117
+  }
 #undef WS
 #undef ES
   if (!out) return;
@@ -589,13 +634,16 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
   v = ((h_0 + elb_0 + h_m1 + elb_m1) * arv * vab - 4. * P.dte * v) / ((h_0 + ec + h_m1 + es) * arv);
   u = u * F2(dum, i, j);
   v = v * F2(dvm, i, j);
-  if (store_f) { F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v; }
+  if (store_f) {
+    F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v;
+    if (FUSE_ADV) { F2(advua, i, j) = advua; F2(advva, i, j) = advva; }
+  }
   // ---- etf weights, Asselin filter, time rotation, accumulation (:295-347), as ext_update_cell
   if (P.iext == P.isplit - 2) F2(etf, i, j) = .25 * P.smoth * ec;
   else if (P.iext == P.isplit - 1) F2(etf, i, j) = F2(etf, i, j) + .5 * (1. - .5 * P.smoth) * ec;
   else if (P.iext == P.isplit) F2(etf, i, j) = (F2(etf, i, j) + .5 * ec) * fsm_0;
-  F2(uab, i, j) = ua_0 + .5 * P.smoth * (uab - 2. * ua_0 + u);
-  F2(vab, i, j) = va_0 + .5 * P.smoth * (vab - 2. * va_0 + v);
+  Y2(uab, i, j) = ua_0 + .5 * P.smoth * (uab - 2. * ua_0 + u);
+  Y2(vab, i, j) = va_0 + .5 * P.smoth * (vab - 2. * va_0 + v);
   Y2(elb, i, j) = el_0 + .5 * P.smoth * (elb_0 - 2. * el_0 + ec);
   Y2(el, i, j) = ec;
   const double dn = h_0 + ec;
@@ -609,7 +657,7 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
   }
 }
 __global__ void k_ext_step_rim(KP P, int store_f) {
-  ext_rim_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f);
+  ext_rim_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f, 0);
 }
 
 // mode_internal tail: rotate the 2-D time levels -- advance.f:525-531 (whole arrays)
@@ -667,17 +715,18 @@ void launch_ext_elf(pomgpu_ctx *c) { LAUNCH(c, k_ext_elf, grid2(c->P), blk2(), c
 void launch_ext_uvaf(pomgpu_ctx *c, int interior) { LAUNCH(c, k_ext_uvaf, grid2(c->P), blk2(), c->P, interior); }
 void launch_ext_update(pomgpu_ctx *c) { LAUNCH(c, k_ext_update, grid2(c->P), blk2(), c->P); }
 // Q: c->P with y2 pointing at the next-generation buffers
-void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f) {
+void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
   const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
   dim3 g = grid2_halo(Q);
-  if (getenv("POMGPU_EXT_RIM_KERNEL")) {                      // developer switch: the rim as a launch of its own
-    LAUNCH(c, k_ext_step, g, blk2(), Q, store_f, 0);
+  if (getenv("POMGPU_EXT_RIM_KERNEL") && !fuse_adv) {         // developer switch: the rim as a launch of its own
+    LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, 0);
     LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
     return;
   }
   const int per_row = (int)g.x * 256, rim_rows = (n + per_row - 1) / per_row;
   g.y += rim_rows;
-  LAUNCH(c, k_ext_step, g, blk2(), Q, store_f, rim_rows);
+  if (fuse_adv) LAUNCHN(c, "k_ext_step_adv", k_ext_step<1>, g, blk2(), Q, store_f, rim_rows);
+  else LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, rim_rows);
 }
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy2, grid2(c->P), blk2(), c->P, dst, src); }
 void launch_int_tail(pomgpu_ctx *c) { LAUNCH(c, k_int_tail, grid2(c->P), blk2(), c->P); }

@@ -147,10 +147,10 @@ extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.1 (gfx
 // launch_ext_step gets a KP whose y2 is the other set.  ext_canonical() moves the current generation
 // back into blk2d; every entry point except pomgpu_mode_external calls it first (a no-op after an
 // even number of fused substeps).
-static const int X2_SLOT[5] = {P2_ua, P2_va, P2_d, P2_el, P2_elb};
+static const int X2_SLOT[POMGPU_NGEN] = {P2_ua, P2_va, P2_d, P2_el, P2_elb, P2_uab, P2_vab};
 static void ext_buffers(pomgpu_ctx *c) {
   KP &P = c->P;
-  for (int n = 0; n < 5; n++) P.x2[n] = P.y2[n] = c->ext_parity ? c->alt2[n] : P.b2 + (size_t)X2_SLOT[n] * P.n2;
+  for (int n = 0; n < POMGPU_NGEN; n++) P.x2[n] = P.y2[n] = c->ext_parity ? c->alt2[n] : P.b2 + (size_t)X2_SLOT[n] * P.n2;
 }
 // trstr, srstr, taurstr of the last internal step, if k_ts_update skipped them
 static void restore_materialize(pomgpu_ctx *c) {
@@ -161,7 +161,7 @@ static void restore_materialize(pomgpu_ctx *c) {
 static void ext_canonical(pomgpu_ctx *c) {
   if (!c->ext_parity) return;
   KP &P = c->P;
-  for (int n = 0; n < 5; n++) launch_copy2(c, P.b2 + (size_t)X2_SLOT[n] * P.n2, c->alt2[n]);
+  for (int n = 0; n < POMGPU_NGEN; n++) launch_copy2(c, P.b2 + (size_t)X2_SLOT[n] * P.n2, c->alt2[n]);
   c->ext_parity = 0;
   ext_buffers(c);
 }
@@ -225,7 +225,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   for (int n = 0; n < POMGPU_NSCR3 && !only2d; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
-  for (int n = 0; n < 5; n++) alloc(&c->alt2[n], P.n2);
+  for (int n = 0; n < POMGPU_NGEN; n++) alloc(&c->alt2[n], P.n2);
   for (int n = 0; n < 2; n++) {
     const size_t len = (size_t)(P.kb + 1) * (n == 0 ? P.jml : P.iml);
     alloc(&c->ord_send[n], len);
@@ -261,7 +261,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
   for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
-  for (int n = 0; n < 5; n++) (void)hipFree(c->alt2[n]);
+  for (int n = 0; n < POMGPU_NGEN; n++) (void)hipFree(c->alt2[n]);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
@@ -702,10 +702,12 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   KP &P = c->P;
   P.iext = c->con.iext;
   if (!c->exch && !getenv("POMGPU_EXT_SPLIT")) {              // one tile: one kernel per substep, two buffer generations
-    if (c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235 (reads ua, va, d of the current generation)
+    // advave every substep (ispadv = 1 is hard-coded in the reference, initialize.f:156): it rides in the substep's kernel
+    const int fuse_adv = c->con.ispadv == 1 && P.mode != 2 && !getenv("POMGPU_ADVAVE_SEPARATE");
+    if (!fuse_adv && c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235 (reads ua, va, d of the current generation)
     KP Q = P;
-    for (int n = 0; n < 5; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
-    launch_ext_step(c, Q, store_f || P.iext == P.isplit);     // :211-347
+    for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
+    launch_ext_step(c, Q, store_f || P.iext == P.isplit, fuse_adv);   // :211-347
     c->ext_parity ^= 1;
     ext_buffers(c);
     return POMGPU_OK;

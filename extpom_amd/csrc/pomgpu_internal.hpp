@@ -16,6 +16,7 @@
 #define POMGPU_MAXREC 8
 #define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
 #define POMGPU_CTX_2D 1
+#define POMGPU_NGEN 7        // arrays of the external mode that exist in two generations (enum pomgpu_x2)
 
 // Kernel parameters, passed by value with every launch.
 struct KP {
@@ -34,13 +35,13 @@ struct KP {
   int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
-  // current (read) and next (written) generation of ua, va, d, el, elb for the external-mode kernels
+  // current (read) and next (written) generation of ua, va, d, el, elb, uab, vab for the external-mode kernels
   // (k_ext.hip); identical and equal to the blk2d arrays except inside the fused external step
-  double *x2[5], *y2[5];
+  double *x2[POMGPU_NGEN], *y2[POMGPU_NGEN];
   // baropg_mcc's extra ghosts: rho4th(0,j,k) [kb x jml], rho4th(i,0,k) [kb x iml], d4th(0,j) [jml], d4th(i,0) [iml]
   double *g4[4];
 };
-enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb };
+enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb, X2_uab, X2_vab };
 
 // ---- Fortran-style accessors (1-based), `P` is the KP in scope ------------------------------
 #define IX2(i, j) ((size_t)((j)-1) * (size_t)P.iml + (size_t)((i)-1))
@@ -217,7 +218,7 @@ struct pomgpu_ctx {
   void (*order)(void *, const double *, int, const double *, int, double *, double *);   // pomgpu_order_fn
   void *order_user;
   double *ord_send[2], *ord_recv[2];   // [0] east/west: (kb+1) x jml, [1] north/south: (kb+1) x iml
-  double *alt2[5];           // second buffer set of ua, va, d, el, elb (fused external step)
+  double *alt2[POMGPU_NGEN]; // second buffer set of ua, va, d, el, elb, uab, vab (fused external step)
   int ext_parity;            // 1 while the current generation of those five lives in alt2
   int rst_pending;           // trstr/srstr/taurstr of the last step exist only as (rst_fold, rst_fnew) weights
   double rst_fold, rst_fnew;
@@ -314,7 +315,7 @@ void launch_modeint_tail(pomgpu_ctx *c);
 void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
-void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f);
+void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate
 void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf);
