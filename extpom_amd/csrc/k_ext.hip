@@ -570,11 +570,30 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
   const double d_m2 = d_(i, j - 2), d_m1 = d_(i, j - 1), d_0 = d_(i, j), d_p1 = d_(i, j + 1);
   const double ua_m1 = ua_(i, j - 1), ua_0 = ua_(i, j);
   const double va_m1 = va_(i, j - 1), va_0 = va_(i, j), va_p1 = va_(i, j + 1);
-  const double dysx_m1 = K2(DYSX, i, j - 1), dysx_0 = K2(DYSX, i, j);                       // dy(i,q)+dy(i-1,q)
-  const double dxsy_m1 = K2(DXSY, i, j - 1), dxsy_0 = K2(DXSY, i, j), dxsy_p1 = K2(DXSY, i, j + 1);   // dx(i,q)+dx(i,q-1)
+  // metric sums: dy(i,q)+dy(i-1,q), dx(i,q)+dx(i,q-1) -- read as derived arrays, or (FUSE_ADV: dx, dy are loaded anyway)
+  // formed from the rows of dx, dy and the west lane's values in the order k_coef_static sums them
+  double dysx_m1, dysx_0, dxsy_m1, dxsy_0, dxsy_p1;
+  double dx_m1 = 0., dx_0 = 0., dx_p1 = 0., dy_m1 = 0., dy_0 = 0., dy_p1 = 0., dxW_m1 = 0., dxW_0 = 0., dxW_p1 = 0., dyW_m1 = 0., dyW_0 = 0., dyW_p1 = 0.;
+  if (FUSE_ADV) {
+    const double dx_m2 = dx_(i, j - 2);
+    dx_m1 = dx_(i, j - 1); dx_0 = dx_(i, j); dx_p1 = dx_(i, j + 1);
+    dy_m1 = dy_(i, j - 1); dy_0 = dy_(i, j); dy_p1 = dy_(i, j + 1);
+    dxW_m1 = WS(dx_m1, dx_(iw, j - 1)); dxW_0 = WS(dx_0, dx_(iw, j)); dxW_p1 = WS(dx_p1, dx_(iw, j + 1));
+    dyW_m1 = WS(dy_m1, dy_(iw, j - 1)); dyW_p1 = WS(dy_p1, dy_(iw, j + 1));
+    dyW_0 = lane_w(dy_0, [&] { return dy_(iw, j); });       // feeds ec, which the east neighbour takes as its ew: true on the west halo lane too
+    dysx_m1 = dy_m1 + dyW_m1; dysx_0 = dy_0 + dyW_0;
+    dxsy_m1 = dx_m1 + dx_m2; dxsy_0 = dx_0 + dx_m1; dxsy_p1 = dx_p1 + dx_0;
+  } else {
+    dysx_m1 = K2(DYSX, i, j - 1); dysx_0 = K2(DYSX, i, j);
+    dxsy_m1 = K2(DXSY, i, j - 1); dxsy_0 = K2(DXSY, i, j); dxsy_p1 = K2(DXSY, i, j + 1);
+  }
   const double elb_m1 = elb_(i, j - 1), elb_0 = elb_(i, j), el_m1 = el_(i, j - 1), el_0 = el_(i, j);
   const double art_m1 = F2(art, i, j - 1), art_0 = F2(art, i, j), vfl_m1 = F2(vfluxf, i, j - 1), vfl_0 = F2(vfluxf, i, j);
-  const double fsm_m1 = F2(fsm, i, j - 1), fsm_0 = F2(fsm, i, j);
+  double fsm_m1, fsm_0, dum_0 = 0., dvm_0 = 0.;
+  if (FUSE_ADV) {                                          // masks from the byte array (KP.m8)
+    const unsigned mk_m1 = P.m8[IX2(i, j - 1)], mk_0 = P.m8[IX2(i, j)];
+    fsm_m1 = (double)(mk_m1 & 1u); fsm_0 = (double)(mk_0 & 1u); dum_0 = (double)((mk_0 >> 1) & 1u); dvm_0 = (double)((mk_0 >> 2) & 1u);
+  } else { fsm_m1 = F2(fsm, i, j - 1); fsm_0 = F2(fsm, i, j); }
   const double ea_m1 = F2(e_atmos, i, j - 1), ea_0 = F2(e_atmos, i, j), h_m1 = F2(h, i, j - 1), h_0 = F2(h, i, j);
   const double cor_m1 = F2(cor, i, j - 1), cor_0 = F2(cor, i, j);
   const double adx2d = F2(adx2d, i, j), aru = F2(aru, i, j), drx2d = F2(drx2d, i, j);
@@ -609,8 +628,9 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
     a.vabW_0 = WS(a.vab_0, vab_(iw, j)); a.vabW_p1 = WS(a.vab_p1, vab_(iw, j + 1));
     a.am_m1 = aam2d_(i, j - 1); a.am_0 = aam2d_(i, j); a.am_p1 = aam2d_(i, j + 1);
     a.amW_m1 = WS(a.am_m1, aam2d_(iw, j - 1)); a.amW_0 = WS(a.am_0, aam2d_(iw, j)); a.amW_p1 = WS(a.am_p1, aam2d_(iw, j + 1));
-    a.dx_0 = dx_(i, j); a.dx_m1 = dx_(i, j - 1); a.dy_0 = dy_(i, j); a.dy_m1 = dy_(i, j - 1);
-    a.DX4_0 = K2(DX4, i, j); a.DX4_p1 = K2(DX4, i, j + 1); a.DY4_0 = K2(DY4, i, j); a.DY4_p1 = K2(DY4, i, j + 1);
+    a.dx_0 = dx_0; a.dx_m1 = dx_m1; a.dy_0 = dy_0; a.dy_m1 = dy_m1;
+    a.DX4_0 = dx_0 + dxW_0 + dx_m1 + dxW_m1; a.DX4_p1 = dx_p1 + dxW_p1 + dx_0 + dxW_0;      // as k_coef_static: (i,j)+(i-1,j)+(i,j-1)+(i-1,j-1)
+    a.DY4_0 = dy_0 + dyW_0 + dy_m1 + dyW_m1; a.DY4_p1 = dy_p1 + dyW_p1 + dy_0 + dyW_0;
     // the flux ranges of the reference: fluxua 2..imm1, the corner quantities 2..im; row j-1 >= 2 here
     const AdvaveOut f = advave_cell(a, i0 >= 2 && i0 <= P.imm1, i0 >= 2 && i0 <= P.im, true);
     const double fu_w = WS(f.fu, advave_fu(P, i - 1, j));
@@ -632,8 +652,8 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
                  ((1. - 2. * P.alpha) * (el_0 - el_m1) + P.alpha * (elb_0 - elb_m1 + ec - es) + ea_0 - ea_m1) +
              dry2d + arv * (wvsurf - wvbot);
   v = ((h_0 + elb_0 + h_m1 + elb_m1) * arv * vab - 4. * P.dte * v) / ((h_0 + ec + h_m1 + es) * arv);
-  u = u * F2(dum, i, j);
-  v = v * F2(dvm, i, j);
+  u = u * (FUSE_ADV ? dum_0 : F2(dum, i, j));
+  v = v * (FUSE_ADV ? dvm_0 : F2(dvm, i, j));
   if (store_f) {
     F2(elf, i, j) = ec; F2(uaf, i, j) = u; F2(vaf, i, j) = v;
     if (FUSE_ADV) { F2(advua, i, j) = advua; F2(advva, i, j) = advva; }

@@ -15,6 +15,7 @@ __global__ void k_coef_static(KP P) {
   const int i = TID_I, j = TID_J;
   if (i > P.iml || j > P.jml) return;
   const int iw = i > 1 ? i - 1 : 1, js = j > 1 ? j - 1 : 1;
+  P.m8[IX2(i, j)] = (unsigned char)((F2(fsm, i, j) != 0. ? 1 : 0) | (F2(dum, i, j) != 0. ? 2 : 0) | (F2(dvm, i, j) != 0. ? 4 : 0));
   K2(HSX, i, j) = F2(h, i, j) + F2(h, iw, j);
   K2(HSY, i, j) = F2(h, i, j) + F2(h, i, js);
   K2(DYSX, i, j) = F2(dy, i, j) + F2(dy, iw, j);

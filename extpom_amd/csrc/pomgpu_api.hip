@@ -226,6 +226,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
   for (int n = 0; n < POMGPU_NGEN; n++) alloc(&c->alt2[n], P.n2);
+  { double *m = NULL; alloc(&m, (P.n2 + 7) / 8 + 1); P.m8 = (unsigned char *)m; }
   for (int n = 0; n < 2; n++) {
     const size_t len = (size_t)(P.kb + 1) * (n == 0 ? P.jml : P.iml);
     alloc(&c->ord_send[n], len);
@@ -262,6 +263,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
   for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
   for (int n = 0; n < POMGPU_NGEN; n++) (void)hipFree(c->alt2[n]);
+  (void)hipFree(P.m8);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
   (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
@@ -370,6 +372,9 @@ static void refresh_coefs(pomgpu_ctx *c) {
 #define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL; ext_canonical(c); restore_materialize(c)
 extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
+  if (s == P2_fsm || s == P2_dum || s == P2_dvm)               // the kernels fold mask multiplies: 0/1 only, as io_pnetcdf.F derives them
+    for (size_t n = 0; n < c->P.n2; n++)
+      if (h[n] != 0. && h[n] != 1.) return fail(c, POMGPU_EINVAL, "mask array (blk2d slot %d) holds a value other than 0/1", s);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->wide.static_done = 0;

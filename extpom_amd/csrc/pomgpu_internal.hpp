@@ -40,6 +40,9 @@ struct KP {
   double *x2[POMGPU_NGEN], *y2[POMGPU_NGEN];
   // baropg_mcc's extra ghosts: rho4th(0,j,k) [kb x jml], rho4th(i,0,k) [kb x iml], d4th(0,j) [jml], d4th(i,0) [iml]
   double *g4[4];
+  // the three 0/1 masks of a cell in one byte (bit 0 fsm, 1 dum, 2 dvm), k_coef_static: the fused external substep
+  // reads 2 bytes instead of 4 doubles per cell; (double)bit * x is the reference's mask multiply, bit for bit
+  unsigned char *m8;
 };
 enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb, X2_uab, X2_vab };
 
