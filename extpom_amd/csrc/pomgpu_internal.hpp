@@ -151,24 +151,6 @@ template <class F> __device__ __forceinline__ double halo_e(double x, F) { retur
 #ifndef COL_ROWS
 #define COL_ROWS 4                                          /* rows (wavefronts) per workgroup of the column kernels */
 #endif
-// COL_CHUNK (developer switch, off): an XCD walks its band in strips COL_CHUNK workgroups wide, top to bottom, so
-// that its ~96 resident workgroups form a tall patch (few exterior halo rows) instead of ~3 full-width block-rows.
-#ifdef COL_CHUNK
-#define HALO_XCD_DECODE                                                                   \
-  const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
-  const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS; \
-  const int rpx__ = (nby__ + 7) / 8, nch__ = (nbx__ + COL_CHUNK - 1) / COL_CHUNK;          \
-  const int m__ = L__ >> 3, ch__ = m__ / (rpx__ * COL_CHUNK), r__ = m__ % (rpx__ * COL_CHUNK); \
-  const int by__ = (L__ & 7) * rpx__ + r__ / COL_CHUNK, bx__ = ch__ * COL_CHUNK + r__ % COL_CHUNK; \
-  if (ch__ >= nch__ || bx__ >= nbx__ || by__ >= nby__) return;                            \
-  const int lane = g__ & 63;                                                              \
-  const int i0 = bx__ * 62 + lane;                                                        \
-  const int j = by__ * COL_ROWS + (int)threadIdx.y + 1;
-static inline dim3 grid1_halo(const KP &P) {
-  const int nbx = (P.iml + 61) / 62, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8, nch = (nbx + COL_CHUNK - 1) / COL_CHUNK;
-  return dim3((unsigned)(8 * rpx * nch * COL_CHUNK), 1, 1);
-}
-#else
 #define HALO_XCD_DECODE                                                                   \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
   const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS; \
@@ -182,7 +164,6 @@ static inline dim3 grid1_halo(const KP &P) {
   const int nbx = (P.iml + 61) / 62, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;
   return dim3((unsigned)(8 * rpx * nbx), 1, 1);
 }
-#endif
 static inline dim3 blk_col() { return dim3(64, COL_ROWS, 1); }
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
