@@ -125,7 +125,7 @@ OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
 
 
 def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None,
-              by_routine=False):
+              by_routine=False, records=False, dte=6.0):
     world = nx * ny
     IMg, JMg = grid or (IM, JM)
     iml, jml = decomp.local_size(IMg, JMg, nx, ny)
@@ -135,7 +135,7 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
     def rank(r):
         try:
             tile = tiles[r]
-            st = make_case(case, IMg, JMg, KB, tile=tile, dte=6.0, isplit=isplit, **nml)
+            st = make_case(case, IMg, JMg, KB, tile=tile, dte=dte, isplit=isplit, **nml)
             g = PomGpu(st, libpath=EMU)
             count = [0]
 
@@ -161,8 +161,19 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
                 g.upload(s); g.call("baropg_mcc" if int(s.npg) == 2 else "baropg"); g.download(s)
 
             finish_initial(st, dens, baropg)
+            if records:                              # file forcing: wind / heat / surface and lateral_bc records (cases.py)
+                from extpom_amd.cases import make_forcing_records, make_lateral_records
+                make_forcing_records(st, 4)
+                make_lateral_records(st, 6)
             g.upload(st)
-            if by_routine:                           # the reference's own sequence (advance.f:6-59), one entry point per subroutine,
+            if records:
+                g.set_forcing_records()
+                g.set_lateral_records()
+                for n in range(1, (steps or STEPS) + 1):
+                    if n % records == 0:
+                        g.set_lateral_records(first=n // records + 2, count=1)   # the record lateral_bc asks for at this step
+                    g.run(1)
+            elif by_routine:                           # the reference's own sequence (advance.f:6-59), one entry point per subroutine,
                 for n in range(1, (steps or STEPS) + 1):   # as the Fortran host drives it
                     g.set_con(iint=n)
                     g.call("get_time")
@@ -292,3 +303,30 @@ def test_wide_halo_mode_under_the_reference_call_sequence():
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, by_routine=True)
     rounds = compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10)
     assert rounds[0] < 12 * STEPS, rounds
+
+
+def test_wide_halo_mode_with_file_forcing_records():
+    """surface_forcing and lateral_bc (advance.f:14-18) change wusurf, wvsurf, e_atmos ... and the open-boundary lines every
+    step: the wide exchange must carry them (and the boundary lines along the tile edges) -- 2x2 tiles of the seamount
+    case (all four sides open) across a lateral record change, against the single-tile oracle with the same records"""
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
+    grid, isplit, dte, steps = WIDE_GRID, 20, 6.0, 32          # dti = 120 s: lateral records (1/24 d) change at step 30; w = 24
+    out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=grid, isplit=isplit, case="seamount", steps=steps, records=30, dte=dte)
+    g = make_case("seamount", grid[0], grid[1], KB, dte=dte, isplit=isplit)
+    oracle_finish_initial(g)
+    make_forcing_records(g, 4)
+    make_lateral_records(g, 6)
+    ot = OracleTile(g)
+    ot.run(steps)
+    assert np.isfinite(g.field("u")).all() and int(g.error_status) == 0
+    bad = []
+    for r, (tile, st, count) in out.items():
+        io, jo, im, jm = tile.i_off, tile.j_off, tile.im, tile.jm
+        sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == grid[1] else jm - 1)
+        sl_i = slice(0 if io == 0 else 1, im if io + im == grid[0] else im - 1)
+        for n in BLK2D + BLK3D:
+            if n in SCRATCH:
+                continue
+            if not np.array_equal(g.field(n)[..., jo:jo + jm, io:io + im][..., sl_j, sl_i], st.field(n)[..., :jm, :im][..., sl_j, sl_i]):
+                bad.append((r, n))
+    assert not bad, bad[:12]
