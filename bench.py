@@ -201,6 +201,25 @@ def cpu_baseline_all_cores(workload):
                       f"{min(r['n'] for r in res)}-{max(r['n'] for r in res)} internal steps each"}
 
 
+def side_config(workload, device, stream, steps=40, warmup=5):
+    """a second workload on the same GPU, timed like the main one (state resident, K steps between syncs)"""
+    case, im, jm, kb, desc = WORKLOADS[workload]
+    from extpom_amd import dist as pdist
+    st = build_state(workload, pdist.tile_for_rank(0, 1, im, jm))
+    g = gpu_initialise(st, device, stream)
+    g.run(warmup)
+    g.sync()
+    t0 = time.perf_counter()
+    g.run(steps)
+    g.sync()
+    dt = time.perf_counter() - t0
+    g.get_con()
+    err = int(st.error_status)
+    g.close()
+    return {"workload": desc, "ms_per_step": dt / steps * 1e3, "value": im * jm * kb * steps / dt, "unit": "cell-updates/s", "steps": steps,
+            "step_algorithmic_GBps": round(P_STEP * 8.0 * im * jm * kb / (dt / steps) / 1e9, 1), "error_status": err}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +227,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("POM_BENCH_WORKLOAD", "basin2048"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--side-config", action="store_true",
+                    help="N=1: also time BASELINE configs[1] (seamount 256x256x30) in the same run; off by default so that a profile "
+                         "of the default command holds the headline workload's kernels only")
     ap.add_argument("--reference", action="store_true", help="internal: with --cpu-sample, time oracle/_ref instead of the oracle")
     ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle sample and print it (no GPU)")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
@@ -358,8 +380,15 @@ def main():
             if ref:
                 out["cpu_baseline_port"] = port
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload)
+        if world == 1 and args.workload == "basin2048" and args.side_config:
+            # BASELINE configs[1] (seamount 256x256x30) in the same run: a launch-latency-bound size, reported beside
+            # the headline grid so that both ends of the size range are on the line
+            g.close()
+            g = None
+            out["config1_seamount256"] = side_config("seamount256", local, stream)
         print(json.dumps(out))
-    g.close()
+    if g is not None:
+        g.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

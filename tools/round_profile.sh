@@ -5,6 +5,7 @@ TAG=${1:-r1}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -2 $O/gputests.log
+python bench.py --side-config > $O/bench_basin2048_with_config1.json 2> /dev/null
 python bench.py > $O/bench_basin2048.json 2> $O/bench_basin2048.err; tail -c 600 $O/bench_basin2048.json; echo
 python bench.py --workload seamount256 --steps 20 > $O/bench_seamount256.json 2>/dev/null
 python bench.py --workload basin1024 --steps 5 > $O/bench_basin1024.json 2>/dev/null
