@@ -618,26 +618,10 @@ static int restore_prepare(pomgpu_ctx *c, double *fold_out, double *fnew_out) { 
   return POMGPU_OK;
 }
 static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.f:1023-1121
-  KP &P = c->P;
-  const pom_blkcon &k = c->con;
-  const double trst = 30.;
-  const int irst = (int)(trst * 86400. / k.dti);
-  const int ntime = (int)(k.time / trst);
-  auto load = [&](int n) -> int {
-    if (n < 1 || n > POMGPU_MAXREC || !c->rec_t[n])
-      return fail(c, POMGPU_EINVAL, "restore_interior: record %d was not supplied (pomgpu_set_restore_record)", n);
-    launch_restore_load(c, c->rec_t[n], c->rec_s[n], 1. / trst);
-    return POMGPU_OK;
-  };
-  if (k.iint == 2) { int rc = load((k.iint / irst) + 1); if (rc) return rc; }
-  if (k.iint == 2 || (irst > 0 && k.iint % irst == 0)) {
-    launch_restore_shift(c);
-    if (k.iint != k.iend) { int rc = load((k.iint + irst) / irst + 1); if (rc) return rc; }
-  }
-  const double fnew = k.time / trst - ntime;
-  const double fold = 1. - fnew;
+  double fold, fnew;
+  const int rc = restore_prepare(c, &fold, &fnew);            // record reads / shifts, interpolation weights
+  if (rc) return rc;
   launch_restore(c, fold, fnew);
-  (void)P;
   return POMGPU_OK;
 }
 
