@@ -272,12 +272,14 @@ def test_config2_seamount_256x256x30_matches_oracle():
     assert not diff(a, b), diff(a, b)
 
 
-def test_general_kernels_behind_the_fast_paths(monkeypatch):
+@pytest.mark.parametrize("switches", [("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
+                                       "POMGPU_REALVERTVL_CELLS"), ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL")])
+def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
-    multi-tile runs, selected through the library's developer switches, on an even and an odd grid"""
+    multi-tile runs, selected through the library's developer switches, on an even and an odd grid; second set: the
+    external substep with advave and the rim cells as kernels of their own"""
     OracleTile, oracle_finish_initial = _oracle()
-    for v in ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
-              "POMGPU_REALVERTVL_CELLS"):
+    for v in switches:
         monkeypatch.setenv(v, "1")
     for im, jm in ((65, 49), (128, 96)):
         a = make_case("seamount", im, jm, 21, dte=6.0, isplit=30)

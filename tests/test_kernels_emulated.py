@@ -148,10 +148,12 @@ FALLBACK_ENV = ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "
                 "POMGPU_REALVERTVL_CELLS")
 
 
-def test_general_kernels_behind_the_fast_paths(monkeypatch):
+@pytest.mark.parametrize("switches", [FALLBACK_ENV, ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL")])
+def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
-    multi-tile runs stay bit-identical too (selected here through the library's developer switches)"""
-    for v in FALLBACK_ENV:
+    multi-tile runs stay bit-identical too (selected here through the library's developer switches); second set:
+    the external substep with advave and the rim cells as kernels of their own (ispadv != 1, mode = 2 take that path)"""
+    for v in switches:
         monkeypatch.setenv(v, "1")
     a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
     oracle_finish_initial(a)

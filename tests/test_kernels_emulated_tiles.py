@@ -330,3 +330,12 @@ def test_wide_halo_mode_with_file_forcing_records():
             if not np.array_equal(g.field(n)[..., jo:jo + jm, io:io + im][..., sl_j, sl_i], st.field(n)[..., :jm, :im][..., sl_j, sl_i]):
                 bad.append((r, n))
     assert not bad, bad[:12]
+
+
+def test_reference_shaped_kernels_under_the_library_exchange(monkeypatch):
+    """the tile shortcuts switched off one level down: advct as its three kernels with whole-array exchanges, advq
+    with its flux exchange, the production term as a full-array kernel -- still through pomgpu_set_transport"""
+    for v in ("POMGPU_ADVCT_SPLIT", "POMGPU_ADVQ_EXCHANGE", "POMGPU_PROD_FULL"):
+        monkeypatch.setenv(v, "1")
+    out = run_tiles(2, 2, {}, library_exchange=True)
+    compare_with_single_tile(out, {})
