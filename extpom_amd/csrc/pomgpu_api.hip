@@ -370,6 +370,7 @@ static void refresh_coefs(pomgpu_ctx *c) {
   launch_coef_eta(c);
 }
 #define SLOTCHK(c, s, n) if (!(c) || (s) < 0 || (s) >= (n)) return POMGPU_EINVAL; ext_canonical(c); restore_materialize(c)
+static bool wide_travels_every_step(int slot2d);
 extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK2D);
   if (s == P2_fsm || s == P2_dum || s == P2_dvm)               // the kernels fold mask multiplies: 0/1 only, as io_pnetcdf.F derives them
@@ -377,7 +378,7 @@ extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
       if (h[n] != 0. && h[n] != 1.) return fail(c, POMGPU_EINVAL, "mask array (blk2d slot %d) holds a value other than 0/1", s);
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->wide.static_done = 0;
+  if (!wide_travels_every_step(s)) c->wide.static_done = 0;   // e.g. forcing fields uploaded every step are gathered every step anyway
   refresh_coefs(c);
   return POMGPU_OK;
 }
@@ -793,6 +794,11 @@ static const int WIDE_BACK[] = {P2_adx2d, P2_ady2d, P2_advua, P2_advva, P2_elf, 
 static const int WIDE_BD_J[] = {PB_uabw, PB_elw, PB_vabw, PB_uabe, PB_ele, PB_vabe};
 static const int WIDE_BD_I[] = {PB_vabs, PB_els, PB_uabs, PB_vabn, PB_eln, PB_uabn};
 #define NEL(a) ((int)(sizeof(a) / sizeof((a)[0])))
+static bool wide_travels_every_step(int slot2d) {
+  for (int n = 0; n < NEL(WIDE_HALO); n++) if (WIDE_HALO[n] == slot2d) return true;
+  for (int n = 0; n < NEL(WIDE_LOCAL); n++) if (WIDE_LOCAL[n] == slot2d) return true;
+  return false;
+}
 
 struct JobList {
   std::vector<RectJob> jobs;
