@@ -16,7 +16,7 @@ from extpom_amd.cases import finish_initial, make_case
 from extpom_amd.halo import DeviceHalo, Halo
 from extpom_amd.layout import BLK2D, BLK3D
 
-IM, JM, KB, STEPS = 97, 61, 16, 3
+IM, JM, KB, STEPS = 97, 61, 16, int(os.environ.get("POM_TILES_STEPS", "3"))    # POM_TILES_STEPS: longer soak runs
 SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
 
 
