@@ -496,14 +496,80 @@ __global__ void k_ext_update(KP P) {
                   (acc && j >= 2) ? F2(elf, i, j - 1) : 0.);
 }
 
-// advua(i,j), advva(i,j) of solver.f:16-121 from memory, any cell of the tile (zero outside 2..imm1 x 2..jmm1) -- as k_advave_fused
-__device__ __forceinline__ void advave_at(const KP &P, int i, int j, double &au, double &av) {
-  au = av = 0.;
-  if (i < 2 || i > P.imm1 || j < 2 || j > P.jmm1) return;
-  const double tps = advave_tps(P, i, j);
-  au = advave_fu(P, i, j) - advave_fu(P, i - 1, j) + advave_fv(P, i, j + 1, advave_tps(P, i, j + 1)) - advave_fv(P, i, j, tps);   // :65-66
-  const double gu_e = (i + 1 <= P.im) ? advave_gu(P, i + 1, j, advave_tps(P, i + 1, j)) : 0.;
-  av = gu_e - advave_gu(P, i, j, tps) + advave_gv(P, i, j) - advave_gv(P, i, j - 1);                                          // :116-117
+// ---- branch-free forms for the rim cells of the fused substep kernel ------------------------------------------------
+// A rim thread walks elf at three cells, advave, the momentum formulas and the update.  Written with range checks
+// around each piece, every piece's loads wait for the arithmetic of the one before (in-order issue): ~15-20 us of
+// dependent latency that bounds the whole launch on small grids (256x256: 23 us per substep, 14 of them this chain).
+// Here every operand is loaded from a clamped, always valid index and the result selected afterwards, so the loads
+// of all pieces can be in flight together.  Same formulas, same operands where the result is used.
+__device__ __forceinline__ double elf_at_nb(const KP &P, int i, int j) {                     // i or j < 1: 0 (the callers' guards)
+  const bool cell = (i >= 1 && j >= 1);
+  const int ci = i < 1 ? 1 : i, cj = j < 1 ? 1 : j;
+  const int ii = (P.W && ci == 1) ? 2 : ((P.E && ci == P.im) ? P.imm1 : ci);
+  const int jj = (P.S && cj == 1) ? 2 : ((P.N && cj == P.jm) ? P.jmm1 : cj);
+  const bool ok = ii >= 2 && ii <= P.imm1 && jj >= 2 && jj <= P.jmm1 && ci <= P.im && cj <= P.jm;
+  const int si = ok ? ii : 2, sj = ok ? jj : 2;
+  const double v1 = elb_(si, sj) +
+                    P.dte2 * (-(flux_ua(P, si + 1, sj) - flux_ua(P, si, sj) + flux_va(P, si, sj + 1) - flux_va(P, si, sj)) /
+                                  F2(art, si, sj) -
+                              F2(vfluxf, si, sj));
+  const double v2 = F2(elf, ci, cj);
+  const double r = (ok ? v1 : v2) * F2(fsm, ci, cj);
+  return cell ? r : 0.;
+}
+__device__ __forceinline__ double advave_fu_raw(const KP &P, int i, int j) {                 // advave_fu without its range guard
+  double f = .125 * ((d_(i + 1, j) + d_(i, j)) * ua_(i + 1, j) + (d_(i, j) + d_(i - 1, j)) * ua_(i, j)) * (ua_(i + 1, j) + ua_(i, j));
+  f = f - d_(i, j) * 2. * aam2d_(i, j) * (uab_(i + 1, j) - uab_(i, j)) / dx_(i, j);
+  return f * dy_(i, j);
+}
+__device__ __forceinline__ double advave_gv_raw(const KP &P, int i, int j) {                 // advave_gv without its range guard
+  double f = .125 * ((d_(i, j + 1) + d_(i, j)) * va_(i, j + 1) + (d_(i, j) + d_(i, j - 1)) * va_(i, j)) * (va_(i, j + 1) + va_(i, j));
+  f = f - d_(i, j) * 2. * aam2d_(i, j) * (vab_(i, j + 1) - vab_(i, j)) / dy_(i, j);
+  return f * dx_(i, j);
+}
+__device__ __forceinline__ void advave_at_nb(const KP &P, int i, int j, double &au, double &av) {
+  const bool in = (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  const int si = in ? i : 2, sj = in ? j : 2;                 // 2 <= si <= imm1, 2 <= sj <= jmm1
+  const double tps = advave_tps(P, si, sj);
+  const int wi = si >= 3 ? si - 1 : 2, mj = sj >= 3 ? sj - 1 : 2;
+  const double fu_c = advave_fu_raw(P, si, sj), fu_w = si >= 3 ? advave_fu_raw(P, wi, sj) : 0.;                      // fluxua(1,j) = 0
+  const double a = fu_c - fu_w + advave_fv(P, si, sj + 1, advave_tps(P, si, sj + 1)) - advave_fv(P, si, sj, tps);   // :65-66
+  const double gv_c = advave_gv_raw(P, si, sj), gv_s = sj >= 3 ? advave_gv_raw(P, si, mj) : 0.;                      // fluxva(i,1) = 0
+  const double b = advave_gu(P, si + 1, sj, advave_tps(P, si + 1, sj)) - advave_gu(P, si, sj, tps) + gv_c - gv_s;   // :116-117
+  au = in ? a : 0.;
+  av = in ? b : 0.;
+}
+// uvaf_cell with the advance.f formulas evaluated at a clamped cell and selected; the open-boundary branches as they are
+__device__ __forceinline__ void uvaf_cell_nb(const KP &P, int i, int j, double ec, double ew, double es, double adu, double adv, double &uo,
+                                             double &vo) {
+  const bool jin = (j >= 2 && j <= P.jmm1), iin = (i >= 2 && i <= P.imm1);
+  const bool ucalc = (i >= 2 && i <= P.im && jin), vcalc = (iin && j >= 2 && j <= P.jm);
+  const double u0 = F2(uaf, i, j), v0 = F2(vaf, i, j);
+  const double u1 = uaf_interior(P, ucalc ? i : 2, ucalc ? j : 2, ec, ew, adu);
+  const double v1 = vaf_interior(P, vcalc ? i : 2, vcalc ? j : 2, ec, es, adv);
+  double u = ucalc ? u1 : u0, v = vcalc ? v1 : v0;
+  if (P.W && jin && (i == 1 || i == 2)) {                                                 // :47-53
+    if (i == 1) v = BD1(vabw, j);
+    u = BD1(uabw, j) - P.rfw * sqrt(P.grav / d_(2, j)) * (el_(2, j) - BD1(elw, j));
+    u = P.ramp * u;
+  }
+  if (P.E && jin && i == P.im) {                                                          // :56-61
+    u = BD1(uabe, j) + P.rfe * sqrt(P.grav / d_(P.imm1, j)) * (el_(P.imm1, j) - BD1(ele, j));
+    u = P.ramp * u;
+    v = BD1(vabe, j);
+  }
+  if (P.S && iin && (j == 1 || j == 2)) {                                                 // :64-70
+    if (j == 1) u = BD1(uabs, i);
+    v = BD1(vabs, i) - P.rfs * sqrt(P.grav / d_(i, 2)) * (el_(i, 2) - BD1(els, i));
+    v = P.ramp * v;
+  }
+  if (P.N && iin && j == P.jm) {                                                          // :73-78
+    v = BD1(vabn, i) + P.rfn * sqrt(P.grav / d_(i, P.jmm1)) * (el_(i, P.jmm1) - BD1(eln, i));
+    v = P.ramp * v;
+    u = BD1(uabn, i);
+  }
+  uo = u;
+  vo = v;
 }
 // the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells.
 // fuse_adv: advua, advva are formed here (advave is part of this substep's kernel) instead of read
@@ -516,11 +582,16 @@ __device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, in
     if (ncol <= 0 || q >= 3 * ncol) return;
     const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
   }
-  const double ec = elf_at(P, i, j), ew = i >= 2 ? elf_at(P, i - 1, j) : 0., es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
-  double u, v, adu, adv;
-  if (fuse_adv) advave_at(P, i, j, adu, adv);
-  else { adu = F2(advua, i, j); adv = F2(advva, i, j); }
-  uvaf_cell(P, i, j, 1, ec, ew, es, adu, adv, u, v);
+  double ec, ew, es, u, v, adu, adv;
+  if (fuse_adv) {                                           // the fused kernel's rim: branch-free forms, loads in flight together
+    ec = elf_at_nb(P, i, j); ew = elf_at_nb(P, i - 1, j); es = elf_at_nb(P, i, j - 1);
+    advave_at_nb(P, i, j, adu, adv);
+    uvaf_cell_nb(P, i, j, ec, ew, es, adu, adv, u, v);
+  } else {
+    ec = elf_at(P, i, j); ew = i >= 2 ? elf_at(P, i - 1, j) : 0.; es = j >= 2 ? elf_at(P, i, j - 1) : 0.;
+    adu = F2(advua, i, j); adv = F2(advva, i, j);
+    uvaf_cell(P, i, j, 1, ec, ew, es, adu, adv, u, v);
+  }
   u = u * F2(dum, i, j);
   v = v * F2(dvm, i, j);
   if (store_f) {
