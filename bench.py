@@ -365,6 +365,9 @@ def main():
                               "algorithmic_GBps": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
                               "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
             "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
+            # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what
+            # the message rounds and the waiting for neighbours cost
+            "kernel_ms_sum_rank0": round(sum(v[1] for v in prof.values()), 3),
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,
