@@ -346,6 +346,7 @@ def main():
                     "avg_launch_ms": round(tms / nl, 4)}
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
         ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
+        msg_ms = prof.pop("msg_round", (0, 0.0))[1]           # the message rounds of the profiled step (N > 1): not a kernel
         int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
         ext_ms = sum(v[1] for k, v in prof.items() if k.startswith(ext))
         step_gbs = P_STEP * 8.0 * cells / (dt / args.steps) / 1e9
@@ -368,6 +369,7 @@ def main():
             # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what
             # the message rounds and the waiting for neighbours cost
             "kernel_ms_sum_rank0": round(sum(v[1] for v in prof.values()), 3),
+            "message_rounds_ms_rank0": round(msg_ms, 3),          # transfers + waiting for the neighbours, same profiled step
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,

@@ -100,7 +100,14 @@ int pomgpu_tp_move_ptr(pomgpu_ctx *c, const double *const *send, const size_t *s
   pomgpu_transport &T = c->tp;
   if (!T.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport: none set");
   T.rounds++;
-  if (T.fn) { T.fn(T.user, send, scount, recv, rcount); return POMGPU_OK; }
+  // profiling: a round is bracketed like a kernel ("msg_round": transfer time plus the wait for the neighbours)
+  const int slot = c->prof_on ? pomgpu_prof_slot(c, "msg_round") : -1;
+  if (slot >= 0) pomgpu_prof_pre(c);
+  if (T.fn) {
+    T.fn(T.user, send, scount, recv, rcount);
+    if (slot >= 0) pomgpu_prof_post(c, slot);
+    return POMGPU_OK;
+  }
 #ifndef POMGPU_EMU
   RcclComm *r = (RcclComm *)T.rccl;
   if (!r) return pomgpu_fail(c, POMGPU_EINVAL, "transport: no mover");
@@ -116,6 +123,7 @@ int pomgpu_tp_move_ptr(pomgpu_ctx *c, const double *const *send, const size_t *s
     if (T.nbr[f] >= 0 && rcount[f]) e = g_rccl.Recv(recv[f], rcount[f], ncclDouble, T.nbr[f], r->comm, c->stream);
   }
   const ncclResult_t e2 = g_rccl.GroupEnd();
+  if (slot >= 0) pomgpu_prof_post(c, slot);
   if (e == ncclSuccess) e = e2;
   if (e != ncclSuccess) return pomgpu_fail(c, POMGPU_EHIP, "transport: RCCL round failed: %s", g_rccl.GetErrorString(e));
   return POMGPU_OK;

@@ -68,10 +68,11 @@ def main():
     g.sync()
     dt = (time.perf_counter() - t0) / a.steps
     rounds = (g.exchange_rounds() - r0) / a.steps
+    msg = prof.pop("msg_round", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
     print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
                       "wide": bool(wide), "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
-                      "kernel_ms_sum": round(sum(v[2] for v in share), 3),
+                      "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
     g.close()
 
