@@ -339,3 +339,11 @@ def test_reference_shaped_kernels_under_the_library_exchange(monkeypatch):
         monkeypatch.setenv(v, "1")
     out = run_tiles(2, 2, {}, library_exchange=True)
     compare_with_single_tile(out, {})
+
+
+@pytest.mark.parametrize("nml", [dict(mode=2), dict(mode=4), dict(nitera=2)])
+def test_wide_halo_mode_in_the_other_modes(nml):
+    """mode = 2 (2-D only: advave's bottom-stress / curvature branch runs on the extended tile), mode = 4 (no tracer
+    step), two Smolarkiewicz iterations (the general advt2 path with its own exchanges) -- 2x2 seamount tiles"""
+    out = run_tiles(2, 2, nml, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, case="seamount")
+    compare_with_single_tile(out, nml, grid=WIDE_GRID, isplit=WIDE_ISPLIT, case="seamount", min_rounds=1)
