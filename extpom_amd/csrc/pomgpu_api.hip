@@ -1080,7 +1080,17 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
     else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);     // :466-467
     launch_uv_filter(c);                                      // :469-514
-    xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
+    if (lib_x && !getenv("POMGPU_UV_FULL_EXCHANGE")) {
+      // :516-521 exchange all kb levels of ub, u, uf, vb, v, vf.  For u, uf, v, vf the levels 1..kbm1 are redundant: uf, vf
+      // were exchanged at :466-467 and not written since, and u = uf, v = vf are copies.  What is not valid in a ghost
+      // column is their level kb (profu / profv write it on owned columns only).  ub, vb are needed in full: the filter
+      // (:469-509) runs on ghost columns too, but from a u whose western / southern ghost cells missed the depth-mean
+      // correction (:365-393 starts at i = 2, j = 2 and is not followed by an exchange).  2 x kb + 4 planes instead of 6 x kb.
+      const size_t top = (size_t)(P.kb - 1) * P.n2;
+      xch(c, 6, D3(c, ub), P.kb, D3(c, vb), P.kb, D3(c, u) + top, 1, D3(c, uf) + top, 1, D3(c, v) + top, 1, D3(c, vf) + top, 1);
+    } else {
+      xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
+    }
   }
   launch_int_tail(c);                                         // :525-531
   launch_coef_dt(c);                                          // dt changed: refresh the derived coefficients
