@@ -294,9 +294,23 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    # warm-up, then a profiled step to find the dominant kernel
+    # warm-up, then a profiled step to find the dominant kernel.  At N > 1 the first rounds also set up the RCCL
+    # connections; if that never completes (a rank lost, mismatched messages) fail within minutes instead of hanging
+    # the node until the caller's own limit
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def expired():
+            print(f"bench[{rank}]: the first steps did not complete within 300 s -- giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(300.0, expired)
+        watchdog.daemon = True
+        watchdog.start()
     g.run(max(args.warmup, 1))
     barrier()
+    if watchdog:
+        watchdog.cancel()
     g.prof_begin()
     g.run(1)
     prof = g.prof_end()
