@@ -16,7 +16,10 @@ from extpom_amd.cases import finish_initial, make_case
 from extpom_amd.halo import DeviceHalo, Halo
 from extpom_amd.layout import BLK2D, BLK3D
 
-IM, JM, KB, STEPS = 97, 61, 16, int(os.environ.get("POM_TILES_STEPS", "3"))    # POM_TILES_STEPS: longer soak runs
+# POM_TILES_STEPS / POM_TILES_GRID ("384x256x24") / POM_TILES_ISPLIT: longer and larger soak runs
+IM, JM, KB = (int(v) for v in os.environ.get("POM_TILES_GRID", "97x61x16").split("x"))
+STEPS = int(os.environ.get("POM_TILES_STEPS", "3"))
+ISPLIT = int(os.environ.get("POM_TILES_ISPLIT", "10"))
 SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
 
 
@@ -31,7 +34,7 @@ def worker(rank, world, split, port, out, nml):
     nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
-    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=10, **nml)
+    st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=ISPLIT, **nml)
     # kernels and torch's pack/unpack must share ONE stream; torch's default stream has handle 0, which
     # the C ABI reads as "create your own", so make a real stream current and hand that over
     ts = torch.cuda.Stream()
@@ -78,7 +81,7 @@ def main(split, nml, exchange="hook"):
     port = 29700 + (os.getpid() % 200)
     world = 4 if split == "xy" else 2
     mp.spawn(worker, args=(world, split, port, out, dict(nml, _exchange=exchange)), nprocs=world, join=True)
-    g = make_case("island", IM, JM, KB, dte=6.0, isplit=10, **nml)
+    g = make_case("island", IM, JM, KB, dte=6.0, isplit=ISPLIT, **nml)
     oracle_finish_initial(g)
     OracleTile(g).run(STEPS)
     bad = []
