@@ -4,9 +4,12 @@ lateral_viscosity, mode_interaction, isplit external substeps, mode_internal, ch
 
     python bench.py --gpus N --steps K --warmup W [--workload basin2048|seamount256|basin1024|...]
 
-N=1 runs in this process; for N>1 the driver launches one rank per GPU with torch.distributed.run
-and the global grid is split into N tiles (strong scaling: the global grid is fixed).  Rank 0
-prints ONE JSON line.  `value` = im_global*jm_global*kb*K / max-over-ranks wall time of the K timed
+N=1 runs in this process.  N>1: one rank per GPU, the global grid split into N tiles (strong scaling: the
+global grid is fixed) -- either started by the caller under torch.distributed.run (WORLD_SIZE set), or, when
+`python bench.py --gpus N` is called plainly, by this script itself: the parent starts
+`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process before it
+touches the GPU, relays the child's output and exits with its code (reference launch shape: pom.sh:1
+`mpiexec -n 8`, parallel_mpi.f:6-20).  Rank 0 prints ONE JSON line.  `value` = im_global*jm_global*kb*K / max-over-ranks wall time of the K timed
 steps, state resident in HBM before the timed region starts.
 
 Extra objects on the same line:
@@ -220,6 +223,23 @@ def side_config(workload, device, stream, steps=40, warmup=5):
             "step_algorithmic_GBps": round(P_STEP * 8.0 * im * jm * kb / (dt / steps) / 1e9, 1), "error_status": err}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1), pass its output through and return its exit code.  The parent never initialises
+    the GPU, and nothing is re-executed in place."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +258,8 @@ def main():
         v, what, n, dt = _reference_sample(args.workload) if args.reference else _cpu_sample(args.workload)
         print(json.dumps({"value": v, "what": what, "n": n, "seconds": dt}))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))                      # nothing in this process has touched the GPU
 
     import torch
     from extpom_amd import decomp, dist as pdist
@@ -267,6 +289,26 @@ def main():
         stream = ts.cuda_stream
     g = gpu_initialise(st, local, stream)
     exchange = "none"
+    # N > 1: a rank that is lost, or a message round whose partner never posts, would leave the others waiting inside
+    # RCCL for ever.  Every phase -- connecting, the first steps (RCCL sets its channels up lazily), the timed steps --
+    # gets a deadline; a rank that misses one says where it was and leaves with a non-zero code, which ends the job.
+    phase = ["start", None]
+
+    def deadline(name, seconds):
+        import threading
+        if phase[1] is not None:
+            phase[1].cancel()
+            phase[1] = None
+        phase[0] = name
+        if world > 1 and seconds:
+            def expired():
+                print(f"bench[{rank}]: '{name}' did not complete within {seconds:.0f} s -- giving up", file=sys.stderr, flush=True)
+                os._exit(4)
+            phase[1] = threading.Timer(seconds, expired)
+            phase[1].daemon = True
+            phase[1].start()
+
+    deadline("connect", 300.0)
     if world > 1:
         # The library serves every exchange point itself: pack -> one grouped ncclSend/ncclRecv round (RCCL over
         # xGMI, enqueued on the kernels' stream by the library, no Python in the loop) -> unpack; and the 2-D
@@ -279,11 +321,16 @@ def main():
         else:
             if H.connect_rccl(g, tile, rank, world):
                 exchange = "library exchange, native RCCL send/recv on the kernels' stream"
-            else:       # e.g. librccl cannot be opened: torch.distributed's RCCL P2P carries the same messages
+            elif os.environ.get("POM_BENCH_ALLOW_P2P") == "1":   # developer switch: torch.distributed's RCCL P2P carries the same messages
                 print(f"bench[{rank}]: native RCCL transport unavailable; using torch.distributed P2P", file=sys.stderr)
                 bench_halo = H.DeviceHalo(g, tile, dev)
                 g.set_order_exchange(H.Halo(tile).device_order_hook(dev))   # npg = 2 only
                 exchange = "torch.distributed batch_isend_irecv (RCCL) per exchange point"
+            else:
+                # a scaling number measured on a silent substitute would be worthless: no line, non-zero exit
+                print(f"bench[{rank}]: the library's RCCL transport could not connect the {world} ranks -- no measurement",
+                      file=sys.stderr, flush=True)
+                sys.exit(5)
         if exchange.startswith("library") and os.environ.get("POM_BENCH_WIDE", "1") != "0":
             tiles = [pdist.tile_for_rank(r, world, im, jm) for r in range(world)]
             if g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles)):
@@ -295,22 +342,11 @@ def main():
             torch.distributed.barrier()
 
     # warm-up, then a profiled step to find the dominant kernel.  At N > 1 the first rounds also set up the RCCL
-    # connections; if that never completes (a rank lost, mismatched messages) fail within minutes instead of hanging
-    # the node until the caller's own limit
-    watchdog = None
-    if world > 1:
-        import threading
-
-        def expired():
-            print(f"bench[{rank}]: the first steps did not complete within 300 s -- giving up", file=sys.stderr, flush=True)
-            os._exit(4)
-        watchdog = threading.Timer(300.0, expired)
-        watchdog.daemon = True
-        watchdog.start()
+    # connections
+    deadline("warm-up steps", 300.0)
     g.run(max(args.warmup, 1))
     barrier()
-    if watchdog:
-        watchdog.cancel()
+    deadline("profiled step", 120.0)
     g.prof_begin()
     g.run(1)
     prof = g.prof_end()
@@ -322,6 +358,7 @@ def main():
     # the timed region: exactly K steps, only the dominant kernel bracketed by events
     g.prof_begin(only=None if args.profile_all else dom)
     barrier()
+    deadline("timed steps", 120.0 + 2.0 * args.steps)          # generous: a step takes tens of milliseconds
     rounds0 = g.exchange_rounds()
     t0 = time.perf_counter()
     g.run(args.steps)
@@ -330,6 +367,7 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     timed = g.prof_end()
+    deadline("wrap-up", 300.0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -410,6 +448,7 @@ def main():
         g.close()
     if world > 1:
         torch.distributed.barrier()
+        deadline("done", 0)
         torch.distributed.destroy_process_group()
 
 

@@ -1143,7 +1143,7 @@ static void launch_proft_reg(pomgpu_ctx *c, double *f, const double *wfsurf, con
 }
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   const int kb = c->P.kb;
-  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64) LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
   else if (kb <= 24) launch_proft_reg<24>(c, f, wfsurf, fsurf, nbc);
   else if (kb <= 32) launch_proft_reg<32>(c, f, wfsurf, fsurf, nbc);
   else if (kb <= 40) launch_proft_reg<40>(c, f, wfsurf, fsurf, nbc);

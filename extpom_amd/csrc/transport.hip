@@ -135,6 +135,18 @@ int pomgpu_tp_move(pomgpu_ctx *c, const size_t *scount, const size_t *rcount) {
   return pomgpu_tp_move_ptr(c, c->tp.send, scount, c->tp.recv, rcount);
 }
 
+// Can this process open librccl and find every entry point the transport uses?  Touches no GPU and no other rank:
+// hosts all-gather the answer BEFORE anyone enters the collective ncclCommInitRank, so that no rank waits there for
+// one that could not even load the library.
+extern "C" int pomgpu_rccl_available(const char *librccl_path) {
+#ifndef POMGPU_EMU
+  return rccl_load(librccl_path) ? POMGPU_ENODEV : POMGPU_OK;
+#else
+  (void)librccl_path;
+  return POMGPU_ENODEV;
+#endif
+}
+
 extern "C" int pomgpu_rccl_unique_id(void *id128, const char *librccl_path) {
 #ifndef POMGPU_EMU
   if (!id128) return POMGPU_EINVAL;

@@ -306,26 +306,20 @@ def rccl_library_path():
 
 def connect_rccl(gpu, tile, rank, world, group=None) -> bool:
     """pomgpu_rccl_init on every rank: rank 0 draws the unique id, torch.distributed (any backend) carries it.
-    Collective and all-or-nothing: returns False on EVERY rank if any rank could not open librccl or join the
-    communicator (the caller then installs another exchange), so that no rank waits for one that gave up."""
+    Two collective steps.  (1) Every rank checks that it can open librccl and find the entry points
+    (pomgpu_rccl_available: no GPU call, nothing collective) and the answers are all-gathered: if any rank cannot, ALL
+    return False before anyone has entered ncclCommInitRank -- a rank that failed there would leave the others waiting
+    inside the collective for ever.  (2) ncclCommInitRank itself; a failure in it cannot be undone rank by rank, so it
+    raises (the caller's deadline, bench.py, ends the job if a partner never arrives)."""
     lib = rccl_library_path()
-    box = [None]
-    if rank == 0:
-        try:
-            box[0] = gpu.rccl_unique_id(lib)
-        except Exception as e:               # noqa: BLE001 -- reported, then every rank falls back together
-            print(f"connect_rccl: {e}", flush=True)
-    dist.broadcast_object_list(box, src=0, group=group)
-    ok = box[0] is not None
-    if ok:
-        try:
-            gpu.rccl_init(tile, box[0], rank, world, lib)
-        except Exception as e:               # noqa: BLE001
-            print(f"connect_rccl[{rank}]: {e}", flush=True)
-            ok = False
-    oks = [None] * world
-    dist.all_gather_object(oks, ok, group=group)
-    if not all(oks):
-        gpu.clear_transport()
+    can = gpu.L.pomgpu_rccl_available(lib.encode() if lib else None) == 0
+    cans = [None] * world
+    dist.all_gather_object(cans, bool(can), group=group)
+    if not all(cans):
+        if rank == 0:
+            print(f"connect_rccl: librccl unusable on ranks {[r for r, c in enumerate(cans) if not c]}", flush=True)
         return False
+    box = [gpu.rccl_unique_id(lib) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    gpu.rccl_init(tile, box[0], rank, world, lib)
     return True

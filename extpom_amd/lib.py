@@ -65,6 +65,7 @@ _SIGS = {
     "pomgpu_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
     "pomgpu_set_order_exchange": (_I, [_P, ORDER_FN, _P]),
     "pomgpu_set_transport": (_I, [_P, ctypes.POINTER(_I), TRANSPORT_FN, _P]),
+    "pomgpu_rccl_available": (_I, [ctypes.c_char_p]),
     "pomgpu_rccl_unique_id": (_I, [_P, ctypes.c_char_p]),
     "pomgpu_rccl_init": (_I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.c_char_p]),
     "pomgpu_exchange_rounds": (ctypes.c_long, [_P]),

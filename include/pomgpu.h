@@ -157,6 +157,7 @@ int pomgpu_halo_unpack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int 
 typedef void (*pomgpu_transport_fn)(void *user, const double *const *send, const size_t *scount, double *const *recv,
                                     const size_t *rcount);
 int pomgpu_set_transport(pomgpu_ctx *ctx, const int *neighbours8, pomgpu_transport_fn fn, void *user);
+int pomgpu_rccl_available(const char *librccl_path);   /* POMGPU_OK if librccl opens and has every entry point; no GPU call, not collective */
 int pomgpu_rccl_unique_id(void *id128, const char *librccl_path);
 int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, const int *neighbours8,
                      const char *librccl_path);

@@ -23,3 +23,10 @@ def golden():
 def golden_planes():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "seamount_65x49x21_planes.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_kb50():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "kb50_256x192x50.json")) as f:
+        return json.load(f)

@@ -1,8 +1,8 @@
-"""Generates tests/golden/seamount_65x49x21.json (+ .npz planes) by running the REFERENCE itself
+"""Generates tests/golden/seamount_65x49x21.json (+ .npz planes) and tests/golden/kb50_256x192x50.json by running the REFERENCE itself
 (oracle/_ref/libpomref_65x49x21.so, built from the unmodified sources by oracle/build_ref.sh) on
 the inputs of extpom_amd.cases.  Run from the repo root in a container that has /root/reference:
 
-    oracle/build_ref.sh 65 49 21 && python tests/golden/make_golden.py
+    oracle/build_ref.sh 65 49 21 && oracle/build_ref.sh 256 192 50 && python tests/golden/make_golden.py [kb50]
 
 The fixture holds, per configuration and checkpoint step, the SHA-256 of every restart-list field
 (the prognostic state, reference io_pnetcdf.F:1724-1886) exactly as the reference left it in its
@@ -45,7 +45,23 @@ def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype="<f8").tobytes()).hexdigest()
 
 
+# kb = 50: the level count of the benchmarked grid (2048x1536x50), i.e. the <50> instantiations of the register-resident
+# column kernels; reference build oracle/_ref/libpomref_256x192x50.so (oracle/build_ref.sh 256 192 50)
+CONFIGS_KB50 = {
+    "basin50_default": ("basin", dict(dte=6.0, isplit=30), [1, 3]),
+    "basin50_nadv1": ("basin", dict(dte=6.0, isplit=30, nadv=1), [3]),
+    "basin50_npg2": ("basin", dict(dte=6.0, isplit=30, npg=2), [3]),
+    "seamount50_default": ("seamount", dict(dte=6.0, isplit=30), [3]),
+}
+
+
 def main():
+    if "kb50" not in sys.argv[1:]:
+        generate(65, 49, 21, CONFIGS, PLANES, "seamount_65x49x21")
+    generate(256, 192, 50, CONFIGS_KB50, {}, "kb50_256x192x50")
+
+
+def generate(IM, JM, KB, CONFIGS, PLANES, stem):
     out = {"grid": [IM, JM, KB], "fields": RESTART_2D + RESTART_3D, "configs": {}}
     planes = {}
     for name, (case, nml, checkpoints) in CONFIGS.items():
@@ -68,10 +84,15 @@ def main():
         out["configs"][name] = cfg
         print(name, "done", flush=True)
     here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "seamount_65x49x21.json"), "w") as f:
+    with open(os.path.join(here, stem + ".json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    np.savez_compressed(os.path.join(here, "seamount_65x49x21_planes.npz"), **planes)
+    if planes:
+        np.savez_compressed(os.path.join(here, stem + "_planes.npz"), **planes)
 
 
 if __name__ == "__main__":
-    main()
+    import threading
+    threading.stack_size(1 << 30)       # the reference's automatic (im,jm,kb) arrays live on the caller's stack
+    t = threading.Thread(target=main)
+    t.start()
+    t.join()

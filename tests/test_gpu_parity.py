@@ -346,3 +346,135 @@ def test_restart_and_determinism_properties_1024x1024x40():
     ge.run(1)
     ge.download()
     assert not diff(c, e), diff(c, e)
+
+
+# ---- the instantiations bench.py runs: kb = 50 and 2048-wide rows ---------------------------------------------------
+@pytest.mark.parametrize("name", ["basin50_default", "basin50_nadv1", "basin50_npg2", "seamount50_default"])
+def test_gpu_reproduces_reference_digests_kb50(golden_kb50, name):
+    """256x192x50: the <50> instantiations of k_proft_reg / k_profuv_reg / k_uv_filter_reg / k_int_uvmean_reg (what the
+    2048x1536x50 bench dispatches) against digests of the REFERENCE's own state (oracle/_ref/libpomref_256x192x50.so,
+    tests/golden/make_golden.py kb50)"""
+    OracleTile, oracle_finish_initial = _oracle()
+    cfg = golden_kb50["configs"][name]
+    im, jm, kb = golden_kb50["grid"]
+    st = make_case(cfg["case"], im, jm, kb, **cfg["nml"])
+    oracle_finish_initial(st)
+    bad = [f for f in golden_kb50["fields"] if _digest(st.field(f)) != cfg["init"][f]]
+    assert not bad, f"{name}: initial state: {bad}"
+    g = _gpu(st)
+    done = 0
+    for step in sorted(int(s) for s in cfg["steps"]):
+        g.run(step - done)
+        done = step
+        g.download()
+        bad = [f for f in golden_kb50["fields"] if _digest(st.field(f)) != cfg["steps"][str(step)][f]]
+        assert not bad, f"{name}: step {step}: {bad} differ from the reference"
+    g.close()
+    assert st.error_status == 0
+
+
+@pytest.mark.parametrize("case,kb,nml", [("basin", 50, {}), ("basin", 50, dict(nadv=1)), ("basin", 50, dict(npg=2)), ("island", 50, {}),
+                                         ("basin", 5, {}), ("basin", 6, {}), ("seamount", 7, {}), ("seamount", 24, {}), ("basin", 25, {}), ("seamount", 32, {}),
+                                         ("basin", 33, {}), ("basin", 40, {}), ("seamount", 41, {}), ("seamount", 44, {}), ("basin", 45, {}), ("seamount", 56, {}), ("basin", 57, {}),
+                                         ("seamount", 64, {})])
+def test_every_register_kernel_instantiation_matches_oracle(case, kb, nml):
+    """ALL fields after 3 steps array_equal to the oracle at the level counts either side of every template bound of
+    the register-resident column kernels (k_vert.hip launchers: 24, 32, 40, 44, 50, 56, 64) and at the smallest kb they take"""
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case(case, 64, 48, kb, dte=6.0, isplit=30, **nml)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(3)
+    g = _gpu(b)
+    g.run(3)
+    g.download()
+    g.close()
+    assert not diff(a, b), (case, kb, nml, diff(a, b))
+
+
+@pytest.mark.parametrize("case,im,jm,kb", [("basin", 2048, 24, 12), ("seamount", 2050, 20, 50), ("basin", 2047, 16, 8)])
+def test_wide_rows_band_geometry_matches_oracle(case, im, jm, kb):
+    """iml >= 2047: the launch geometry of the bench grid's rows (set_band_geometry picks 4-row bands, 33-34 workgroups
+    per block-row in HALO_XCD_DECODE), all fields after 2 steps array_equal to the oracle"""
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case(case, im, jm, kb, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(2)
+    g = _gpu(b)
+    g.run(2)
+    g.download()
+    g.close()
+    assert not diff(a, b), diff(a, b)
+
+
+def test_100_internal_steps_256x192x50_within_1e_10():
+    """north_star's 1e-10 bar on a grid with the bench's level count: 100 internal steps (3000 external) of the basin
+    case at 256x192x50 against the oracle; observed difference is zero"""
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("basin", 256, 192, 50, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(100)
+    g = _gpu(b)
+    g.run(100)
+    g.download()
+    g.close()
+    r = reldiff(a, b, PROGNOSTIC)
+    assert max(r.values()) <= 1e-10, r
+    assert not diff(a, b), diff(a, b)
+    assert a.error_status == b.error_status == 0
+
+
+def test_config4_2048x1536x50_full_size():
+    """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU: (i) ONE step, every field
+    array_equal to the oracle (about a minute of CPU), (ii) the restart property: the device's second step equals a
+    second step started from the ORACLE's first-step state uploaded into a fresh context, (iii) two contexts fed the
+    same state produce the same bits, (iv) land stays masked, nothing non-finite.  ~50 GB per host copy of the state."""
+    import os
+    import time
+    OracleTile, oracle_finish_initial = _oracle()
+    os.makedirs("gpurun_out", exist_ok=True)
+    t0 = time.time()
+
+    def beat(msg):                                   # the GPU box's watchdog looks for signs of life under gpurun_out/
+        with open("gpurun_out/fullsize_progress.log", "a") as f:
+            f.write(f"{time.time() - t0:7.1f} s  {msg}\n")
+
+    a = make_case("basin", 2048, 1536, 50, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    beat("case built")
+    c = a.copy()
+    ga = _gpu(a)
+    ga.run(1)
+    ga.download()
+    beat("device step 1 downloaded")
+    OracleTile(c).run(1)
+    beat("oracle step 1 done")
+    bad = diff(a, c)
+    assert not bad, f"step 1 differs from the oracle: {bad}"
+    beat("step 1 compared")
+    ga.run(1)
+    ga.download()
+    gc = _gpu(c)                                     # the oracle's state after one step, uploaded
+    gc.run(1)
+    gc.download()
+    beat("step 2 both ways")
+    bad = diff(a, c)
+    assert not bad, f"restart property: {bad}"
+    ga.run(1)
+    gc.run(1)
+    ga.download()
+    gc.download()
+    ga.close()
+    gc.close()
+    bad = diff(a, c)
+    assert not bad, f"two contexts, same state, different bits: {bad}"
+    beat("step 3 compared")
+    for f in PROGNOSTIC + ["q2", "km", "rho", "w"]:
+        assert np.isfinite(a.field(f)).all(), f
+    for f in ("t", "s", "el", "et"):
+        x = a.field(f)
+        assert not np.any((x if x.ndim == 2 else x[:49]) * (1.0 - a.fsm)), f
+    assert a.error_status == c.error_status == 0
+    beat("done")

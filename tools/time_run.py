@@ -12,4 +12,4 @@ st = bench.build_state(wl, tile)
 g = bench.gpu_initialise(st, 0, None)
 g.run(5); g.sync()
 t0 = time.perf_counter(); g.run(n); g.sync(); dt = time.perf_counter() - t0
-print(f"{wl}: {dt / n * 1e3:.3f} ms/step over {n} steps  ({im * jm * kb * n / dt:.3e} cell-updates/s)  graph={'off' if os.environ.get('POMGPU_NO_GRAPH') else 'on'}")
+print(f"{wl}: {dt / n * 1e3:.3f} ms/step over {n} steps  ({im * jm * kb * n / dt:.3e} cell-updates/s)")
