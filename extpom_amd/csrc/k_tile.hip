@@ -69,27 +69,28 @@ struct FaceT { double adv, dif; };
 // coefficients are read once for both fields.
 struct TFields { const double *fb[2], *f[2], *fcl[2]; double *ff[2]; };
 template <int NF> struct LevT { double fb_c[NF], fb_s[NF], fb_n[NF], fc_c[NF], fc_s[NF], fc_n[NF], am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
+template <int NF> struct BufT { BufA fb[NF], fcl[NF], ff[NF], aam, u, v, w; };
 // every load of a level is issued here, in one batch, BEFORE the level that is being computed
 // needs anything: vmcnt counts in order, so a load issued in the middle of the arithmetic would
-// make the wave wait for the whole prefetch batch of the next level
-template <int NF> __device__ __forceinline__ LevT<NF> advt2_load(const KP &P, const TFields &A, int i, int js, int j, int jn, int k) {
-  LevT<NF> L;
+// make the wave wait for the whole prefetch batch of the next level.
+// oc / os / on: byte offsets of the cell and its southern / northern neighbour inside a level, lv: the level's
+// byte offset -- buffer addressing, see pomgpu_internal.hpp
+template <int NF> __device__ __forceinline__ void advt2_load(LevT<NF> &L, const BufT<NF> &B, unsigned oc, unsigned os, unsigned on, unsigned lv) {
 #pragma unroll
   for (int f = 0; f < NF; f++) {
-    L.fb_c[f] = G3(A.fb[f], i, j, k);  L.fb_s[f] = G3(A.fb[f], i, js, k);  L.fb_n[f] = G3(A.fb[f], i, jn, k);
-    L.fc_c[f] = G3(A.fcl[f], i, j, k); L.fc_s[f] = G3(A.fcl[f], i, js, k); L.fc_n[f] = G3(A.fcl[f], i, jn, k);
+    L.fb_c[f] = bld(B.fb[f], oc, lv);  L.fb_s[f] = bld(B.fb[f], os, lv);  L.fb_n[f] = bld(B.fb[f], on, lv);
+    L.fc_c[f] = bld(B.fcl[f], oc, lv); L.fc_s[f] = bld(B.fcl[f], os, lv); L.fc_n[f] = bld(B.fcl[f], on, lv);
   }
-  L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
-  L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
-  L.w_c = F3(w, i, j, k);
-  return L;
+  L.am_c = bld(B.aam, oc, lv); L.am_s = bld(B.aam, os, lv); L.am_n = bld(B.aam, on, lv);
+  L.u_c = bld(B.u, oc, lv);    L.v_c = bld(B.v, oc, lv);    L.v_n = bld(B.v, on, lv);
+  L.w_c = bld(B.w, oc, lv);
 }
-struct CoefT { double cm, hs, msk, ds_num, ds_den; };   // mass-flux coefficient, h sum, mask, metric sums of one face
+struct CoefT { double cm, hs, msk, ds_num; InvD den; };   // mass-flux coefficient, h sum, mask, metric sums of one face
 __device__ __forceinline__ CoefT coef_x(const KP &P, int i, int j) {
-  CoefT c; c.cm = K2(CMX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.ds_num = K2(DYSX, i, j); c.ds_den = K2(DXSX, i, j); return c;
+  CoefT c; c.cm = K2(CMX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.ds_num = K2(DYSX, i, j); c.den = inv_of(K2(DXSX, i, j)); return c;
 }
 __device__ __forceinline__ CoefT coef_y(const KP &P, int i, int j) {
-  CoefT c; c.cm = K2(CMY, i, j); c.hs = K2(HSY, i, j); c.msk = F2(dvm, i, j); c.ds_num = K2(DXSY, i, j); c.ds_den = K2(DYSY, i, j); return c;
+  CoefT c; c.cm = K2(CMY, i, j); c.hs = K2(HSY, i, j); c.msk = F2(dvm, i, j); c.ds_num = K2(DXSY, i, j); c.den = inv_of(K2(DYSY, i, j)); return c;
 }
 // face between a "lo" cell (west / south) and a "hi" cell; vel = u or v on that face
 __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double vel, double fb_hi, double fb_lo, double fc_hi,
@@ -97,7 +98,7 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   FaceT f;
   f.adv = upw_(c.cm * vel, fb_lo, fb_hi);
   const double am = 0.5 * (am_hi + am_lo);
-  f.dif = -am * c.hs * P.tprni * ((fb_hi - fc_hi) - (fb_lo - fc_lo)) * c.msk * c.ds_num * 0.5 / c.ds_den;
+  f.dif = divi(-am * c.hs * P.tprni * ((fb_hi - fc_hi) - (fb_lo - fc_lo)) * c.msk * c.ds_num * 0.5, c.den);
   return f;
 }
 template <int NF>
@@ -116,19 +117,27 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
   const double fsm = F2(fsm, i, j);
   // column-resident coefficients of the west, south and north faces and of the cell
   const CoefT cw = coef_x(P, i, j), cs = coef_y(P, i, j), cn = coef_y(P, i, jn);
-  const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
+  const double art = F2(art, i, j), hea = K2(HEA, i, j);
+  const InvD hfa = inv_of(K2(HFA, i, j));
+  BufT<NF> B;
+#pragma unroll
+  for (int f = 0; f < NF; f++) { B.fb[f] = BUF3(A.fb[f]); B.fcl[f] = BUF3(A.fcl[f]); B.ff[f] = BUF3(A.ff[f]); }
+  B.aam = BUF3(A3(aam)); B.u = BUF3(A3(u)); B.v = BUF3(A3(v)); B.w = BUF3(A3(w));
+  const unsigned oc = BOFF2(i, j), os = BOFF2(i, js), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
   double f1[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) f1[f] = G3(A.f[f], i, j, 1);
   const int kbm1 = P.kbm1;
-  LevT<NF> cur = advt2_load<NF>(P, A, i, js, j, jn, 1), nxt = cur;
   // carried from level L-1 to its completion in iteration L
   double p_adv[NF], p_dif[NF], p_fb[NF], p_zu[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) p_adv[f] = p_dif[f] = p_fb[f] = p_zu[f] = 0.;
-  for (int L = 1; L <= kbm1 + 1; L++) {
-    if (L + 1 <= kbm1) nxt = advt2_load<NF>(P, A, i, js, j, jn, L + 1);            // in flight during this iteration
+  // one iteration: issue the loads of level L+1 into `nxt`, evaluate the faces of level L from `cur`, finish level L-1
+  auto step = [&](const int L, const LevT<NF> &cur, LevT<NF> &nxt) {
+    if (L + 1 <= kbm1) advt2_load<NF>(nxt, B, oc, os, on, (unsigned)L * lvb);       // in flight during this iteration
     const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
+    InvD dzk; dzk.b = dzk.y = 0.;
+    if (L >= 2) { dzk.b = F1(dz, L - 1); dzk.y = P.r1[(size_t)P1_dz * P.kb + (L - 2)]; }
 #pragma unroll
     for (int f = 0; f < NF; f++) {
       const double ffk = (L >= 2 && !in && icol) ? G3(A.ff[f], i, j, L - 1) : 0.;
@@ -152,21 +161,27 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
         zu = (L == 1) ? cur.w_c * f1[f] * art : upw_(cur.w_c, cur.fb_c[f], p_fb[f]) * art;    // :646-662
       }
       if (L >= 2 && icol) {                                 // finish level L-1: its bottom face is this level's top face
-        const int k = L - 1;
         double r;
         if (in) {
-          r = p_adv[f] + (p_zu[f] - zu) / F1(dz, k);                                          // :670-672
-          r = (p_fb[f] * hea - P.dti2 * r) / hfa;                                             // :673-674
+          r = p_adv[f] + divi(p_zu[f] - zu, dzk);                                             // :670-672
+          r = divi(p_fb[f] * hea - P.dti2 * r, hfa);                                          // :673-674
           r = r * fsm;                                                                        // :1899
-          r = r - P.dti2 * p_dif[f] / hfa;                                                    // :721-723
+          r = r - divi(P.dti2 * p_dif[f], hfa);                                               // :721-723
         } else {
           r = ffk * fsm;                                                                      // :1899 (rim cells)
         }
-        G3(A.ff[f], i, j, k) = r;
+        bst(B.ff[f], oc, (unsigned)(L - 2) * lvb, r);
       }
       p_adv[f] = s_adv; p_dif[f] = s_dif; p_fb[f] = cur.fb_c[f]; p_zu[f] = zu;
     }
-    cur = nxt;
+  };
+  // two register sets take turns as "current" and "next" level: no copy between iterations
+  LevT<NF> ra, rb;
+  advt2_load<NF>(ra, B, oc, os, on, 0u);
+  rb = ra;
+  for (int L = 1; L <= kbm1 + 1; L += 2) {
+    step(L, ra, rb);
+    if (L + 1 <= kbm1 + 1) step(L + 1, rb, ra);
   }
   if (icol) {
 #pragma unroll

@@ -24,6 +24,7 @@ struct KP {
   int W, E, S, N;            // 1 where the tile edge is a physical boundary (n_west == -1 ...)
   size_t n2, n3;
   double *b1, *b2, *b3, *bd; // device mirrors of blk1d, blk2d, blk3d, bdry
+  double *r1;                // 1.0 / b1 element by element (k_coef_static): reciprocals of dz, dzz for divi()
   double *s3[POMGPU_NSCR3];
   double *s2[POMGPU_NSCR2];
   double *c2[POMGPU_NCOEF2]; // derived 2-D coefficient arrays (enum pomgpu_coef2), see k_tile.hip
@@ -140,6 +141,63 @@ template <class F> __device__ __forceinline__ double halo_e(double x, F) { retur
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #define HALO_LANE (int)((blockIdx.x * blockDim.x + threadIdx.x) & 63)
+
+// ---- buffer addressing for the column kernels ---------------------------------------------------------------------
+// A column kernel reads the same cell of ~10 arrays at every level.  With plain pointers the compiler keeps one
+// 64-bit address per (array, row) in VGPRs and advances each of them every level (PMC / ISA of k_advt2_col<2>: 44
+// v_lshl_add_u64 per level out of 445 instructions, ~40 VGPRs of addresses).  Buffer loads split the address the way
+// the data is laid out: a resource descriptor per array (4 SGPRs, constant), a per-lane byte offset of the cell inside
+// a level (one VGPR per row used, constant for the whole column) and the level's byte offset as the scalar offset
+// (one SGPR shared by ALL arrays, advanced by the scalar unit).  No vector instruction is spent on addresses.
+// Offsets are 32 bits: a 3-D array must stay below 4 GiB (checked in pomgpu_create).
+#ifndef POMGPU_EMU
+typedef unsigned int pomgpu_u32x2 __attribute__((ext_vector_type(2)));
+struct BufA { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ BufA buf_of(const double *p, size_t doubles) {
+  BufA b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (unsigned)(doubles * 8), 0x00020000);   // raw buffer, no swizzle
+  return b;
+}
+__device__ __forceinline__ double bld(const BufA &b, unsigned voff, unsigned soff) {
+  const pomgpu_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void bst(const BufA &b, unsigned voff, unsigned soff, double x) {
+  pomgpu_u32x2 v;
+  v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
+}
+#else
+struct BufA { double *p; };
+static inline BufA buf_of(const double *p, size_t) { BufA b; b.p = (double *)p; return b; }
+static inline double bld(const BufA &b, unsigned voff, unsigned soff) { return b.p[((size_t)voff + soff) >> 3]; }
+static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { b.p[((size_t)voff + soff) >> 3] = x; }
+#endif
+#define BUF3(p) buf_of((p), P.n3)
+#define BOFF2(i, j) (unsigned)(((unsigned)((j)-1) * (unsigned)P.iml + (unsigned)((i)-1)) * 8u)   /* byte offset of (i,j) inside a level */
+
+// ---- division by a divisor that does not change along the column ---------------------------------------------------
+// a / b is the reference's operation (IEEE, correctly rounded); the GPU's macro for it is ~10 instructions, several of
+// them slow (v_div_scale x2, v_rcp_f64, 5 fma, v_div_fmas, v_div_fixup).  The column kernels divide by the same
+// metric sums at every level.  With y = RN(1/b) formed once (by a real division) the correctly rounded quotient is
+//   q0 = RN(a*y); r0 = a - b*q0 (exact in one fma); q1 = RN(q0 + r0*y)   -- faithful (within one ulp of a/b)
+//   r1 = a - b*q1 (exact);                        q  = RN(q1 + r1*y)   -- = RN(a/b): Markstein's theorem (y correctly
+// rounded, q1 faithful; Muller et al., Handbook of Floating-Point Arithmetic, Thm. 4.9) -- five full-rate
+// instructions, no special cases as long as nothing over- or underflows (metric sums and depths: never).
+// tools/micro/f64_rates.hip compares it with the hardware quotient on 3e9 operand pairs; tests compare whole steps.
+struct InvD { double b, y; };
+__device__ __forceinline__ InvD inv_of(double b) { InvD d; d.b = b; d.y = 1.0 / b; return d; }
+#ifndef POMGPU_EMU
+__device__ __forceinline__ double divi(double a, const InvD &d) {
+  double q = a * d.y;
+  double r = __builtin_fma(-d.b, q, a);
+  q = __builtin_fma(r, d.y, q);
+  r = __builtin_fma(-d.b, q, a);
+  return __builtin_fma(r, d.y, q);
+}
+#else
+static inline double divi(double a, const InvD &d) { return a / d.b; }
+#endif
 // XCD-aware placement of the column kernels' workgroups (64 x 4 columns each).  Workgroups are dealt
 // to the 8 XCDs round-robin in linear-id order, and every XCD has its own 4 MiB L2.  A plain
 // (bx, by) grid therefore puts vertically adjacent workgroups on different XCDs and each re-fetches
