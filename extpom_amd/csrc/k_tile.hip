@@ -29,6 +29,9 @@ __global__ void k_coef_static(KP P) {
   K2(CVB, i, j) = F2(dx, i, jn) - F2(dx, i, js);
   K2(R2DXSX, i, j) = 2.0 / (F2(dx, i, j) + F2(dx, iw, j));
   K2(R2DYSY, i, j) = 2.0 / (F2(dy, i, j) + F2(dy, i, js));
+  // reciprocals of the vertical grid arrays (divi(), pomgpu_internal.hpp); 1/0 = inf where dz, dzz are 0 (level kb): never used
+  if (j == 1)
+    for (int n = i - 1; n < POM_NBLK1D * P.kb; n += P.iml) P.r1[n] = 1.0 / P.b1[n];
 }
 __global__ void k_coef_dt(KP P) {
   const int i = TID_I, j = TID_J;
@@ -101,8 +104,11 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   f.dif = divi(-am * c.hs * P.tprni * ((fb_hi - fc_hi) - (fb_lo - fc_lo)) * c.msk * c.ds_num * 0.5, c.den);
   return f;
 }
+#ifndef ADVT2_WAVES
+#define ADVT2_WAVES 2
+#endif
 template <int NF>
-__global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
+__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) __attribute__((amdgpu_waves_per_eu(ADVT2_WAVES, ADVT2_WAVES))) k_advt2_col(KP P, TFields A) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
@@ -124,6 +130,7 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
   for (int f = 0; f < NF; f++) { B.fb[f] = BUF3(A.fb[f]); B.fcl[f] = BUF3(A.fcl[f]); B.ff[f] = BUF3(A.ff[f]); }
   B.aam = BUF3(A3(aam)); B.u = BUF3(A3(u)); B.v = BUF3(A3(v)); B.w = BUF3(A3(w));
   const unsigned oc = BOFF2(i, j), os = BOFF2(i, js), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  const unsigned ost = in ? oc : BOFF_NONE;
   double f1[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) f1[f] = G3(A.f[f], i, j, 1);
@@ -134,13 +141,17 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
   for (int f = 0; f < NF; f++) p_adv[f] = p_dif[f] = p_fb[f] = p_zu[f] = 0.;
   // one iteration: issue the loads of level L+1 into `nxt`, evaluate the faces of level L from `cur`, finish level L-1
   auto step = [&](const int L, const LevT<NF> &cur, LevT<NF> &nxt) {
-    if (L + 1 <= kbm1) advt2_load<NF>(nxt, B, oc, os, on, (unsigned)L * lvb);       // in flight during this iteration
+#ifdef ADVT2_SYNC
+    __syncthreads();      // experiment: the rows of a workgroup request a level together (L1 merges the shared rows?)
+#endif
+    // in flight during this iteration.  Unconditional (the last iterations re-request level kbm1, a cache hit): a
+    // branch around the batch would cost the exact vmcnt bookkeeping of every wait below
+    advt2_load<NF>(nxt, B, oc, os, on, (unsigned)(L < kbm1 ? L : kbm1 - 1) * lvb);
     const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
     InvD dzk; dzk.b = dzk.y = 0.;
-    if (L >= 2) { dzk.b = F1(dz, L - 1); dzk.y = P.r1[(size_t)P1_dz * P.kb + (L - 2)]; }
+    if (L >= 2) { dzk.b = F1(dz, L - 1); dzk.y = R1(dz, L - 1); }
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-      const double ffk = (L >= 2 && !in && icol) ? G3(A.ff[f], i, j, L - 1) : 0.;
       double zu = 0.;                                                              // top face of level L (0 below kbm1)
       double s_adv = 0., s_dif = 0.;
       if (L <= kbm1) {
@@ -160,17 +171,14 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
         s_dif = xe.dif - xw.dif + yn.dif - ys.dif;                                            // :721-722
         zu = (L == 1) ? cur.w_c * f1[f] * art : upw_(cur.w_c, cur.fb_c[f], p_fb[f]) * art;    // :646-662
       }
-      if (L >= 2 && icol) {                                 // finish level L-1: its bottom face is this level's top face
-        double r;
-        if (in) {
-          r = p_adv[f] + divi(p_zu[f] - zu, dzk);                                             // :670-672
-          r = divi(p_fb[f] * hea - P.dti2 * r, hfa);                                          // :673-674
-          r = r * fsm;                                                                        // :1899
-          r = r - divi(P.dti2 * p_dif[f], hfa);                                               // :721-723
-        } else {
-          r = ffk * fsm;                                                                      // :1899 (rim cells)
-        }
-        bst(B.ff[f], oc, (unsigned)(L - 2) * lvb, r);
+      {                                                     // finish level L-1: its bottom face is this level's top face
+        double r = p_adv[f] + divi(p_zu[f] - zu, dzk);                                        // :670-672
+        r = divi(p_fb[f] * hea - P.dti2 * r, hfa);                                            // :673-674
+        r = r * fsm;                                                                          // :1899
+        r = r - divi(P.dti2 * p_dif[f], hfa);                                                 // :721-723
+        // every lane stores, every iteration: lanes without an interior column (and the first iteration, which has
+        // no finished level yet) aim outside the buffer and the hardware drops the store
+        bst(B.ff[f], (L >= 2) ? ost : BOFF_NONE, (unsigned)(L >= 2 ? L - 2 : 0) * lvb, r);
       }
       p_adv[f] = s_adv; p_dif[f] = s_dif; p_fb[f] = cur.fb_c[f]; p_zu[f] = zu;
     }
@@ -183,9 +191,14 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
     step(L, ra, rb);
     if (L + 1 <= kbm1 + 1) step(L + 1, rb, ra);
   }
+  // :1899 on what the loop did not write: level kb everywhere, every level of the rim cells.  AFTER the loop: a load
+  // inside it (even one only rim lanes execute) makes the compiler wait for vmcnt(0) where the paths join, i.e. for
+  // the whole prefetch batch of the next level, in every wavefront
   if (icol) {
+    for (int k = in ? P.kb : 1; k <= P.kb; k++) {
 #pragma unroll
-    for (int f = 0; f < NF; f++) G3(A.ff[f], i, j, P.kb) = G3(A.ff[f], i, j, P.kb) * fsm;     // :1899, level kb
+      for (int f = 0; f < NF; f++) G3(A.ff[f], i, j, k) = G3(A.ff[f], i, j, k) * fsm;
+    }
   }
 }
 
@@ -225,7 +238,7 @@ __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double 
   return .5 * c.ds_num * x;
 }
 template <int NF>
-__global__ void __launch_bounds__(64 * COL_ROWS) k_advq_col(KP P, QFields A, int zero_else) {
+__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advq_col(KP P, QFields A, int zero_else) {
   HALO_XCD_DECODE
   const int j0 = j;
   if (j0 > P.jml) return;
@@ -391,7 +404,7 @@ __global__ void k_advct_fix(KP P, const double *from_w, const double *from_s) {
   }
 }
 // sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
-__global__ void __launch_bounds__(64 * COL_ROWS) k_advct_col(KP P, int sum2d) {
+__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advct_col(KP P, int sum2d) {
   HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
   if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
@@ -517,7 +530,7 @@ __device__ __forceinline__ LevUV advuv_load(const KP &P, int i, int js, int j, i
   L.advx = F3(advx, i, j, k);  L.advy = F3(advy, i, j, k);  L.drhox = F3(drhox, i, j, k); L.drhoy = F3(drhoy, i, j, k);
   return L;
 }
-__global__ void __launch_bounds__(64 * COL_ROWS) k_advuv_col(KP P) {
+__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advuv_col(KP P) {
   HALO_XCD_DECODE
   if (j > P.jm) return;                                     // whole wavefront (one row)
   const bool out = (lane >= 1 && lane <= 62 && i0 <= P.im);

@@ -177,6 +177,11 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
             d->kb, POMGPU_KBMAX);
     return POMGPU_EINVAL;
   }
+  if ((size_t)d->im_local * d->jm_local * d->kb * sizeof(double) >= ((size_t)1 << 32)) {
+    fprintf(stderr, "pomgpu_create: a 3-D array of this tile has %zu bytes; the column kernels address a level with 32-bit offsets "
+                    "(< 4 GiB per array): split the domain into more tiles\n", (size_t)d->im_local * d->jm_local * d->kb * sizeof(double));
+    return POMGPU_EINVAL;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
     fprintf(stderr, "pomgpu_create: no usable HIP device (count=%d, asked %d); the hot path has no CPU fallback\n", ndev,
@@ -218,6 +223,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
     if (hipMemsetAsync(*p, 0, n * sizeof(double), c->stream) != hipSuccess) ok = false;
   };
   alloc(&P.b1, (size_t)POM_NBLK1D * P.kb);
+  alloc(&P.r1, (size_t)POM_NBLK1D * P.kb);
   alloc(&P.b2, (size_t)POM_NBLK2D * P.n2);
   const bool only2d = (flags & POMGPU_CTX_2D) != 0;
   if (!only2d) alloc(&P.b3, (size_t)POM_NBLK3D * P.n3);
@@ -258,6 +264,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   wide_free(c);
   pomgpu_tp_free(c);
   KP &P = c->P;
+  (void)hipFree(P.r1);
   (void)hipFree(P.b1); (void)hipFree(P.b2); (void)hipFree(P.b3); (void)hipFree(P.bd);
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);

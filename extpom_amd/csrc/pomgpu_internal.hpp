@@ -50,7 +50,20 @@ enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb, X2_uab, X2_vab };
 // ---- Fortran-style accessors (1-based), `P` is the KP in scope ------------------------------
 #define IX2(i, j) ((size_t)((j)-1) * (size_t)P.iml + (size_t)((i)-1))
 #define IX3(i, j, k) ((size_t)((k)-1) * P.n2 + IX2(i, j))
+// blk1d (z, zz, dz, dzz) is indexed by the level only: the address is uniform across the wavefront.  Read through the
+// CONSTANT address space the loads become scalar loads (s_load, counted by lgkmcnt).  As plain global loads the compiler
+// cannot prove the arrays are not written by the kernel's own stores and issues VECTOR loads of a uniform address -- which
+// queue behind the prefetch batch of the next level and, vmcnt being in-order, make the first use of dz(k) wait for that
+// whole batch: the software pipeline of every column kernel was serialised by it (ISA of k_advt2_col: s_waitcnt vmcnt(0)
+// in the middle of each iteration).  The arrays never change while a kernel runs (upload writes them).
+#ifndef POMGPU_EMU
+typedef const double __attribute__((address_space(4))) *pomgpu_cptr;
+#define F1(name, k) ((pomgpu_cptr)(size_t)P.b1)[(size_t)P1_##name * P.kb + ((k)-1)]
+#define R1(name, k) ((pomgpu_cptr)(size_t)P.r1)[(size_t)P1_##name * P.kb + ((k)-1)]
+#else
 #define F1(name, k) P.b1[(size_t)P1_##name * P.kb + ((k)-1)]
+#define R1(name, k) P.r1[(size_t)P1_##name * P.kb + ((k)-1)]
+#endif
 #define F2(name, i, j) P.b2[(size_t)P2_##name * P.n2 + IX2(i, j)]
 #define F3(name, i, j, k) P.b3[(size_t)P3_##name * P.n3 + IX3(i, j, k)]
 #define A2(name) (P.b2 + (size_t)P2_##name * P.n2)
@@ -170,9 +183,14 @@ __device__ __forceinline__ void bst(const BufA &b, unsigned voff, unsigned soff,
 #else
 struct BufA { double *p; };
 static inline BufA buf_of(const double *p, size_t) { BufA b; b.p = (double *)p; return b; }
-static inline double bld(const BufA &b, unsigned voff, unsigned soff) { return b.p[((size_t)voff + soff) >> 3]; }
-static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { b.p[((size_t)voff + soff) >> 3] = x; }
+static inline double bld(const BufA &b, unsigned voff, unsigned soff) { return voff >= 0xFFFFFFF0u ? 0. : b.p[((size_t)voff + soff) >> 3]; }
+static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { if (voff < 0xFFFFFFF0u) b.p[((size_t)voff + soff) >> 3] = x; }
 #endif
+// per-lane offset of a lane that must not store: outside every descriptor, the hardware drops the access (loads return 0;
+// tools/micro/buf_oob.hip).  A branch around a store or load inside a software-pipelined loop costs far more than the
+// wasted lanes: where the paths join the compiler no longer knows how many memory operations are outstanding and waits
+// for vmcnt(0), i.e. for the prefetch batch that was just issued.
+#define BOFF_NONE 0xFFFFFFF0u
 #define BUF3(p) buf_of((p), P.n3)
 #define BOFF2(i, j) (unsigned)(((unsigned)((j)-1) * (unsigned)P.iml + (unsigned)((i)-1)) * 8u)   /* byte offset of (i,j) inside a level */
 
@@ -207,22 +225,26 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
 // are L2 hits.  The mapping is only a performance hint: any dispatch order gives the same results.
 // HALO_XCD_DECODE defines i0 (1-based column, halo-lane numbering) and j (1-based row), or returns.
 #ifndef COL_ROWS
-#define COL_ROWS 4                                          /* rows (wavefronts) per workgroup of the column kernels */
+#define COL_ROWS 4                                          /* rows per workgroup of the column kernels */
+#endif
+#ifndef COL_WX
+#define COL_WX 1                                            /* wavefronts side by side along i per workgroup row */
 #endif
 #define HALO_XCD_DECODE                                                                   \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
-  const int L__ = g__ >> 6, nbx__ = (P.iml + 61) / 62, nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS; \
+  const int L__ = g__ >> 6, nwx__ = (P.iml + 61) / 62, nbx__ = (nwx__ + COL_WX - 1) / COL_WX; \
+  const int nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS;                                    \
   const int rpx__ = (nby__ + 7) / 8;                                                      \
   const int by__ = (L__ & 7) * rpx__ + (L__ >> 3) / nbx__;                                \
   if ((L__ >> 3) / nbx__ >= rpx__ || by__ >= nby__) return;                               \
   const int lane = g__ & 63;                                                              \
-  const int i0 = ((L__ >> 3) % nbx__) * 62 + lane;                                        \
-  const int j = by__ * COL_ROWS + (int)threadIdx.y + 1;
+  const int i0 = (((L__ >> 3) % nbx__) * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane; \
+  const int j = by__ * COL_ROWS + (int)threadIdx.y / COL_WX + 1;
 static inline dim3 grid1_halo(const KP &P) {
-  const int nbx = (P.iml + 61) / 62, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;
+  const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;
   return dim3((unsigned)(8 * rpx * nbx), 1, 1);
 }
-static inline dim3 blk_col() { return dim3(64, COL_ROWS, 1); }
+static inline dim3 blk_col() { return dim3(64, COL_ROWS * COL_WX, 1); }
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }
 
