@@ -71,23 +71,11 @@ struct FaceT { double adv, dif; };
 // NF = 2 advances T and S in ONE pass (advance.f:431-432 calls advt2 twice): u, v, w, aam and the face
 // coefficients are read once for both fields.
 struct TFields { const double *fb[2], *f[2], *fcl[2]; double *ff[2]; };
-template <int NF> struct LevT { double fb_c[NF], fb_s[NF], fb_n[NF], fc_c[NF], fc_s[NF], fc_n[NF], am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
-template <int NF> struct BufT { BufA fb[NF], fcl[NF], ff[NF], aam, u, v, w; };
-// every load of a level is issued here, in one batch, BEFORE the level that is being computed
-// needs anything: vmcnt counts in order, so a load issued in the middle of the arithmetic would
-// make the wave wait for the whole prefetch batch of the next level.
-// oc / os / on: byte offsets of the cell and its southern / northern neighbour inside a level, lv: the level's
-// byte offset -- buffer addressing, see pomgpu_internal.hpp
-template <int NF> __device__ __forceinline__ void advt2_load(LevT<NF> &L, const BufT<NF> &B, unsigned oc, unsigned os, unsigned on, unsigned lv) {
-#pragma unroll
-  for (int f = 0; f < NF; f++) {
-    L.fb_c[f] = bld(B.fb[f], oc, lv);  L.fb_s[f] = bld(B.fb[f], os, lv);  L.fb_n[f] = bld(B.fb[f], on, lv);
-    L.fc_c[f] = bld(B.fcl[f], oc, lv); L.fc_s[f] = bld(B.fcl[f], os, lv); L.fc_n[f] = bld(B.fcl[f], on, lv);
-  }
-  L.am_c = bld(B.aam, oc, lv); L.am_s = bld(B.aam, os, lv); L.am_n = bld(B.aam, on, lv);
-  L.u_c = bld(B.u, oc, lv);    L.v_c = bld(B.v, oc, lv);    L.v_n = bld(B.v, on, lv);
-  L.w_c = bld(B.w, oc, lv);
-}
+// Operands of a level.  Shared with the rows above and below through the workgroup's LDS slab (RowShare,
+// pomgpu_internal.hpp), in this order: fb[0..NF-1], fclim[0..NF-1], aam, v; this row only: u, w.
+// c: the wavefront's own row, h: its share of the two rows outside the workgroup.
+template <int NF> struct LevT { double c[2 * NF + 2], o[2], h[ROWSHARE_SLOTS(2 * NF + 2)]; };
+template <int NS> struct NbrT { double s[NS], n[NS]; };
 struct CoefT { double cm, hs, msk, ds_num; InvD den; };   // mass-flux coefficient, h sum, mask, metric sums of one face
 __device__ __forceinline__ CoefT coef_x(const KP &P, int i, int j) {
   CoefT c; c.cm = K2(CMX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.ds_num = K2(DYSX, i, j); c.den = inv_of(K2(DXSX, i, j)); return c;
@@ -104,100 +92,141 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
   f.dif = divi(-am * c.hs * P.tprni * ((fb_hi - fc_hi) - (fb_lo - fc_lo)) * c.msk * c.ds_num * 0.5, c.den);
   return f;
 }
-#ifndef ADVT2_WAVES
-#define ADVT2_WAVES 2
+#if COL_WX != 1
+#error "the row-sharing column kernels keep one wavefront per workgroup row (COL_WX == 1)"
 #endif
+// What keeps the level loop a pipeline (each item was a stall in the ISA of the first version):
+//   * every load of a level is issued in ONE batch a whole iteration before its first use, and NO memory instruction sits
+//     inside a branch: where control flow joins, the compiler no longer knows how many operations are outstanding and
+//     waits for vmcnt(0), i.e. for the batch it has just issued.  Lanes / iterations with nothing to store aim outside
+//     the buffer (BOFF_NONE, dropped by the hardware); the last iterations re-request level kbm1;
+//   * dz(k) comes through the constant address space (scalar load) -- as a vector load it queued behind the batch;
+//   * buffer addressing: no vector instruction computes an address; two register sets alternate as current / next
+//     level (no copies); divisors that are fixed along the column are inverted once (divi).
 template <int NF>
-__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) __attribute__((amdgpu_waves_per_eu(ADVT2_WAVES, ADVT2_WAVES))) k_advt2_col(KP P, TFields A) {
-  HALO_XCD_DECODE
-  const int j0 = j;
-  if (j0 > P.jml) return;                                   // whole wavefront (one row) leaves together
-  const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);   // this lane owns an output column
+__global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
+  constexpr int NS = 2 * NF + 2, NH = ROWSHARE_SLOTS(NS), AM = 2 * NF, VV = 2 * NF + 1;
+  HALO_XCD_DECODE                                           // a workgroup outside the grid leaves as a whole
+  const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
+  const bool jrow = j <= P.jml;                             // rows beyond the tile shadow row jml and store nothing
+  const int jc = jrow ? j : P.jml;
+  const bool icol = jrow && (lane >= 1 && lane <= 62 && i0 <= P.iml);   // this lane owns an output column
 #ifdef POMGPU_EMU
   if (!icol) return;
 #endif
   const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);          // halo / padding lanes shadow a valid column
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
-  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
-  const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  const double fsm = F2(fsm, i, j);
+  const int js = jc > 1 ? jc - 1 : 1, jn = jc < P.jml ? jc + 1 : P.jml;
+  const bool in = icol && (i >= 2 && i <= P.imm1 && jc >= 2 && jc <= P.jmm1);
+  const double fsm = F2(fsm, i, jc);
   // column-resident coefficients of the west, south and north faces and of the cell
-  const CoefT cw = coef_x(P, i, j), cs = coef_y(P, i, j), cn = coef_y(P, i, jn);
-  const double art = F2(art, i, j), hea = K2(HEA, i, j);
-  const InvD hfa = inv_of(K2(HFA, i, j));
-  BufT<NF> B;
+  const CoefT cw = coef_x(P, i, jc), cs = coef_y(P, i, jc), cn = coef_y(P, i, jn);
+  const double art = F2(art, i, jc), hea = K2(HEA, i, jc);
+  const InvD hfa = inv_of(K2(HFA, i, jc));
+  BufA bs[NS], bo[2], bff[NF], bh[NH];
+  const double *ps[NS];
 #pragma unroll
-  for (int f = 0; f < NF; f++) { B.fb[f] = BUF3(A.fb[f]); B.fcl[f] = BUF3(A.fcl[f]); B.ff[f] = BUF3(A.ff[f]); }
-  B.aam = BUF3(A3(aam)); B.u = BUF3(A3(u)); B.v = BUF3(A3(v)); B.w = BUF3(A3(w));
-  const unsigned oc = BOFF2(i, j), os = BOFF2(i, js), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  for (int f = 0; f < NF; f++) { ps[f] = A.fb[f]; ps[NF + f] = A.fcl[f]; bff[f] = BUF3(A.ff[f]); }
+  ps[AM] = A3(aam); ps[VV] = A3(v); bo[0] = BUF3(A3(u)); bo[1] = BUF3(A3(w));
+#pragma unroll
+  for (int x = 0; x < NS; x++) bs[x] = BUF3(ps[x]);
+  const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
+#pragma unroll
+  for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
+  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
   const unsigned ost = in ? oc : BOFF_NONE;
+#ifndef POMGPU_EMU
+  __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
+#else
+  const unsigned os = BOFF2(i, js), on = BOFF2(i, jn);
+#endif
+  auto load = [&](LevT<NF> &L, unsigned lv) {
+#pragma unroll
+    for (int x = 0; x < NS; x++) L.c[x] = bld(bs[x], oc, lv);
+    L.o[0] = bld(bo[0], oc, lv); L.o[1] = bld(bo[1], oc, lv);
+#pragma unroll
+    for (int q = 0; q < NH; q++) L.h[q] = bld(bh[q], S.hoff[q], lv);
+  };
   double f1[NF];
 #pragma unroll
-  for (int f = 0; f < NF; f++) f1[f] = G3(A.f[f], i, j, 1);
+  for (int f = 0; f < NF; f++) f1[f] = G3(A.f[f], i, jc, 1);
   const int kbm1 = P.kbm1;
   // carried from level L-1 to its completion in iteration L
   double p_adv[NF], p_dif[NF], p_fb[NF], p_zu[NF];
 #pragma unroll
   for (int f = 0; f < NF; f++) p_adv[f] = p_dif[f] = p_fb[f] = p_zu[f] = 0.;
-  // one iteration: issue the loads of level L+1 into `nxt`, evaluate the faces of level L from `cur`, finish level L-1
-  auto step = [&](const int L, const LevT<NF> &cur, LevT<NF> &nxt) {
-#ifdef ADVT2_SYNC
-    __syncthreads();      // experiment: the rows of a workgroup request a level together (L1 merges the shared rows?)
+  // one iteration: request level L+1 into `nxt`, park level L (`cur`) in the slab, evaluate its faces, finish level L-1.
+  // (Tried: parking a level one iteration ahead, the level itself re-read from the slab, one register set less -- the
+  // barrier then waits for nobody less than an iteration behind, but the LDS round trip of the own row sits in front of
+  // every level's arithmetic: 3-5 % slower.)
+  auto step = [&](const int L, const int par, const LevT<NF> &cur, LevT<NF> &nxt) {
+    load(nxt, (unsigned)(L < kbm1 ? L : kbm1 - 1) * lvb);     // the last iterations re-request level kbm1
+    NbrT<NS> nb;
+#ifndef POMGPU_EMU
+#pragma unroll
+    for (int x = 0; x < NS; x++) slab[par][x][r + 1][lane] = cur.c[x];
+#pragma unroll
+    for (int q = 0; q < NH; q++) slab[par][S.hop[q]][S.hrow[q]][lane] = cur.h[q];
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = slab[par][x][S.ss][lane]; nb.n[x] = slab[par][x][S.sn][lane]; }
+#else
+    const unsigned lvc = (unsigned)((L <= kbm1 ? L : kbm1) - 1) * lvb;
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = bld(bs[x], os, lvc); nb.n[x] = bld(bs[x], on, lvc); }
 #endif
-    // in flight during this iteration.  Unconditional (the last iterations re-request level kbm1, a cache hit): a
-    // branch around the batch would cost the exact vmcnt bookkeeping of every wait below
-    advt2_load<NF>(nxt, B, oc, os, on, (unsigned)(L < kbm1 ? L : kbm1 - 1) * lvb);
-    const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
+    const double am_c = cur.c[AM], u_c = cur.o[0], w_c = cur.o[1];
+    const double am_w = halo_w(am_c, [&] { return F3(aam, iw, jc, L); });
     InvD dzk; dzk.b = dzk.y = 0.;
     if (L >= 2) { dzk.b = F1(dz, L - 1); dzk.y = R1(dz, L - 1); }
 #pragma unroll
     for (int f = 0; f < NF; f++) {
+      const double fb_c = cur.c[f], fc_c = cur.c[NF + f];
       double zu = 0.;                                                              // top face of level L (0 below kbm1)
       double s_adv = 0., s_dif = 0.;
       if (L <= kbm1) {
-        const double fb_w = halo_w(cur.fb_c[f], [&] { return G3(A.fb[f], iw, j, L); });
-        const double fc_w = halo_w(cur.fc_c[f], [&] { return G3(A.fcl[f], iw, j, L); });
-        const FaceT xw = advt2_face(P, cw, cur.u_c, cur.fb_c[f], fb_w, cur.fc_c[f], fc_w, cur.am_c, am_w);
+        const double fb_w = halo_w(fb_c, [&] { return G3(A.fb[f], iw, jc, L); });
+        const double fc_w = halo_w(fc_c, [&] { return G3(A.fcl[f], iw, jc, L); });
+        const FaceT xw = advt2_face(P, cw, u_c, fb_c, fb_w, fc_c, fc_w, am_c, am_w);
         auto east = [&] {                                   // emulation only: the east face from memory
-          return advt2_face(P, coef_x(P, ie, j), F3(u, ie, j, L), G3(A.fb[f], ie, j, L), cur.fb_c[f], G3(A.fcl[f], ie, j, L), cur.fc_c[f],
-                            F3(aam, ie, j, L), cur.am_c);
+          return advt2_face(P, coef_x(P, ie, jc), F3(u, ie, jc, L), G3(A.fb[f], ie, jc, L), fb_c, G3(A.fcl[f], ie, jc, L), fc_c,
+                            F3(aam, ie, jc, L), am_c);
         };
         FaceT xe;
         xe.adv = halo_e(xw.adv, [&] { return east().adv; });
         xe.dif = halo_e(xw.dif, [&] { return east().dif; });
-        const FaceT ys = advt2_face(P, cs, cur.v_c, cur.fb_c[f], cur.fb_s[f], cur.fc_c[f], cur.fc_s[f], cur.am_c, cur.am_s);
-        const FaceT yn = advt2_face(P, cn, cur.v_n, cur.fb_n[f], cur.fb_c[f], cur.fc_n[f], cur.fc_c[f], cur.am_n, cur.am_c);
+        const FaceT ys = advt2_face(P, cs, cur.c[VV], fb_c, nb.s[f], fc_c, nb.s[NF + f], am_c, nb.s[AM]);
+        const FaceT yn = advt2_face(P, cn, nb.n[VV], nb.n[f], fb_c, nb.n[NF + f], fc_c, nb.n[AM], am_c);
         s_adv = xe.adv - xw.adv + yn.adv - ys.adv;                                            // solver.f:670-671
         s_dif = xe.dif - xw.dif + yn.dif - ys.dif;                                            // :721-722
-        zu = (L == 1) ? cur.w_c * f1[f] * art : upw_(cur.w_c, cur.fb_c[f], p_fb[f]) * art;    // :646-662
+        zu = (L == 1) ? w_c * f1[f] * art : upw_(w_c, fb_c, p_fb[f]) * art;                   // :646-662
       }
       {                                                     // finish level L-1: its bottom face is this level's top face
-        double r = p_adv[f] + divi(p_zu[f] - zu, dzk);                                        // :670-672
-        r = divi(p_fb[f] * hea - P.dti2 * r, hfa);                                            // :673-674
-        r = r * fsm;                                                                          // :1899
-        r = r - divi(P.dti2 * p_dif[f], hfa);                                                 // :721-723
+        double rr = p_adv[f] + divi(p_zu[f] - zu, dzk);                                       // :670-672
+        rr = divi(p_fb[f] * hea - P.dti2 * rr, hfa);                                          // :673-674
+        rr = rr * fsm;                                                                        // :1899
+        rr = rr - divi(P.dti2 * p_dif[f], hfa);                                               // :721-723
         // every lane stores, every iteration: lanes without an interior column (and the first iteration, which has
         // no finished level yet) aim outside the buffer and the hardware drops the store
-        bst(B.ff[f], (L >= 2) ? ost : BOFF_NONE, (unsigned)(L >= 2 ? L - 2 : 0) * lvb, r);
+        bst(bff[f], (L >= 2 && L <= kbm1 + 1) ? ost : BOFF_NONE, (unsigned)(L >= 2 ? L - 2 : 0) * lvb, rr);
       }
-      p_adv[f] = s_adv; p_dif[f] = s_dif; p_fb[f] = cur.fb_c[f]; p_zu[f] = zu;
+      p_adv[f] = s_adv; p_dif[f] = s_dif; p_fb[f] = fb_c; p_zu[f] = zu;
     }
   };
   // two register sets take turns as "current" and "next" level: no copy between iterations
   LevT<NF> ra, rb;
-  advt2_load<NF>(ra, B, oc, os, on, 0u);
+  load(ra, 0u);
   rb = ra;
   for (int L = 1; L <= kbm1 + 1; L += 2) {
-    step(L, ra, rb);
-    if (L + 1 <= kbm1 + 1) step(L + 1, rb, ra);
+    step(L, 1, ra, rb);
+    step(L + 1, 0, rb, ra);                                 // for even kbm1 one iteration too many: its stores aim outside the buffer
   }
   // :1899 on what the loop did not write: level kb everywhere, every level of the rim cells.  AFTER the loop: a load
-  // inside it (even one only rim lanes execute) makes the compiler wait for vmcnt(0) where the paths join, i.e. for
-  // the whole prefetch batch of the next level, in every wavefront
+  // inside it (even one only rim lanes execute) makes the compiler wait for vmcnt(0) where the paths join
   if (icol) {
     for (int k = in ? P.kb : 1; k <= P.kb; k++) {
 #pragma unroll
-      for (int f = 0; f < NF; f++) G3(A.ff[f], i, j, k) = G3(A.ff[f], i, j, k) * fsm;
+      for (int f = 0; f < NF; f++) G3(A.ff[f], i, jc, k) = G3(A.ff[f], i, jc, k) * fsm;
     }
   }
 }

@@ -10,6 +10,12 @@
 #include <stdlib.h>
 #include "pom_layout.h"
 
+#ifndef COL_ROWS
+#define COL_ROWS 4                                          /* rows per workgroup of the column kernels */
+#endif
+#ifndef COL_WX
+#define COL_WX 1                                            /* wavefronts side by side along i per workgroup row */
+#endif
 #define POMGPU_NSCR3 8     // 3-D scratch arrays (the reference's automatic arrays that survive fusion)
 #define POMGPU_NSCR2 8     // 2-D scratch arrays
 #define POMGPU_NCOEF2 24   // derived 2-D coefficient arrays
@@ -153,6 +159,12 @@ template <class F> __device__ __forceinline__ double halo_e(double x, F) { retur
 #else
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// a value that is the same in every lane of the wavefront (e.g. threadIdx.y with 64-wide rows), told to the compiler
+#ifndef POMGPU_EMU
+#define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define WAVE_UNIFORM(x) (x)
+#endif
 #define HALO_LANE (int)((blockIdx.x * blockDim.x + threadIdx.x) & 63)
 
 // ---- buffer addressing for the column kernels ---------------------------------------------------------------------
@@ -194,6 +206,61 @@ static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { 
 #define BUF3(p) buf_of((p), P.n3)
 #define BOFF2(i, j) (unsigned)(((unsigned)((j)-1) * (unsigned)P.iml + (unsigned)((i)-1)) * 8u)   /* byte offset of (i,j) inside a level */
 
+// ---- rows of a workgroup shared through LDS ---------------------------------------------------------------------------
+// A column kernel with a j-stencil needs every such operand of rows j-1, j, j+1.  Loaded per wavefront (one row each)
+// that is three wavefront loads per operand and level, and the counters say that is what bounds these kernels: the L1
+// (TCP) spends ~21 accesses on every 8-byte-per-lane wavefront load and saturates at ~0.6 accesses per CU-cycle
+// (k_advt2_col: 0.59, whatever the occupancy; with the neighbour-row loads taken out the kernel ran 26 % faster), and
+// the re-requested rows are L2 hits only 40 % of the time (+45 % HBM-side reads).  Here the COL_ROWS wavefronts of a
+// workgroup load their OWN row of each shared operand, park it in an LDS slab and read the rows next to theirs from
+// there; the two rows outside the workgroup (south of its first row, north of its last) are split among its wavefronts
+// (ROWSHARE_SLOTS loads each).  One s_barrier per level; two slabs, so a wavefront may fill the next level's slab while
+// its neighbours still read this level's.  Loads per wavefront and level: NS + NO + slots instead of 3*NS + NO.
+// Slab rows: 0 = south halo, 1..COL_ROWS = the workgroup's rows, COL_ROWS+1 = north halo, COL_ROWS+2 = sink for the
+// slots a wavefront has no job for.  Host emulation (one lane at a time, no concurrency) reads the rows from memory.
+#define ROWSHARE_SLOTS(NS) ((2 * (NS) + COL_ROWS - 1) / COL_ROWS)
+#define ROWSHARE_ROWS (COL_ROWS + 3)
+template <int NS> struct RowShare {
+  int r;                                   // this wavefront's row inside the workgroup (scalar)
+  int ss, sn;                              // slab rows holding the southern / northern neighbour row of this wavefront's row
+  int hop[ROWSHARE_SLOTS(NS)];             // halo jobs of this wavefront: which shared operand ...
+  int hrow[ROWSHARE_SLOTS(NS)];            // ... into which slab row ...
+  unsigned hoff[ROWSHARE_SLOTS(NS)];       // ... from which cell (per-lane byte offset inside a level; BOFF_NONE = no job)
+};
+// j: the wavefront's row (may lie beyond jml in the last workgroup: such rows shadow row jml and store nothing),
+// jc = min(j, jml), j0w: first row of the workgroup, i: the lane's (clamped) column
+template <int NS> __device__ __forceinline__ RowShare<NS> rowshare_setup(const KP &P, int r, int j, int j0w, int i) {
+  RowShare<NS> S;
+  S.r = r;
+  S.ss = (j > 1 && j <= P.jml) ? r : r + 1;
+  S.sn = (j < P.jml) ? r + 2 : r + 1;
+  const int jsouth = j0w > 1 ? j0w - 1 : 1, jnorth = j0w + COL_ROWS <= P.jml ? j0w + COL_ROWS : P.jml;
+#pragma unroll
+  for (int q = 0; q < ROWSHARE_SLOTS(NS); q++) {
+    const int job = q * COL_ROWS + r;
+    const bool valid = job < 2 * NS;
+    const int side = valid ? job / NS : 0;
+    S.hop[q] = valid ? job % NS : 0;
+    S.hrow[q] = valid ? (side ? COL_ROWS + 1 : 0) : COL_ROWS + 2;
+    S.hoff[q] = valid ? BOFF2(i, side ? jnorth : jsouth) : BOFF_NONE;
+  }
+  return S;
+}
+// the array a halo job reads: chosen by a wavefront-uniform index; the pointer is pinned to scalar registers so that the
+// descriptor built from it is one (a descriptor in vector registers costs a waterfall loop around every load)
+template <int NS> __device__ __forceinline__ const double *rowshare_pick(const double *const (&b)[NS], int op) {
+  const double *x = b[0];
+#pragma unroll
+  for (int o = 1; o < NS; o++)
+    if (op == o) x = b[o];
+#ifndef POMGPU_EMU
+  const unsigned long long v = (unsigned long long)x;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  x = (const double *)(((unsigned long long)hi << 32) | lo);
+#endif
+  return x;
+}
+
 // ---- division by a divisor that does not change along the column ---------------------------------------------------
 // a / b is the reference's operation (IEEE, correctly rounded); the GPU's macro for it is ~10 instructions, several of
 // them slow (v_div_scale x2, v_rcp_f64, 5 fma, v_div_fmas, v_div_fixup).  The column kernels divide by the same
@@ -224,21 +291,34 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
 // it row by row, so the ~3 block-rows an XCD has resident at any time are neighbours and the halo rows
 // are L2 hits.  The mapping is only a performance hint: any dispatch order gives the same results.
 // HALO_XCD_DECODE defines i0 (1-based column, halo-lane numbering) and j (1-based row), or returns.
-#ifndef COL_ROWS
-#define COL_ROWS 4                                          /* rows per workgroup of the column kernels */
+#ifndef COL_STRIP
+#define COL_STRIP 0                                         /* > 0: an XCD walks its band in strips this many workgroups wide */
 #endif
-#ifndef COL_WX
-#define COL_WX 1                                            /* wavefronts side by side along i per workgroup row */
+#if COL_STRIP > 0
+// strip order: the workgroups an XCD has resident at one time are a tall patch (COL_STRIP wide), so that the row a
+// workgroup reads beyond its own rows is being read by the workgroup above / below it at about the same time (L2 hit)
+#define HALO_XCD_ORDER                                                                    \
+  const int nfull__ = nbx__ / COL_STRIP, wlast__ = nbx__ - nfull__ * COL_STRIP;           \
+  int s__ = m__ / (rpx__ * COL_STRIP);                                                    \
+  if (s__ > nfull__) s__ = nfull__;                                                       \
+  const int rem__ = m__ - s__ * rpx__ * COL_STRIP, w__ = s__ < nfull__ ? COL_STRIP : (wlast__ > 0 ? wlast__ : 1); \
+  const int byl__ = rem__ / w__, bxg__ = s__ * COL_STRIP + rem__ % w__;                   \
+  if (bxg__ >= nbx__ || byl__ >= rpx__) return;
+#else
+#define HALO_XCD_ORDER                                                                    \
+  const int byl__ = m__ / nbx__, bxg__ = m__ % nbx__;                                     \
+  if (byl__ >= rpx__) return;
 #endif
 #define HALO_XCD_DECODE                                                                   \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
   const int L__ = g__ >> 6, nwx__ = (P.iml + 61) / 62, nbx__ = (nwx__ + COL_WX - 1) / COL_WX; \
   const int nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS;                                    \
-  const int rpx__ = (nby__ + 7) / 8;                                                      \
-  const int by__ = (L__ & 7) * rpx__ + (L__ >> 3) / nbx__;                                \
-  if ((L__ >> 3) / nbx__ >= rpx__ || by__ >= nby__) return;                               \
+  const int rpx__ = (nby__ + 7) / 8, m__ = L__ >> 3;                                      \
+  HALO_XCD_ORDER                                                                          \
+  const int by__ = (L__ & 7) * rpx__ + byl__;                                             \
+  if (by__ >= nby__) return;                                                              \
   const int lane = g__ & 63;                                                              \
-  const int i0 = (((L__ >> 3) % nbx__) * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane; \
+  const int i0 = (bxg__ * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane;                \
   const int j = by__ * COL_ROWS + (int)threadIdx.y / COL_WX + 1;
 static inline dim3 grid1_halo(const KP &P) {
   const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;

@@ -70,3 +70,5 @@ static inline void emu_launch(K kern, dim3 g, dim3 b, const A &...a) {
       }
 }
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) emu_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
+static inline void __syncthreads() {}
+#define __shared__ static thread_local
