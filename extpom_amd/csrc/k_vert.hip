@@ -309,17 +309,29 @@ __global__ void k_profq_prod_lines(KP P) {
 // memory there (only their level-kb left-overs do, see k_q_filter); the two outermost lines of columns
 // keep the plain path (bcond(6), which also reads their old q2/q2l, and on several tiles the exchange
 // come between the solve and their filter).
-// operands of one level of the forward walk, requested one level ahead
-struct LevQ { double t, s, rho, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn; };
-// __launch_bounds__: without it the compiler plans for 1024-thread workgroups, caps the kernel at 128 VGPRs and
-// spills 22 of them (11.2 ms per launch at 2048x1536x50; 10.3 with the bound, 9.95 with the operands of level
-// k+1 requested during level k: 215 VGPRs, two waves per SIMD)
-__global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_filter) {
+// The elimination vectors do not fit registers or LDS at a useful occupancy (4 x kb doubles per column); they live in
+// memory: gg1 in uf and gg2 in vf IN PLACE (the right-hand side of a level is consumed before its gg is written, and
+// the back substitution overwrites them or -- with the fused filter -- nobody reads uf, vf of those columns again),
+// ee1 / ee2 in the scratch arrays s3[4] / s3[5].  Same traffic as the private (scratch-memory) arrays of the first
+// version, but ordinary buffer accesses that take part in the exact vmcnt bookkeeping below.
+//
+// What the ISA of the first version showed (k_profq spent 62-65 % of its wave cycles in s_waitcnt, SQ_WAIT_ANY): the
+// ~15 operand loads of level k+1 were requested at the top of iteration k, but half of them sat inside branches
+// (`if (mid)`, `if (pin)`, `if (!repl)` ...) -- where such branches join, the compiler cannot know how many memory
+// operations are outstanding and waits for vmcnt(0), i.e. for the batch it has just issued: every level paid a full
+// memory round trip.  Here NO memory instruction of the two walks sits inside a branch: every lane requests every
+// operand of every level (a value that is not needed is not used), and a lane / level with nothing to store aims
+// outside the buffer (BOFF_NONE: the hardware drops the store).  Buffer addressing throughout (no address arithmetic
+// in vector registers), two register sets alternating as current / next level.
+// FP: 0 = the production term comes from s3[0] (k_profq_prod), 1 = formed here for interior columns, 0 on the rim (one
+// tile), 2 = formed here for interior columns, s3[0] on the rim (tiles, the library's exchange).  FF: fused filter.
+struct LevQ { double t, s, rho, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn, kq1, prod; };
+struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
+template <int FP, int FF>
+__global__ void __launch_bounds__(128) k_profq(KP P) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
-  const double *prod = P.s3[0];
-  double ee1[POMGPU_KBMAX], gg1[POMGPU_KBMAX], ee2[POMGPU_KBMAX], gg2[POMGPU_KBMAX];
   const int kb = P.kb, kbm1 = P.kbm1;
   const double dh = h_(i, j) + F2(etf, i, j);
   const double utau2 = G2(P.s2[4], i, j);
@@ -336,49 +348,67 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
   const int ti = (P.W && i == 2) ? 1 : ((P.E && i == P.imm1) ? P.im : 0);
   const int tj = (P.S && j == 2) ? 1 : ((P.N && j == P.jmm1) ? P.jm : 0);
   const double fsm_c = F2(fsm, i, j);
+  const double m_ti = F2(fsm, ti ? ti : i, j), m_tj = F2(fsm, i, tj ? tj : j), m_tij = F2(fsm, ti ? ti : i, tj ? tj : j);   // masks of the cells that copy this column
+  // the shear + buoyancy production of k_profq_prod is formed here from the same sound speed / density / km / kh this
+  // walk reads anyway (FP = 1, 2: the columns 2..imm1 x 2..jmm1; the rim columns -- ghost cells of a neighbour's owned
+  // column, or a physical edge -- take the exchanged value from s3[0] (FP = 2) or zero)
+  const bool pin = FP && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  // not the two outermost lines: bcond(6) reads the OLD q2, q2l of columns 2 / imm1 / jmm1 (bounds_forcing.f:262-318)
+  const bool ffil = FF && (i >= 3 && i <= P.imm1 - 1 && j >= 3 && j <= P.jmm1 - 1);
+  const int ie = i < P.iml ? i + 1 : i, jn = j < P.jml ? j + 1 : j;
+  const double hij = h_(i, j);
+  const InvD dhk = inv_of(dh * P.kappa);
+  // buffers and per-lane offsets
+  // descriptors are formed where they are used (uniform pointer -> scalar registers); kept as named values they were
+  // carried through the loops in vector registers (too many for the scalar file) at the price of a waterfall loop per load
+#define bt BUF3(A3(t))
+#define bs_ BUF3(A3(s))
+#define brho BUF3(A3(rho))
+#define bq2b BUF3(A3(q2b))
+#define bq2lb BUF3(A3(q2lb))
+#define bq2 BUF3(A3(q2))
+#define bq2l BUF3(A3(q2l))
+#define bkm BUF3(A3(km))
+#define bkh BUF3(A3(kh))
+#define bkq BUF3(A3(kq))
+#define buf BUF3(A3(uf))
+#define bvf BUF3(A3(vf))
+#define bu BUF3(A3(u))
+#define bv BUF3(A3(v))
+#define bl BUF3(A3(l))
+#define bdt BUF3(A3(dtef))
+#define bpr BUF3(P.s3[0])
+#define be1 BUF3(P.s3[4])
+#define be2 BUF3(P.s3[5])
+  const unsigned oc = BOFF2(i, j), oe = BOFF2(ie, j), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  const unsigned o_k = repl ? BOFF_NONE : oc;               // new km, kh, kq: not on physical-edge columns
+  const unsigned o_abs = ffil ? BOFF_NONE : oc;             // |q2b|, |q2lb| on the way down: rewritten on the way up where the filter is fused
+  const unsigned o_fil = ffil ? oc : BOFF_NONE, o_uv = ffil ? BOFF_NONE : oc;
+  const unsigned o_pr = (FP == 0 || (FP == 2 && !pin)) ? oc : BOFF_NONE;
   // boundary values of the two solves -- :1296-1297, :1417-1425
   const double vbot = P.kappa * (1 + F1(z, kbm1)) * dh * F3(q2, i, j, kbm1);
   const double ufbot = F3(uf, i, j, kb);
-  ee1[0] = 0.;
-  gg1[0] = P.cb_profq * utau2;
-  double e1p = 0., g1p = gg1[0];          // ee1, gg1 of level k-1
-  double e2p = 0., g2p = 0.;              // ee2, gg2 of level k-1
-  double ccm = 0., rhom = 0.;             // sound speed and density of level k-1
-  double kqm = 0., kqc = F3(kq, i, j, 1), kqp = F3(kq, i, j, 2);   // OLD kq at k-1, k, k+1
-  // fuse_prod (one tile, nothing to exchange at :1374): the shear + buoyancy production of k_profq_prod
-  // is formed here from the same sound speed / density / km / kh this walk reads anyway, instead of
-  // being written by a kernel of its own and read back
-  // fuse_prod = 2 (tiles): the same for the columns 2..imm1 x 2..jmm1; the rim columns -- ghost cells of a
-  // neighbour's owned column, or a physical edge -- take the exchanged value (or the zero) from s3[0]
-  const bool pin = fuse_prod && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  // not the two outermost lines: bcond(6) reads the OLD q2, q2l of columns 2 / imm1 / jmm1 (bounds_forcing.f:262-318)
-  const bool ffil = fuse_filter && (i >= 3 && i <= P.imm1 - 1 && j >= 3 && j <= P.jmm1 - 1);
-  const int ie = i < P.iml ? i + 1 : i, jn = j < P.jml ? j + 1 : j;
-  double ucm = 0., uem = 0., vcm = 0., vnm = 0.;                   // u(i), u(i+1), v(j), v(j+1) of level k-1
-  // every operand of level k is requested while level k-1 is being worked on: the walk is a chain of dependent
-  // divides and square roots per level, and a level's ~14 loads issued only when it starts leave the memory
-  // pipeline idle for most of it
-  const double hij = h_(i, j);
-  auto lev = [&](int k) {
-    LevQ L;
-    const bool m = (k >= 2 && k <= kbm1);
-    L.t = L.s = L.rho = L.q2lb = L.uf = L.vf = L.uc = L.ue = L.vc = L.vn = L.km = L.kh = L.q2 = 0.;
-    if (k <= kbm1) { L.t = F3(t, i, j, k); L.s = F3(s, i, j, k); L.rho = F3(rho, i, j, k); }
-    L.q2b = F3(q2b, i, j, k);
-    if (pin && k <= kbm1) { L.uc = u_(i, j, k); L.ue = u_(ie, j, k); L.vc = v_(i, j, k); L.vn = v_(i, jn, k); }
-    if (m) {
-      L.q2lb = F3(q2lb, i, j, k);
-      L.uf = F3(uf, i, j, k);
-      if (k >= 3 && k != kbm1) L.vf = F3(vf, i, j, k);
-    }
-    if (!repl || (pin && m)) { L.km = F3(km, i, j, k); L.kh = F3(kh, i, j, k); }
-    if (!repl || k == 2) L.q2 = F3(q2, i, j, k);
-    return L;
+  double e1p = 0., g1p = P.cb_profq * utau2;    // ee1, gg1 of level k-1 (level 1: the surface boundary value)
+  double e2p = 0., g2p = 0.;                    // ee2, gg2 of level k-1
+  double ccm = 0., rhom = 0.;                   // sound speed and density of level k-1
+  double kqm = 0., kqc = F3(kq, i, j, 1);       // OLD kq at k-1, k (k+1 arrives with the level: kq1)
+  double ucm = 0., uem = 0., vcm = 0., vnm = 0.;   // u(i), u(i+1), v(j), v(j+1) of level k-1
+  auto lev = [&](LevQ &L, int k) {              // k = 1..kb; every operand, every lane
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    L.t = bld(bt, oc, lv); L.s = bld(bs_, oc, lv); L.rho = bld(brho, oc, lv);
+    L.q2b = bld(bq2b, oc, lv); L.q2lb = bld(bq2lb, oc, lv); L.q2 = bld(bq2, oc, lv);
+    L.km = bld(bkm, oc, lv); L.kh = bld(bkh, oc, lv);
+    L.uf = bld(buf, oc, lv); L.vf = bld(bvf, oc, lv);
+    if (FP) { L.uc = bld(bu, oc, lv); L.ue = bld(bu, oe, lv); L.vc = bld(bv, oc, lv); L.vn = bld(bv, on, lv); }
+    else L.uc = L.ue = L.vc = L.vn = 0.;
+    L.kq1 = bld(bkq, oc, (unsigned)WAVE_UNIFORM(k < kb ? k : kb - 1) * lvb);     // OLD kq of level k+1 (overwritten two iterations from now)
+    L.prod = (FP != 1) ? bld(bpr, o_pr, lv) : 0.;
   };
-  LevQ cur = lev(1), nxt = cur;
-  for (int k = 1; k <= kb; k++) {
+  auto step = [&](const int k, const LevQ &cur, LevQ &nxt) {
+    lev(nxt, k + 1 <= kb ? k + 1 : kb);         // in flight during this iteration (the last one re-requests level kb)
     const bool mid = (k >= 2 && k <= kbm1);
-    if (k + 1 <= kb) nxt = lev(k + 1);
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    const double kqp = cur.kq1;
     // ---- level-local quantities
     double cck = 0., rhok = 0.;
     if (k <= kbm1) { cck = profq_cc_v(P, cur.t, cur.s, hij, k); rhok = cur.rho; }
@@ -386,13 +416,10 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
     double l, gh = 0.;
     double uck = 0., uek = 0., vck = 0., vnk = 0., bg = 0.;
     if (pin && k <= kbm1) { uck = cur.uc; uek = cur.ue; vck = cur.vc; vnk = cur.vn; }
+    double q2lb = 0.;
     if (mid) {
       q2b = fabs(q2b);                                                                      // :1325-1326
-      const double q2lb = fabs(cur.q2lb);
-      if (!ffil) {                                           // with the fused filter q2b, q2lb are rewritten on the way up
-        F3(q2b, i, j, k) = q2b;
-        F3(q2lb, i, j, k) = q2lb;
-      }
+      q2lb = fabs(cur.q2lb);
       bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * hij) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
       l = fabs(q2lb / q2b);                                                                 // :1338-1344
       if (F1(z, k) > -0.5) l = fmax(l, P.kappa * l0);
@@ -400,18 +427,20 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
     } else {
       l = (k == 1) ? P.kappa * l0 : 0.;                                                     // :1351-1354
     }
-    F3(l, i, j, k) = l;
+    bst(bq2b, mid ? o_abs : BOFF_NONE, lv, q2b);
+    bst(bq2lb, mid ? o_abs : BOFF_NONE, lv, q2lb);
+    bst(bl, oc, lv, l);
     const double dtef1 = sqrt(fabs(q2b)) * 1. / (b1 * l + P.small_);                        // :1388-1389
     double dtef2 = dtef1;
-    if (mid) dtef2 = dtef1 * (1. + e2 * sq((1. / fabs(F1(z, k) - z1) + 1. / fabs(F1(z, k) - zkb)) * l / (dh * P.kappa)));   // :1429-1432
-    F3(dtef, i, j, k) = dtef2;
+    if (mid) dtef2 = dtef1 * (1. + e2 * sq(divi((1. / fabs(F1(z, k) - z1) + 1. / fabs(F1(z, k) - zkb)) * l, dhk)));   // :1429-1432
+    bst(bdt, oc, lv, dtef2);
     // ---- both forward eliminations -- :1394-1404, :1436-1446
     if (mid) {
       const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);      // :1261-1264
       const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
       double pr;
-      if (!fuse_prod || (fuse_prod == 2 && !pin)) {
-        pr = G3(prod, i, j, k);
+      if (FP == 0 || (FP == 2 && !pin)) {
+        pr = cur.prod;
       } else if (pin) {                                                                     // :1359-1373, as k_profq_prod
         const double sef = 1., shiw = 0.;
         const double km = cur.km;
@@ -423,8 +452,6 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
       const double g = 1. / (a + c * (1. - e1p) - (2. * P.dti2 * dtef1 + 1.));
       e1p = a * g;
       g1p = (-2. * P.dti2 * pr + c * g1p - cur.uf) * g;
-      ee1[k - 1] = e1p;
-      gg1[k - 1] = g1p;
       if (k == 2) {
         e2p = 0.;
         g2p = -P.kappa * F1(z, 2) * dh * cur.q2;
@@ -434,88 +461,129 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int fuse_prod, int fuse_fil
         e2p = a * g2;
         g2p = (P.dti2 * (-pr * l * e1) + c * g2p - rhs) * g2;
       }
-      ee2[k - 1] = e2p;
-      gg2[k - 1] = g2p;
+    }
+    // the vectors' level k (level 1: the boundary values; level kb has none -- and uf, vf of level kb stay what they are)
+    {
+      const unsigned ov = (k <= kbm1) ? oc : BOFF_NONE;
+      bst(be1, ov, lv, e1p); bst(buf, ov, lv, g1p); bst(be2, ov, lv, e2p); bst(bvf, ov, lv, g2p);
     }
     // ---- new mixing coefficients -- :1484-1503, cosmetics + mask :1510-1535
-    if (!repl) {
+    double kq_n = 0., km_n = 0., kh_n = 0.;
+    {
       const double sh = coef1 / (1. - coef2 * gh);
       double sm = coef3 + sh * coef4 * gh;
       sm = sm / (1. - coef5 * gh);
       const double pl = l * sqrt(fabs(cur.q2));
-      const double kq = (pl * .41 * sh + kqc) * .5;
-      const double km = (pl * sm + cur.km) * .5;
-      const double kh = (pl * sh + cur.kh) * .5;
-      // own cell: in place (old kq lives on in kqm/kqc/kqp).  Physical-edge cells that copy this
-      // column are written to the staging arrays s3[1..3] (their own threads still read the old
-      // kq) and moved by k_profq_rim.
-      F3(kq, i, j, k) = kq * fsm_c;
-      F3(km, i, j, k) = km * fsm_c;
-      F3(kh, i, j, k) = kh * fsm_c;
-#define PUT(ii, jj)                                  \
+      kq_n = (pl * .41 * sh + kqc) * .5;
+      km_n = (pl * sm + cur.km) * .5;
+      kh_n = (pl * sh + cur.kh) * .5;
+      // own cell: in place (old kq lives on in kqm / kqc / kq1)
+      bst(bkq, o_k, lv, kq_n * fsm_c);
+      bst(bkm, o_k, lv, km_n * fsm_c);
+      bst(bkh, o_k, lv, kh_n * fsm_c);
+    }
+    // Physical-edge cells that copy this column are written to the staging arrays s3[1..3] (their own threads still
+    // read the old kq) and moved by k_profq_rim.  Stores only, in the few columns next to such an edge.
+    if ((ti | tj) && !repl) {
+#define PUT(ii, jj, m)                               \
   {                                                  \
-    const double m = F2(fsm, ii, jj);                \
-    G3(P.s3[1], ii, jj, k) = km * m;                 \
-    G3(P.s3[2], ii, jj, k) = kh * m;                 \
-    G3(P.s3[3], ii, jj, k) = kq * m;                 \
+    G3(P.s3[1], ii, jj, k) = km_n * m;               \
+    G3(P.s3[2], ii, jj, k) = kh_n * m;               \
+    G3(P.s3[3], ii, jj, k) = kq_n * m;               \
   }
-      if (ti) PUT(ti, j)
-      if (tj) PUT(i, tj)
-      if (ti && tj) PUT(ti, tj)
+      if (ti) PUT(ti, j, m_ti)
+      if (tj) PUT(i, tj, m_tj)
+      if (ti && tj) PUT(ti, tj, m_tij)
 #undef PUT
     }
     ccm = cck; rhom = rhok;
     ucm = uck; uem = uek; vcm = vck; vnm = vnk;
     kqm = kqc; kqc = kqp;
-    if (k + 2 <= kb) kqp = F3(kq, i, j, k + 2);
-    cur = nxt;
-  }
-  // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468
-  if (!ffil) {
-    double x = ufbot, y = 0.;
-    for (int ki = kbm1; ki >= 1; ki--) {
-      x = ee1[ki - 1] * x + gg1[ki - 1];
-      F3(uf, i, j, ki) = (ki >= 2) ? fabs(x) : x;
-      if (ki >= 2) {
-        y = ee2[ki - 1] * y + gg2[ki - 1];
-        F3(vf, i, j, ki) = fabs(y);
-      }
+  };
+  {
+    LevQ ra, rb;
+    lev(ra, 1);
+    rb = ra;
+    for (int k = 1; k <= kb; k += 2) {
+      step(k, ra, rb);
+      if (k + 1 <= kb) step(k + 1, rb, ra);
     }
-    F3(vf, i, j, 1) = 0.;
-    F3(vf, i, j, kb) = 0.;
-  } else {
-    const double hs = .5 * P.smoth;
-    // one level of k_q_filter: bcond(6)'s mask, Asselin filter, rotation; q2b, q2lb as k_profq leaves them
-    // (|.| at 2..kbm1).  The four operands of the level above are requested one iteration ahead.
-    struct QL { double qb, qlb, q, ql; };
-    auto qload = [&](int k) { QL L; L.qb = F3(q2b, i, j, k); L.qlb = F3(q2lb, i, j, k); L.q = F3(q2, i, j, k); L.ql = F3(q2l, i, j, k); return L; };
-    auto filt = [&](int k, const QL &L, double ufv, double vfv) {
-      const double ufm = ufv * fsm_c + 1.e-10, vfm = vfv * fsm_c + 1.e-10;
-      double qb = L.qb, qlb = L.qlb;
-      if (k >= 2 && k <= kbm1) { qb = fabs(qb); qlb = fabs(qlb); }
-      F3(q2b, i, j, k) = L.q + hs * (ufm + qb - 2. * L.q);
-      F3(q2, i, j, k) = ufm;
-      F3(q2lb, i, j, k) = L.ql + hs * (vfm + qlb - 2. * L.ql);
-      F3(q2l, i, j, k) = vfm;
-      if (k == kb) { F3(uf, i, j, k) = ufm; F3(vf, i, j, k) = vfm; }   // advt leaves level kb of uf, vf as it finds it
-    };
-    QL cur = qload(kb), nxt = qload(kbm1);
-    filt(kb, cur, ufbot, 0.);
-    double x = ufbot, y = 0.;
-    for (int ki = kbm1; ki >= 1; ki--) {
-      cur = nxt;
-      if (ki >= 2) nxt = qload(ki - 1);
-      x = ee1[ki - 1] * x + gg1[ki - 1];
-      double yv = 0.;
-      if (ki >= 2) {
-        y = ee2[ki - 1] * y + gg2[ki - 1];
-        yv = fabs(y);
+  }
+  // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468; with the fused filter one level of k_q_filter rides
+  // on every level: bcond(6)'s mask, Asselin filter, rotation; q2b, q2lb as the walk down leaves them (|.| at 2..kbm1)
+  const double hs = .5 * P.smoth;
+  auto levb = [&](LevB &L, int k) {             // k = 1..kb
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    L.e1 = bld(be1, oc, lv); L.g1 = bld(buf, oc, lv); L.e2 = bld(be2, oc, lv); L.g2 = bld(bvf, oc, lv);
+    if (FF) { L.qb = bld(bq2b, oc, lv); L.qlb = bld(bq2lb, oc, lv); L.q = bld(bq2, oc, lv); L.ql = bld(bq2l, oc, lv); }
+    else L.qb = L.qlb = L.q = L.ql = 0.;
+  };
+  auto filt = [&](int k, const LevB &L, double ufv, double vfv) {
+    const double ufm = ufv * fsm_c + 1.e-10, vfm = vfv * fsm_c + 1.e-10;
+    double qb = L.qb, qlb = L.qlb;
+    if (k >= 2 && k <= kbm1) { qb = fabs(qb); qlb = fabs(qlb); }
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    bst(bq2b, o_fil, lv, L.q + hs * (ufm + qb - 2. * L.q));
+    bst(bq2, o_fil, lv, ufm);
+    bst(bq2lb, o_fil, lv, L.ql + hs * (vfm + qlb - 2. * L.ql));
+    bst(bq2l, o_fil, lv, vfm);
+    return ufm;
+  };
+  double x = ufbot, y = 0.;
+  auto stepb = [&](const int ki, const LevB &cur, LevB &nxt) {   // ki = kb (filter only) .. 1
+    levb(nxt, ki > 1 ? ki - 1 : 1);
+    const unsigned lv = (unsigned)WAVE_UNIFORM(ki - 1) * lvb;
+    if (ki == kb) {
+      if (FF) {
+        const double ufm = ufbot * fsm_c + 1.e-10, vfm = 0. * fsm_c + 1.e-10;
+        filt(kb, cur, ufbot, 0.);
+        bst(buf, o_fil, lv, ufm);                           // advt leaves level kb of uf, vf as it finds it
+        bst(bvf, o_fil, lv, vfm);
       }
-      filt(ki, cur, (ki >= 2) ? fabs(x) : x, yv);
+      bst(bvf, o_uv, lv, 0.);                               // without the filter: vf(kb) = 0
+      return;
+    }
+    x = cur.e1 * x + cur.g1;
+    double yv = 0.;
+    if (ki >= 2) {
+      y = cur.e2 * y + cur.g2;
+      yv = fabs(y);
+    }
+    const double xv = (ki >= 2) ? fabs(x) : x;
+    if (FF) filt(ki, cur, xv, yv);
+    bst(buf, o_uv, lv, xv);
+    bst(bvf, o_uv, lv, yv);                                 // level 1: 0
+  };
+  {
+    LevB ra, rb;
+    levb(ra, kb);
+    rb = ra;
+    for (int ki = kb; ki >= 1; ki -= 2) {
+      stepb(ki, ra, rb);
+      if (ki - 1 >= 1) stepb(ki - 1, rb, ra);
     }
   }
 }
 
+#undef bt
+#undef bs_
+#undef brho
+#undef bq2b
+#undef bq2lb
+#undef bq2
+#undef bq2l
+#undef bkm
+#undef bkh
+#undef bkq
+#undef buf
+#undef bvf
+#undef bu
+#undef bv
+#undef bl
+#undef bdt
+#undef bpr
+#undef be1
+#undef be2
 // (4) move the staged km/kh/kq of the physical-edge cells into place (solver.f:1510-1529)
 __global__ void k_profq_rim(KP P) {
   const int t = TID_I, line = (int)blockIdx.y, k = TID_K;
@@ -1129,7 +1197,10 @@ void launch_profq_prod(pomgpu_ctx *c, int lines_only) {
   LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P);
 }
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter) {
-  LAUNCH(c, k_profq, colgrid(c->P), colblk(), c->P, fuse_prod, fuse_filter);
+#define PQ(FP, FF) LAUNCHN(c, "k_profq", (k_profq<FP, FF>), colgrid(c->P), colblk(), c->P)
+  if (fuse_filter) { if (fuse_prod == 0) PQ(0, 1); else if (fuse_prod == 1) PQ(1, 1); else PQ(2, 1); }
+  else { if (fuse_prod == 0) PQ(0, 0); else if (fuse_prod == 1) PQ(1, 0); else PQ(2, 0); }
+#undef PQ
   const KP &P = c->P;
   if (P.W || P.E || P.S || P.N) {
     const int len = P.im > P.jm ? P.im : P.jm;
