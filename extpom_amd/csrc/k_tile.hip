@@ -104,9 +104,9 @@ __device__ __forceinline__ FaceT advt2_face(const KP &P, const CoefT &c, double 
 //   * buffer addressing: no vector instruction computes an address; two register sets alternate as current / next
 //     level (no copies); divisors that are fixed along the column are inverted once (divi).
 template <int NF>
-__global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
+__global__ void __launch_bounds__(64 * LDS_ROWS) k_advt2_col(KP P, TFields A) {
   constexpr int NS = 2 * NF + 2, NH = ROWSHARE_SLOTS(NS), AM = 2 * NF, VV = 2 * NF + 1;
-  HALO_XCD_DECODE                                           // a workgroup outside the grid leaves as a whole
+  HALO_XCD_DECODE_R(LDS_ROWS)                                           // a workgroup outside the grid leaves as a whole
   const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
   const bool jrow = j <= P.jml;                             // rows beyond the tile shadow row jml and store nothing
   const int jc = jrow ? j : P.jml;
@@ -239,95 +239,141 @@ __global__ void __launch_bounds__(64 * COL_ROWS) k_advt2_col(KP P, TFields A) {
 // NF = 2 advances q2 and q2l in ONE pass (advance.f:407-408 calls advq twice): u, v, w, aam and every
 // face coefficient are read once for both -- 12.5 array passes instead of 2 x 9.5.
 struct QFields { const double *q[2], *qb[2]; double *qf[2]; };
-template <int NF> struct LevQ { double q_c[NF], q_s[NF], q_n[NF], qb_c[NF], qb_s[NF], qb_n[NF], am_c, am_s, am_n, u_c, v_c, v_n, w_c; };
-template <int NF> __device__ __forceinline__ LevQ<NF> advq_load(const KP &P, const QFields &A, int i, int js, int j, int jn, int k) {
-  LevQ<NF> L;
-#pragma unroll
-  for (int f = 0; f < NF; f++) {
-    L.q_c[f] = G3(A.q[f], i, j, k);    L.q_s[f] = G3(A.q[f], i, js, k);    L.q_n[f] = G3(A.q[f], i, jn, k);
-    L.qb_c[f] = G3(A.qb[f], i, j, k);  L.qb_s[f] = G3(A.qb[f], i, js, k);  L.qb_n[f] = G3(A.qb[f], i, jn, k);
-  }
-  L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
-  L.u_c = F3(u, i, j, k);    L.v_c = F3(v, i, j, k);     L.v_n = F3(v, i, jn, k);
-  L.w_c = F3(w, i, j, k);
-  return L;
-}
-struct CoefQ { double dts, hs, msk, ds_den, ds_num; };
+// operands of a level, shared through the workgroup's LDS slab in this order: q[0..NF-1], qb[0..NF-1], aam, v; own row only: u, w
+template <int NF> struct LevQa { double c[2 * NF + 2], o[2], h[ROWSHARE_SLOTS(2 * NF + 2)]; };
+struct CoefQ { double dts, hs, msk, ds_num; InvD den; };
 __device__ __forceinline__ CoefQ coefq_x(const KP &P, int i, int j) {
-  CoefQ c; c.dts = K2(DTSX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.ds_den = K2(DXSX, i, j); c.ds_num = K2(DYSX, i, j); return c;
+  CoefQ c; c.dts = K2(DTSX, i, j); c.hs = K2(HSX, i, j); c.msk = F2(dum, i, j); c.den = inv_of(K2(DXSX, i, j)); c.ds_num = K2(DYSX, i, j); return c;
 }
 __device__ __forceinline__ CoefQ coefq_y(const KP &P, int i, int j) {
-  CoefQ c; c.dts = K2(DTSY, i, j); c.hs = K2(HSY, i, j); c.msk = F2(dvm, i, j); c.ds_den = K2(DYSY, i, j); c.ds_num = K2(DXSY, i, j); return c;
+  CoefQ c; c.dts = K2(DTSY, i, j); c.hs = K2(HSY, i, j); c.msk = F2(dvm, i, j); c.den = inv_of(K2(DYSY, i, j)); c.ds_num = K2(DXSY, i, j); return c;
 }
 // flux through the face between a "lo" (west/south) and a "hi" cell at w-level k (:428-453)
 __device__ __forceinline__ double advq_face(const CoefQ &c, double q_hi, double q_lo, double vel_k, double vel_km1, double am_hi_k,
                                             double am_lo_k, double am_hi_m, double am_lo_m, double qb_hi, double qb_lo) {
   double x = .125 * (q_hi + q_lo) * c.dts * (vel_k + vel_km1);
-  x = x - .25 * (am_hi_k + am_lo_k + am_hi_m + am_lo_m) * c.hs * (qb_hi - qb_lo) * c.msk / c.ds_den;
+  x = x - divi(.25 * (am_hi_k + am_lo_k + am_hi_m + am_lo_m) * c.hs * (qb_hi - qb_lo) * c.msk, c.den);
   return .5 * c.ds_num * x;
 }
+// loop discipline and row sharing as in k_advt2_col
 template <int NF>
-__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advq_col(KP P, QFields A, int zero_else) {
-  HALO_XCD_DECODE
-  const int j0 = j;
-  if (j0 > P.jml) return;
-  const bool icol = (lane >= 1 && lane <= 62 && i0 <= P.iml);
+__global__ void __launch_bounds__(64 * LDS_ROWS) k_advq_col(KP P, QFields A, int zero_else) {
+  constexpr int NS = 2 * NF + 2, NH = ROWSHARE_SLOTS(NS), AM = 2 * NF, VV = 2 * NF + 1;
+  HALO_XCD_DECODE_R(LDS_ROWS)
+  const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
+  const bool jrow = j <= P.jml;
+  const int jc = jrow ? j : P.jml;
+  const bool icol = jrow && (lane >= 1 && lane <= 62 && i0 <= P.iml);
 #ifdef POMGPU_EMU
   if (!icol) return;
 #endif
   const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
-  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
-  const bool in = icol && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
-  const CoefQ cw = coefq_x(P, i, j), cs = coefq_y(P, i, j), cn = coefq_y(P, i, jn);
-  const double art = F2(art, i, j), hea = K2(HEA, i, j), hfa = K2(HFA, i, j);
+  const int js = jc > 1 ? jc - 1 : 1, jn = jc < P.jml ? jc + 1 : P.jml;
+  const bool in = icol && (i >= 2 && i <= P.imm1 && jc >= 2 && jc <= P.jmm1);
+  const CoefQ cw = coefq_x(P, i, jc), cs = coefq_y(P, i, jc), cn = coefq_y(P, i, jn);
+  const double art = F2(art, i, jc), hea = K2(HEA, i, jc);
+  const InvD hfa = inv_of(K2(HFA, i, jc));
   const int kb = P.kb, kbm1 = P.kbm1;
-  LevQ<NF> cur = advq_load<NF>(P, A, i, js, j, jn, 1), nxt = cur;
+  BufA bs[NS], bo[2], bqf[NF], bh[NH];
+  const double *ps[NS];
+#pragma unroll
+  for (int f = 0; f < NF; f++) { ps[f] = A.q[f]; ps[NF + f] = A.qb[f]; bqf[f] = BUF3(A.qf[f]); }
+  ps[AM] = A3(aam); ps[VV] = A3(v); bo[0] = BUF3(A3(u)); bo[1] = BUF3(A3(w));
+#pragma unroll
+  for (int x = 0; x < NS; x++) bs[x] = BUF3(ps[x]);
+  const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
+#pragma unroll
+  for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
+  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  // interior columns get the new value, every other owned column a zero (zero_else) or nothing
+  const unsigned ost = in ? oc : ((zero_else && icol) ? oc : BOFF_NONE);
+#ifndef POMGPU_EMU
+  __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
+#else
+  const unsigned os = BOFF2(i, js), on = BOFF2(i, jn);
+#endif
+  auto load = [&](LevQa<NF> &L, int k) {
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+#pragma unroll
+    for (int x = 0; x < NS; x++) L.c[x] = bld(bs[x], oc, lv);
+    L.o[0] = bld(bo[0], oc, lv); L.o[1] = bld(bo[1], oc, lv);
+#pragma unroll
+    for (int q = 0; q < NH; q++) L.h[q] = bld(bh[q], S.hoff[q], lv);
+  };
   double u_m = 0., v_m = 0., vn_m = 0., am_m = 0., ams_m = 0., amn_m = 0.;   // u, v, v(j+1), aam (c, s, n) of level L-1
   double am_w_prv = 0.;                       // aam(i-1,j,L-1) as seen by this lane
   double wq_pp[NF], wq_p[NF];                 // w*q of levels L-2 and L-1
   double xe_p[NF], xw_p[NF], yn_p[NF], ys_p[NF], qb_p[NF];   // faces and qb of level L-1, waiting for w(L)*q(L)
 #pragma unroll
   for (int f = 0; f < NF; f++) wq_pp[f] = wq_p[f] = xe_p[f] = xw_p[f] = yn_p[f] = ys_p[f] = qb_p[f] = 0.;
-  for (int L = 1; L <= kb; L++) {
-    if (L + 1 <= kb) nxt = advq_load<NF>(P, A, i, js, j, jn, L + 1);
-    const double am_w = halo_w(cur.am_c, [&] { return F3(aam, iw, j, L); });
+  auto step = [&](const int L, const int par, const LevQa<NF> &cur, LevQa<NF> &nxt) {
+    load(nxt, L + 1 <= kb ? L + 1 : kb);                    // the last iterations re-request level kb
+    NbrT<NS> nb;
+#ifndef POMGPU_EMU
+#pragma unroll
+    for (int x = 0; x < NS; x++) slab[par][x][r + 1][lane] = cur.c[x];
+#pragma unroll
+    for (int q = 0; q < NH; q++) slab[par][S.hop[q]][S.hrow[q]][lane] = cur.h[q];
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = slab[par][x][S.ss][lane]; nb.n[x] = slab[par][x][S.sn][lane]; }
+#else
+    const unsigned lvc = (unsigned)((L <= kb ? L : kb) - 1) * lvb;
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = bld(bs[x], os, lvc); nb.n[x] = bld(bs[x], on, lvc); }
+#endif
+    const double am_c = cur.c[AM], v_c = cur.c[VV], u_c = cur.o[0], w_c = cur.o[1];
+    const double am_s = nb.s[AM], am_n = nb.n[AM], v_n = nb.n[VV];
+    const double am_w = halo_w(am_c, [&] { return F3(aam, iw, jc, L); });
+    const int k = L - 1;                                    // level completed in this iteration
+    InvD dz2; dz2.b = dz2.y = 0.;
+    if (k >= 2 && k <= kbm1) { dz2.b = F1(dz, k) + F1(dz, k - 1); dz2.y = 1.0 / dz2.b; }
 #pragma unroll
     for (int f = 0; f < NF; f++) {
+      const double q_c = cur.c[f], qb_c = cur.c[NF + f];
       double xe_c = 0., xw_c = 0., yn_c = 0., ys_c = 0.;
       if (L >= 2 && L <= kbm1) {
-        const double q_w = halo_w(cur.q_c[f], [&] { return G3(A.q[f], iw, j, L); });
-        const double qb_w = halo_w(cur.qb_c[f], [&] { return G3(A.qb[f], iw, j, L); });
-        const double xw = advq_face(cw, cur.q_c[f], q_w, cur.u_c, u_m, cur.am_c, am_w, am_m, am_w_prv, cur.qb_c[f], qb_w);
+        const double q_w = halo_w(q_c, [&] { return G3(A.q[f], iw, jc, L); });
+        const double qb_w = halo_w(qb_c, [&] { return G3(A.qb[f], iw, jc, L); });
+        const double xw = advq_face(cw, q_c, q_w, u_c, u_m, am_c, am_w, am_m, am_w_prv, qb_c, qb_w);
         xw_c = xw;
         xe_c = halo_e(xw, [&] {                             // emulation only: the east face from memory
-          return advq_face(coefq_x(P, ie, j), G3(A.q[f], ie, j, L), cur.q_c[f], F3(u, ie, j, L), F3(u, ie, j, L - 1), F3(aam, ie, j, L), cur.am_c,
-                           F3(aam, ie, j, L - 1), am_m, G3(A.qb[f], ie, j, L), cur.qb_c[f]);
+          return advq_face(coefq_x(P, ie, jc), G3(A.q[f], ie, jc, L), q_c, F3(u, ie, jc, L), F3(u, ie, jc, L - 1), F3(aam, ie, jc, L), am_c,
+                           F3(aam, ie, jc, L - 1), am_m, G3(A.qb[f], ie, jc, L), qb_c);
         });
-        ys_c = advq_face(cs, cur.q_c[f], cur.q_s[f], cur.v_c, v_m, cur.am_c, cur.am_s, am_m, ams_m, cur.qb_c[f], cur.qb_s[f]);
-        yn_c = advq_face(cn, cur.q_n[f], cur.q_c[f], cur.v_n, vn_m, cur.am_n, cur.am_c, amn_m, am_m, cur.qb_n[f], cur.qb_c[f]);
+        ys_c = advq_face(cs, q_c, nb.s[f], v_c, v_m, am_c, am_s, am_m, ams_m, qb_c, nb.s[NF + f]);
+        yn_c = advq_face(cn, nb.n[f], q_c, v_n, vn_m, am_n, am_c, amn_m, am_m, nb.n[NF + f], qb_c);
       }
-      const double wq_c = cur.w_c * cur.q_c[f];
-      if (icol) {
-        const int k = L - 1;                                 // level completed in this iteration
+      const double wq_c = w_c * q_c;
+      {
+        double rr = 0.;
         if (in && k >= 2 && k <= kbm1) {
-          double r = (wq_pp[f] - wq_c) * art / (F1(dz, k) + F1(dz, k - 1)) + xe_p[f] - xw_p[f] + yn_p[f] - ys_p[f];   // :465-468
-          r = (hea * qb_p[f] - P.dti2 * r) / hfa;                                               // :469-471
-          G3(A.qf[f], i, j, k) = r;
-        } else if (zero_else && k >= 1) {
-          G3(A.qf[f], i, j, k) = 0.;
+          rr = divi((wq_pp[f] - wq_c) * art, dz2) + xe_p[f] - xw_p[f] + yn_p[f] - ys_p[f];    // :465-468
+          rr = divi(hea * qb_p[f] - P.dti2 * rr, hfa);                                        // :469-471
         }
+        // levels 2..kbm1 of interior columns: the new value; with zero_else every other owned cell (levels 1..kb-1 here,
+        // kb below): zero; everything else aims outside the buffer
+        const bool lev_in = (k >= 2 && k <= kbm1);
+        const unsigned o = (k >= 1) ? (lev_in ? ost : ((zero_else && icol) ? oc : BOFF_NONE)) : BOFF_NONE;
+        bst(bqf[f], o, (unsigned)WAVE_UNIFORM(k >= 1 ? k - 1 : 0) * lvb, rr);
       }
-      wq_pp[f] = wq_p[f]; wq_p[f] = wq_c; qb_p[f] = cur.qb_c[f];
+      wq_pp[f] = wq_p[f]; wq_p[f] = wq_c; qb_p[f] = qb_c;
       xe_p[f] = xe_c; xw_p[f] = xw_c; yn_p[f] = yn_c; ys_p[f] = ys_c;
     }
     am_w_prv = am_w;
-    u_m = cur.u_c; v_m = cur.v_c; vn_m = cur.v_n; am_m = cur.am_c; ams_m = cur.am_s; amn_m = cur.am_n;
-    cur = nxt;
+    u_m = u_c; v_m = v_c; vn_m = v_n; am_m = am_c; ams_m = am_s; amn_m = am_n;
+  };
+  LevQa<NF> ra, rb;
+  load(ra, 1);
+  rb = ra;
+  for (int L = 1; L <= kb; L += 2) {
+    step(L, 1, ra, rb);
+    if (L + 1 <= kb) step(L + 1, 0, rb, ra);                // uniform for the whole workgroup (barrier inside)
   }
   if (icol && zero_else) {
 #pragma unroll
-    for (int f = 0; f < NF; f++) G3(A.qf[f], i, j, kb) = 0.;
+    for (int f = 0; f < NF; f++) G3(A.qf[f], i, jc, kb) = 0.;
   }
 }
 
@@ -344,16 +390,6 @@ __global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advq_col(KP P, QFiel
 // west operands / west face flux of lane 1, lane 63 the east operands / corner flux of lane 62), so
 // no lane ever needs a mid-iteration fallback load (vmcnt is in-order) and no flux is evaluated
 // from memory.  Wave w covers columns 62w .. 62w+63.
-struct LevC { double u_c, u_s, u_n, v_c, v_s, v_n, ub_c, ub_s, ub_n, vb_c, vb_s, vb_n, am_c, am_s, am_n; };
-__device__ __forceinline__ LevC advct_load(const KP &P, int i, int js, int j, int jn, int k) {
-  LevC L;
-  L.u_c = F3(u, i, j, k);    L.u_s = F3(u, i, js, k);    L.u_n = F3(u, i, jn, k);
-  L.v_c = F3(v, i, j, k);    L.v_s = F3(v, i, js, k);    L.v_n = F3(v, i, jn, k);
-  L.ub_c = F3(ub, i, j, k);  L.ub_s = F3(ub, i, js, k);  L.ub_n = F3(ub, i, jn, k);
-  L.vb_c = F3(vb, i, j, k);  L.vb_s = F3(vb, i, js, k);  L.vb_n = F3(vb, i, jn, k);
-  L.am_c = F3(aam, i, j, k); L.am_s = F3(aam, i, js, k); L.am_n = F3(aam, i, jn, k);
-  return L;
-}
 // the same quantities evaluated from memory (emulation fallbacks only); i, j inside the tile
 __device__ double advct_xf_mem(const KP &P, int i, int j, int k) {                 // x-eq. xflux, 2<=j
   if (i < 2 || i > P.imm1) return 0.;
@@ -433,114 +469,169 @@ __global__ void k_advct_fix(KP P, const double *from_w, const double *from_s) {
   }
 }
 // sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
-__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advct_col(KP P, int sum2d) {
-  HALO_XCD_DECODE                                           // i0: 1-based column of this lane (0 for the very first halo lane)
-  if (j > P.jml) return;                                    // whole wavefront (one row) leaves together
-  const bool out = (lane >= 1 && lane <= 62 && i0 <= P.iml);
+// Operands of a level, all five shared through the workgroup's LDS slab (rows j-1, j, j+1): u, v, ub, vb, aam.
+// Loop discipline and row sharing as in k_advt2_col.
+struct LevCa { double c[5], h[ROWSHARE_SLOTS(5)]; };
+__global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
+  constexpr int NS = 5, NH = ROWSHARE_SLOTS(NS), U = 0, V = 1, UB = 2, VB = 3, AM = 4;
+  HALO_XCD_DECODE_R(LDS_ROWS)                                           // i0: 1-based column of this lane (0 for the very first halo lane)
+  const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
+  const bool jvalid = j <= P.jml;                           // rows beyond the tile shadow row jml and store nothing
+  const int jc = jvalid ? j : P.jml;
+  const bool out = jvalid && (lane >= 1 && lane <= 62 && i0 <= P.iml);
 #ifdef POMGPU_EMU
   if (!out) return;
 #endif
   const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
-  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
-  const bool jrow = (j >= 2 && j <= P.jmm1);
+  const int js = jc > 1 ? jc - 1 : 1, jn = jc < P.jml ? jc + 1 : P.jml;
+  const bool jrow = (jc >= 2 && jc <= P.jmm1);
   const bool iin = (i0 >= 2 && i0 <= P.imm1);
   const bool in = out && iin && jrow;
   const int kb = P.kb, kbm1 = P.kbm1;
-  if (!jrow) {                                              // rim rows: advx = advy = 0 (solver.f:211,:317)
-    if (out) {
-      for (int k = 1; k <= kb; k++) { F3(advx, i, j, k) = 0.; F3(advy, i, j, k) = 0.; }
-      if (sum2d) { F2(adx2d, i, j) = 0.; F2(ady2d, i, j) = 0.; }
-    }
-    return;
-  }
   double ax2 = 0., ay2 = 0.;
   // column-resident coefficients
-  const double dtsx_c = K2(DTSX, i, j), dtsx_s = K2(DTSX, i, js);
-  const double dtsx_e = halo_e(dtsx_c, [&] { return K2(DTSX, ie, j); });
-  const double dtsy_c = K2(DTSY, i, j), dtsy_n = K2(DTSY, i, jn), dtsy_s = K2(DTSY, i, js);
-  const double dtsy_w = halo_w(dtsy_c, [&] { return K2(DTSY, iw, j); });
+  const double dtsx_c = K2(DTSX, i, jc), dtsx_s = K2(DTSX, i, js);
+  const double dtsx_e = halo_e(dtsx_c, [&] { return K2(DTSX, ie, jc); });
+  const double dtsy_c = K2(DTSY, i, jc), dtsy_n = K2(DTSY, i, jn), dtsy_s = K2(DTSY, i, js);
+  const double dtsy_w = halo_w(dtsy_c, [&] { return K2(DTSY, iw, jc); });
   const double dtsy_nw = halo_w(dtsy_n, [&] { return K2(DTSY, iw, jn); });
-  const double dt4_c = K2(DT4, i, j), dt4_n = K2(DT4, i, jn);
-  const double dx4_c = K2(DX4, i, j), dx4_n = K2(DX4, i, jn), dy4_c = K2(DY4, i, j), dy4_n = K2(DY4, i, jn);
-  const double dt_c = F2(dt, i, j), dx_c = F2(dx, i, j), dy_c = F2(dy, i, j);
-  const double dt_s = F2(dt, i, js), dx_s = F2(dx, i, js), dy_s = F2(dy, i, js);
-  const double cva_c = K2(CVA, i, j), cvb_c = K2(CVB, i, j), art_c = F2(art, i, j);
-  const double cva_s = K2(CVA, i, js), cvb_s = K2(CVB, i, js), art_s = F2(art, i, js);
-  const double aru = F2(aru, i, j), arv = F2(arv, i, j);
-  const bool srow = (j - 1 >= 2);                           // row j-1 carries y-eq. fluxes / curv
-  const bool curvx = (i0 >= (P.W ? 3 : 2)), curvy = (j >= (P.S ? 3 : 2));
-  LevC c = advct_load(P, i, js, j, jn, 1), nxt = c;
-  for (int k = 1; k <= kbm1; k++) {
-    if (k + 1 <= kbm1) nxt = advct_load(P, i, js, j, jn, k + 1);      // in flight during this iteration
-    const double u_e = halo_e(c.u_c, [&] { return F3(u, ie, j, k); });
-    const double u_se = halo_e(c.u_s, [&] { return F3(u, ie, js, k); });
-    const double ub_e = halo_e(c.ub_c, [&] { return F3(ub, ie, j, k); });
-    const double v_w = halo_w(c.v_c, [&] { return F3(v, iw, j, k); });
-    const double v_nw = halo_w(c.v_n, [&] { return F3(v, iw, jn, k); });
-    const double vb_w = halo_w(c.vb_c, [&] { return F3(vb, iw, j, k); });
-    const double vb_nw = halo_w(c.vb_n, [&] { return F3(vb, iw, jn, k); });
-    const double am_w = halo_w(c.am_c, [&] { return F3(aam, iw, j, k); });
-    const double am_sw = halo_w(c.am_s, [&] { return F3(aam, iw, js, k); });
-    const double am_nw = halo_w(c.am_n, [&] { return F3(aam, iw, jn, k); });
+  const double dt4_c = K2(DT4, i, jc), dt4_n = K2(DT4, i, jn);
+  const double dx4_c = K2(DX4, i, jc), dx4_n = K2(DX4, i, jn);
+  const InvD dy4_c = inv_of(K2(DY4, i, jc)), dy4_n = inv_of(K2(DY4, i, jn)), idx4_c = inv_of(dx4_c), idx4_n = inv_of(dx4_n);
+  const double dt_c = F2(dt, i, jc), dy_c = F2(dy, i, jc), dx_c = F2(dx, i, jc);
+  const double dt_s = F2(dt, i, js), dx_s = F2(dx, i, js);
+  const InvD idx_c = inv_of(dx_c), idy_c = inv_of(dy_c), idy_s = inv_of(F2(dy, i, js));
+  const double cva_c = K2(CVA, i, jc), cvb_c = K2(CVB, i, jc);
+  const double cva_s = K2(CVA, i, js), cvb_s = K2(CVB, i, js);
+  const InvD art_c = inv_of(F2(art, i, jc)), art_s = inv_of(F2(art, i, js));
+  const double aru = F2(aru, i, jc), arv = F2(arv, i, jc);
+  const bool srow = (jc - 1 >= 2);                          // row j-1 carries y-eq. fluxes / curv
+  const bool curvx = (i0 >= (P.W ? 3 : 2)), curvy = (jc >= (P.S ? 3 : 2));
+  BufA bs[NS], bh[NH];
+  const double *ps[NS] = {A3(u), A3(v), A3(ub), A3(vb), A3(aam)};
+#pragma unroll
+  for (int x = 0; x < NS; x++) bs[x] = BUF3(ps[x]);
+  const BufA bax = BUF3(A3(advx)), bay = BUF3(A3(advy));
+  const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
+#pragma unroll
+  for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
+  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  const unsigned ost = (out && jrow) ? oc : BOFF_NONE;      // rim rows are zeroed after the loop
+#ifndef POMGPU_EMU
+  __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
+#else
+  const unsigned os = BOFF2(i, js), on = BOFF2(i, jn);
+#endif
+  auto load = [&](LevCa &L, int k) {
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+#pragma unroll
+    for (int x = 0; x < NS; x++) L.c[x] = bld(bs[x], oc, lv);
+#pragma unroll
+    for (int q = 0; q < NH; q++) L.h[q] = bld(bh[q], S.hoff[q], lv);
+  };
+  auto step = [&](const int k, const int par, const LevCa &cur, LevCa &nxt) {
+    load(nxt, k + 1 <= kbm1 ? k + 1 : kbm1);                // in flight during this iteration (the last one re-requests level kbm1)
+    NbrT<NS> nb;
+#ifndef POMGPU_EMU
+#pragma unroll
+    for (int x = 0; x < NS; x++) slab[par][x][r + 1][lane] = cur.c[x];
+#pragma unroll
+    for (int q = 0; q < NH; q++) slab[par][S.hop[q]][S.hrow[q]][lane] = cur.h[q];
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = slab[par][x][S.ss][lane]; nb.n[x] = slab[par][x][S.sn][lane]; }
+#else
+    const unsigned lvc = (unsigned)(k - 1) * lvb;
+#pragma unroll
+    for (int x = 0; x < NS; x++) { nb.s[x] = bld(bs[x], os, lvc); nb.n[x] = bld(bs[x], on, lvc); }
+#endif
+    const double u_c = cur.c[U], v_c = cur.c[V], ub_c = cur.c[UB], vb_c = cur.c[VB], am_c = cur.c[AM];
+    const double u_s = nb.s[U], v_s = nb.s[V], ub_s = nb.s[UB], vb_s = nb.s[VB], am_s = nb.s[AM];
+    const double u_n = nb.n[U], v_n = nb.n[V], ub_n = nb.n[UB], vb_n = nb.n[VB], am_n = nb.n[AM];
+    const double u_e = halo_e(u_c, [&] { return F3(u, ie, jc, k); });
+    const double u_se = halo_e(u_s, [&] { return F3(u, ie, js, k); });
+    const double ub_e = halo_e(ub_c, [&] { return F3(ub, ie, jc, k); });
+    const double v_w = halo_w(v_c, [&] { return F3(v, iw, jc, k); });
+    const double v_nw = halo_w(v_n, [&] { return F3(v, iw, jn, k); });
+    const double vb_w = halo_w(vb_c, [&] { return F3(vb, iw, jc, k); });
+    const double vb_nw = halo_w(vb_n, [&] { return F3(vb, iw, jn, k); });
+    const double am_w = halo_w(am_c, [&] { return F3(aam, iw, jc, k); });
+    const double am_sw = halo_w(am_s, [&] { return F3(aam, iw, js, k); });
+    const double am_nw = halo_w(am_n, [&] { return F3(aam, iw, jn, k); });
     // x-equation xflux at the cell centre (:233-239, :257-262, :275); 0 outside 2..imm1
     double xf = 0., cv = 0.;
     if (iin) {
-      xf = .125 * (dtsx_e * u_e + dtsx_c * c.u_c) * (u_e + c.u_c);
-      xf = xf - dt_c * c.am_c * 2. * (ub_e - c.ub_c) / dx_c;
+      xf = .125 * (dtsx_e * u_e + dtsx_c * u_c) * (u_e + u_c);
+      xf = xf - divi(dt_c * am_c * 2. * (ub_e - ub_c), idx_c);
       xf = dy_c * xf;
-      cv = .25 * ((c.v_n + c.v_c) * cva_c - (u_e + c.u_c) * cvb_c) / art_c;                    // :217-227
+      cv = divi(.25 * ((v_n + v_c) * cva_c - (u_e + u_c) * cvb_c), art_c);                     // :217-227
     }
-    const double ctx = cv * dt_c * (c.v_n + c.v_c);                                            // :296-297
-    const double xf_w = halo_w(xf, [&] { return advct_xf_mem(P, i - 1, j, k); });
+    const double ctx = cv * dt_c * (v_n + v_c);                                                // :296-297
+    const double xf_w = halo_w(xf, [&] { return advct_xf_mem(P, i - 1, jc, k); });
     const double ctx_w = halo_w(ctx, [&] {
-      return advct_curv_mem(P, i - 1, j, k) * F2(dt, i - 1, j) * (F3(v, i - 1, j + 1, k) + F3(v, i - 1, j, k));
+      return advct_curv_mem(P, i - 1, jc, k) * F2(dt, i - 1, jc) * (F3(v, i - 1, jc + 1, k) + F3(v, i - 1, jc, k));
     });
     // corner (i,j): y-flux of the x-equation and x-flux of the y-equation share dtaam and the shear bracket
-    const double dtaam = .25 * dt4_c * (c.am_c + am_w + c.am_s + am_sw);                       // :264-266
-    const double br = (c.ub_c - c.ub_s) / dy4_c + (c.vb_c - vb_w) / dx4_c;
-    double yf_c = .125 * (dtsy_c * c.v_c + dtsy_w * v_w) * (c.u_c + c.u_s);                    // :244-250
+    const double dtaam = .25 * dt4_c * (am_c + am_w + am_s + am_sw);                           // :264-266
+    const double br = divi(ub_c - ub_s, dy4_c) + divi(vb_c - vb_w, idx4_c);
+    double yf_c = .125 * (dtsy_c * v_c + dtsy_w * v_w) * (u_c + u_s);                          // :244-250
     yf_c = yf_c - dtaam * br;                                                                  // :267-272
     yf_c = .25 * dx4_c * yf_c;                                                                 // :276-277
-    double xg = .125 * (dtsx_c * c.u_c + dtsx_s * c.u_s) * (c.v_c + v_w);                      // :322-328
+    double xg = .125 * (dtsx_c * u_c + dtsx_s * u_s) * (v_c + v_w);                            // :322-328
     xg = xg - dtaam * br;                                                                      // :348-353
-    xg = .25 * dy4_c * xg;                                                                     // :363-364
-    const double xg_e = halo_e(xg, [&] { return advct_xg_mem(P, i + 1, j, k); });
+    xg = .25 * dy4_c.b * xg;                                                                   // :363-364
+    const double xg_e = halo_e(xg, [&] { return advct_xg_mem(P, i + 1, jc, k); });
     // corner (i,j+1): y-flux of the x-equation only
-    const double dtaam_n = .25 * dt4_n * (c.am_n + am_nw + c.am_c + am_w);
-    double yf_n = .125 * (dtsy_n * c.v_n + dtsy_nw * v_nw) * (c.u_n + c.u_c);
-    yf_n = yf_n - dtaam_n * ((c.ub_n - c.ub_c) / dy4_n + (c.vb_n - vb_nw) / dx4_n);
+    const double dtaam_n = .25 * dt4_n * (am_n + am_nw + am_c + am_w);
+    double yf_n = .125 * (dtsy_n * v_n + dtsy_nw * v_nw) * (u_n + u_c);
+    yf_n = yf_n - dtaam_n * (divi(ub_n - ub_c, dy4_n) + divi(vb_n - vb_nw, idx4_n));
     yf_n = .25 * dx4_n * yf_n;
     // y-equation yflux at the centres of rows j and j-1 (:333-339, :355-358, :365)
-    double yg_c = .125 * (dtsy_n * c.v_n + dtsy_c * c.v_c) * (c.v_n + c.v_c);
-    yg_c = yg_c - dt_c * c.am_c * 2. * (c.vb_n - c.vb_c) / dy_c;
+    double yg_c = .125 * (dtsy_n * v_n + dtsy_c * v_c) * (v_n + v_c);
+    yg_c = yg_c - divi(dt_c * am_c * 2. * (vb_n - vb_c), idy_c);
     yg_c = dx_c * yg_c;
     double yg_s = 0., cv_s = 0.;
     if (srow) {
-      yg_s = .125 * (dtsy_c * c.v_c + dtsy_s * c.v_s) * (c.v_c + c.v_s);
-      yg_s = yg_s - dt_s * c.am_s * 2. * (c.vb_c - c.vb_s) / dy_s;
+      yg_s = .125 * (dtsy_c * v_c + dtsy_s * v_s) * (v_c + v_s);
+      yg_s = yg_s - divi(dt_s * am_s * 2. * (vb_c - vb_s), idy_s);
       yg_s = dx_s * yg_s;
-      if (iin) cv_s = .25 * ((c.v_c + c.v_s) * cva_s - (u_se + c.u_s) * cvb_s) / art_s;
+      if (iin) cv_s = divi(.25 * ((v_c + v_s) * cva_s - (u_se + u_s) * cvb_s), art_s);
     }
-    if (out) {
-      double ax = 0., ay = 0.;
-      if (in) {
-        ax = xf - xf_w + yf_n - yf_c;                                                          // :284-288
-        if (curvx) ax = ax - aru * .25 * (ctx + ctx_w);                                        // :291-301
-        ay = xg_e - xg + yg_c - yg_s;                                                          // :374-378
-        if (curvy) ay = ay + arv * .25 * (cv * dt_c * (u_e + c.u_c) + cv_s * dt_s * (u_se + c.u_s));   // :381-391
-      }
-      F3(advx, i, j, k) = ax;
-      F3(advy, i, j, k) = ay;
-      const double dzk = F1(dz, k);
-      ax2 = ax2 + ax * dzk;
-      ay2 = ay2 + ay * dzk;
+    double ax = 0., ay = 0.;
+    if (in) {
+      ax = xf - xf_w + yf_n - yf_c;                                                            // :284-288
+      if (curvx) ax = ax - aru * .25 * (ctx + ctx_w);                                          // :291-301
+      ay = xg_e - xg + yg_c - yg_s;                                                            // :374-378
+      if (curvy) ay = ay + arv * .25 * (cv * dt_c * (u_e + u_c) + cv_s * dt_s * (u_se + u_s));   // :381-391
     }
-    c = nxt;
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    bst(bax, ost, lv, ax);
+    bst(bay, ost, lv, ay);
+    const double dzk = F1(dz, k);
+    ax2 = ax2 + ax * dzk;
+    ay2 = ay2 + ay * dzk;
+  };
+  LevCa ra, rb;
+#ifdef POMGPU_EMU
+  if (jrow) {                                               // the emulation's neighbour fallbacks reach beyond a rim row
+#endif
+  load(ra, 1);
+  rb = ra;
+  for (int k = 1; k <= kbm1; k += 2) {
+    step(k, 1, ra, rb);
+    if (k + 1 <= kbm1) step(k + 1, 0, rb, ra);              // uniform for the whole workgroup (barrier inside)
   }
+#ifdef POMGPU_EMU
+  }
+#endif
   if (out) {
-    F3(advx, i, j, kb) = 0.; F3(advy, i, j, kb) = 0.;
-    if (sum2d) { F2(adx2d, i, j) = ax2; F2(ady2d, i, j) = ay2; }
+    if (jrow) {
+      F3(advx, i, jc, kb) = 0.; F3(advy, i, jc, kb) = 0.;
+    } else {                                                // rim rows: advx = advy = 0 (solver.f:211,:317)
+      for (int k = 1; k <= kb; k++) { F3(advx, i, jc, k) = 0.; F3(advy, i, jc, k) = 0.; }
+    }
+    if (sum2d) { F2(adx2d, i, jc) = jrow ? ax2 : 0.; F2(ady2d, i, jc) = jrow ? ay2 : 0.; }
   }
 }
 
@@ -551,14 +642,8 @@ __global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advct_col(KP P, int 
 // the level loop carries the vertical fluxes, the (i-1) / (i+1) operands are neighbour-lane values.
 // Columns outside the interior get the reference's left-over vertical flux (:744-751, :801-808).
 struct LevUV { double w_c, w_s, u_c, v_c, u_s, v_n, ub, vb, advx, advy, drhox, drhoy; };   // w, u_c, v_c at level k+1; the rest at k
-__device__ __forceinline__ LevUV advuv_load(const KP &P, int i, int js, int j, int jn, int k) {
-  LevUV L;
-  L.w_c = F3(w, i, j, k + 1);  L.w_s = F3(w, i, js, k + 1); L.u_c = F3(u, i, j, k + 1); L.v_c = F3(v, i, j, k + 1);
-  L.u_s = F3(u, i, js, k);     L.v_n = F3(v, i, jn, k);
-  L.ub = F3(ub, i, j, k);      L.vb = F3(vb, i, j, k);
-  L.advx = F3(advx, i, j, k);  L.advy = F3(advy, i, j, k);  L.drhox = F3(drhox, i, j, k); L.drhoy = F3(drhoy, i, j, k);
-  return L;
-}
+// Same loop discipline as k_advt2_col: one batch of loads per level, issued a whole iteration ahead and never inside a
+// branch, stores of lanes without an output column aimed outside the buffer, buffer addressing, two register sets.
 __global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advuv_col(KP P) {
   HALO_XCD_DECODE
   if (j > P.jm) return;                                     // whole wavefront (one row)
@@ -582,13 +667,31 @@ __global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advuv_col(KP P) {
                      (F2(egf, i, j) - F2(egf, i, js) + F2(egb, i, j) - F2(egb, i, js) + (F2(e_atmos, i, j) - F2(e_atmos, i, js)) * 2.) *
                      (F2(dx, i, j) + F2(dx, i, js));                                          // :822-827
   const double hb = F2(h, i, j) + F2(etb, i, j), hf = F2(h, i, j) + F2(etf, i, j);
-  const double sau = (hb + F2(h, iw, j) + F2(etb, iw, j)) * aru, sdu = (hf + F2(h, iw, j) + F2(etf, iw, j)) * aru;   // :758, :781
-  const double sav = (hb + F2(h, i, js) + F2(etb, i, js)) * arv, sdv = (hf + F2(h, i, js) + F2(etf, i, js)) * arv;   // :815, :838
+  const double sau = (hb + F2(h, iw, j) + F2(etb, iw, j)) * aru;                            // :758
+  const double sav = (hb + F2(h, i, js) + F2(etb, i, js)) * arv;                            // :815
+  const InvD sdu = inv_of((hf + F2(h, iw, j) + F2(etf, iw, j)) * aru), sdv = inv_of((hf + F2(h, i, js) + F2(etf, i, js)) * arv);   // :781, :838
+  const BufA bw = BUF3(A3(w)), bu = BUF3(A3(u)), bv = BUF3(A3(v)), bub = BUF3(A3(ub)), bvb = BUF3(A3(vb)), bax = BUF3(A3(advx)),
+             bay = BUF3(A3(advy)), bdx = BUF3(A3(drhox)), bdy = BUF3(A3(drhoy)), buf = BUF3(A3(uf)), bvf = BUF3(A3(vf));
+  const unsigned oc = BOFF2(i, j), os = BOFF2(i, js), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  const unsigned ost = out ? oc : BOFF_NONE;
+  auto load = [&](LevUV &L, int k) {                        // operands of level k (w, u_c, v_c: level k+1)
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb, lv1 = lv + lvb;
+    L.w_c = bld(bw, oc, lv1); L.w_s = bld(bw, os, lv1); L.u_c = bld(bu, oc, lv1); L.v_c = bld(bv, oc, lv1);
+    L.u_s = bld(bu, os, lv);  L.v_n = bld(bv, on, lv);
+    L.ub = bld(bub, oc, lv);  L.vb = bld(bvb, oc, lv);
+    L.advx = bld(bax, oc, lv); L.advy = bld(bay, oc, lv); L.drhox = bld(bdx, oc, lv); L.drhoy = bld(bdy, oc, lv);
+  };
   double u_k = F3(u, i, j, 1), v_k = F3(v, i, j, 1);       // u, v of this column at level k
   double fu_k = 0., fv_k = 0.;                              // vertical fluxes at level k (0 at the surface)
-  LevUV c = advuv_load(P, i, js, j, jn, 1), nxt = c;
-  for (int k = 1; k <= kbm1; k++) {
-    if (k + 1 <= kbm1) nxt = advuv_load(P, i, js, j, jn, k + 1);
+#ifdef ADVUV_DZ_AHEAD
+  InvD dzn; dzn.b = F1(dz, 1); dzn.y = R1(dz, 1);
+#endif
+  auto step = [&](const int k, const LevUV &c, LevUV &nxt) {
+    load(nxt, k + 1 <= kbm1 ? k + 1 : kbm1);                // in flight during this iteration (the last one re-requests level kbm1)
+#ifdef ADVUV_DZ_AHEAD
+    const InvD dzk = dzn;
+    dzn.b = F1(dz, k + 1 <= kbm1 ? k + 1 : kbm1); dzn.y = R1(dz, k + 1 <= kbm1 ? k + 1 : kbm1);
+#endif
     const double w_w = halo_w(c.w_c, [&] { return F3(w, iw, j, k + 1); });
     const double tc = cd_c * (c.v_n + v_k);                                                 // cor*dt*(v(i,j+1,k)+v(i,j,k))
     const double tw = halo_w(tc, [&] { return F2(cor, iw, j) * F2(dt, iw, j) * (F3(v, iw, jn, k) + F3(v, iw, j, k)); });
@@ -600,20 +703,28 @@ __global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advuv_col(KP P) {
       if (i >= 2) fu_n = .25 * (c.w_c + w_w) * (c.u_c + u_k);
       if (j >= 2) fv_n = .25 * (c.w_c + c.w_s) * (c.v_c + v_k);
     }
-    if (out) {
-      double ru = fu_k, rv = fv_k;                                                          // outside the interior: the flux itself
-      if (in) {
-        ru = (sau * c.ub - 2. * P.dti2 * (c.advx + (fu_k - fu_n) * aru / F1(dz, k) - aru * .25 * (tc + tw) + hcu + c.drhox)) / sdu;   // :758-782
-        rv = (sav * c.vb -
-              2. * P.dti2 * (c.advy + (fv_k - fv_n) * arv / F1(dz, k) + arv * .25 * (cd_c * (u_e + u_k) + cd_s * (u_se + c.u_s)) + hcv + c.drhoy)) /
-             sdv;                                                                           // :815-839
-      }
-      F3(uf, i, j, k) = ru;
-      F3(vf, i, j, k) = rv;
+    double ru = fu_k, rv = fv_k;                                                            // outside the interior: the flux itself
+    if (in) {
+#ifndef ADVUV_DZ_AHEAD
+      InvD dzk; dzk.b = F1(dz, k); dzk.y = R1(dz, k);
+#endif
+      ru = divi(sau * c.ub - 2. * P.dti2 * (c.advx + divi((fu_k - fu_n) * aru, dzk) - aru * .25 * (tc + tw) + hcu + c.drhox), sdu);   // :758-782
+      rv = divi(sav * c.vb -
+                    2. * P.dti2 * (c.advy + divi((fv_k - fv_n) * arv, dzk) + arv * .25 * (cd_c * (u_e + u_k) + cd_s * (u_se + c.u_s)) + hcv + c.drhoy),
+                sdv);                                                                       // :815-839
     }
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    bst(buf, ost, lv, ru);
+    bst(bvf, ost, lv, rv);
     fu_k = fu_n; fv_k = fv_n;
     u_k = c.u_c; v_k = c.v_c;
-    c = nxt;
+  };
+  LevUV ra, rb;
+  load(ra, 1);
+  rb = ra;
+  for (int k = 1; k <= kbm1; k += 2) {
+    step(k, ra, rb);
+    if (k + 1 <= kbm1) step(k + 1, rb, ra);
   }
   if (out) { F3(uf, i, j, kb) = 0.; F3(vf, i, j, kb) = 0.; }
 }
@@ -624,14 +735,14 @@ void launch_coef_dt(pomgpu_ctx *c) { LAUNCH(c, k_coef_dt, grid2(c->P), blk2(), c
 void launch_coef_eta(pomgpu_ctx *c) { LAUNCH(c, k_coef_eta, grid2(c->P), blk2(), c->P); }
 void launch_advq_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, int zero_else) {
   QFields A; A.q[0] = A.q[1] = q; A.qb[0] = A.qb[1] = qb; A.qf[0] = A.qf[1] = qf;
-  LAUNCHN(c, "k_advq_col", (k_advq_col<1>), grid1_halo(c->P), blk_col(), c->P, A, zero_else);
+  LAUNCHN(c, "k_advq_col", (k_advq_col<1>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, A, zero_else);
 }
 void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *ql, const double *qlb, double *qlf, int zero_else) {
   QFields A; A.q[0] = q; A.qb[0] = qb; A.qf[0] = qf; A.q[1] = ql; A.qb[1] = qlb; A.qf[1] = qlf;
-  LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo(c->P), blk_col(), c->P, A, zero_else);
+  LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, A, zero_else);
 }
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
-  LAUNCH(c, k_advct_col, grid1_halo(c->P), blk_col(), c->P, sum2d);
+  LAUNCH(c, k_advct_col, grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, sum2d);
 }
 // with sum2d the column kernel has left adx2d, ady2d (advance.f:152-168) from its own advx(2,:), advy(:,2): redo the
 // two lines from the corrected values, in the column kernel's order of summation
@@ -669,11 +780,11 @@ void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), 
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   {
     TFields A; A.fb[0] = A.fb[1] = fb; A.f[0] = A.f[1] = f; A.fcl[0] = A.fcl[1] = fc; A.ff[0] = A.ff[1] = ff;
-    LAUNCHN(c, "k_advt2_col", (k_advt2_col<1>), grid1_halo(c->P), blk_col(), c->P, A);
+    LAUNCHN(c, "k_advt2_col", (k_advt2_col<1>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, A);
   }
 }
 void launch_advt2x2_col(pomgpu_ctx *c, const double *tb, const double *t, const double *tc, double *tf, const double *sb, const double *s_,
                         const double *sc, double *sf) {
   TFields A; A.fb[0] = tb; A.f[0] = t; A.fcl[0] = tc; A.ff[0] = tf; A.fb[1] = sb; A.f[1] = s_; A.fcl[1] = sc; A.ff[1] = sf;
-  LAUNCHN(c, "k_advt2x2_col", (k_advt2_col<2>), grid1_halo(c->P), blk_col(), c->P, A);
+  LAUNCHN(c, "k_advt2x2_col", (k_advt2_col<2>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, A);
 }

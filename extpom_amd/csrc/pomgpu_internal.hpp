@@ -62,7 +62,7 @@ enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb, X2_uab, X2_vab };
 // queue behind the prefetch batch of the next level and, vmcnt being in-order, make the first use of dz(k) wait for that
 // whole batch: the software pipeline of every column kernel was serialised by it (ISA of k_advt2_col: s_waitcnt vmcnt(0)
 // in the middle of each iteration).  The arrays never change while a kernel runs (upload writes them).
-#ifndef POMGPU_EMU
+#if !defined(POMGPU_EMU) && !defined(POMGPU_F1_GLOBAL)
 typedef const double __attribute__((address_space(4))) *pomgpu_cptr;
 #define F1(name, k) ((pomgpu_cptr)(size_t)P.b1)[(size_t)P1_##name * P.kb + ((k)-1)]
 #define R1(name, k) ((pomgpu_cptr)(size_t)P.r1)[(size_t)P1_##name * P.kb + ((k)-1)]
@@ -211,15 +211,18 @@ static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { 
 // that is three wavefront loads per operand and level, and the counters say that is what bounds these kernels: the L1
 // (TCP) spends ~21 accesses on every 8-byte-per-lane wavefront load and saturates at ~0.6 accesses per CU-cycle
 // (k_advt2_col: 0.59, whatever the occupancy; with the neighbour-row loads taken out the kernel ran 26 % faster), and
-// the re-requested rows are L2 hits only 40 % of the time (+45 % HBM-side reads).  Here the COL_ROWS wavefronts of a
+// the re-requested rows are L2 hits only 40 % of the time (+45 % HBM-side reads).  Here the LDS_ROWS wavefronts of a
 // workgroup load their OWN row of each shared operand, park it in an LDS slab and read the rows next to theirs from
 // there; the two rows outside the workgroup (south of its first row, north of its last) are split among its wavefronts
 // (ROWSHARE_SLOTS loads each).  One s_barrier per level; two slabs, so a wavefront may fill the next level's slab while
 // its neighbours still read this level's.  Loads per wavefront and level: NS + NO + slots instead of 3*NS + NO.
-// Slab rows: 0 = south halo, 1..COL_ROWS = the workgroup's rows, COL_ROWS+1 = north halo, COL_ROWS+2 = sink for the
+// Slab rows: 0 = south halo, 1..LDS_ROWS = the workgroup's rows, LDS_ROWS+1 = north halo, LDS_ROWS+2 = sink for the
 // slots a wavefront has no job for.  Host emulation (one lane at a time, no concurrency) reads the rows from memory.
-#define ROWSHARE_SLOTS(NS) ((2 * (NS) + COL_ROWS - 1) / COL_ROWS)
-#define ROWSHARE_ROWS (COL_ROWS + 3)
+#ifndef LDS_ROWS
+#define LDS_ROWS 8                                          /* rows per workgroup of the row-sharing kernels (kbench: 8 beats 4 and 6 by 8-14 %) */
+#endif
+#define ROWSHARE_SLOTS(NS) ((2 * (NS) + LDS_ROWS - 1) / LDS_ROWS)
+#define ROWSHARE_ROWS (LDS_ROWS + 3)
 template <int NS> struct RowShare {
   int r;                                   // this wavefront's row inside the workgroup (scalar)
   int ss, sn;                              // slab rows holding the southern / northern neighbour row of this wavefront's row
@@ -234,14 +237,14 @@ template <int NS> __device__ __forceinline__ RowShare<NS> rowshare_setup(const K
   S.r = r;
   S.ss = (j > 1 && j <= P.jml) ? r : r + 1;
   S.sn = (j < P.jml) ? r + 2 : r + 1;
-  const int jsouth = j0w > 1 ? j0w - 1 : 1, jnorth = j0w + COL_ROWS <= P.jml ? j0w + COL_ROWS : P.jml;
+  const int jsouth = j0w > 1 ? j0w - 1 : 1, jnorth = j0w + LDS_ROWS <= P.jml ? j0w + LDS_ROWS : P.jml;
 #pragma unroll
   for (int q = 0; q < ROWSHARE_SLOTS(NS); q++) {
-    const int job = q * COL_ROWS + r;
+    const int job = q * LDS_ROWS + r;
     const bool valid = job < 2 * NS;
     const int side = valid ? job / NS : 0;
     S.hop[q] = valid ? job % NS : 0;
-    S.hrow[q] = valid ? (side ? COL_ROWS + 1 : 0) : COL_ROWS + 2;
+    S.hrow[q] = valid ? (side ? LDS_ROWS + 1 : 0) : LDS_ROWS + 2;
     S.hoff[q] = valid ? BOFF2(i, side ? jnorth : jsouth) : BOFF_NONE;
   }
   return S;
@@ -309,21 +312,24 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
   const int byl__ = m__ / nbx__, bxg__ = m__ % nbx__;                                     \
   if (byl__ >= rpx__) return;
 #endif
-#define HALO_XCD_DECODE                                                                   \
+#define HALO_XCD_DECODE HALO_XCD_DECODE_R(COL_ROWS)
+#define HALO_XCD_DECODE_R(ROWS__)                                                         \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
   const int L__ = g__ >> 6, nwx__ = (P.iml + 61) / 62, nbx__ = (nwx__ + COL_WX - 1) / COL_WX; \
-  const int nby__ = (P.jml + COL_ROWS - 1) / COL_ROWS;                                    \
+  const int nby__ = (P.jml + ROWS__ - 1) / ROWS__;                                        \
   const int rpx__ = (nby__ + 7) / 8, m__ = L__ >> 3;                                      \
   HALO_XCD_ORDER                                                                          \
   const int by__ = (L__ & 7) * rpx__ + byl__;                                             \
   if (by__ >= nby__) return;                                                              \
   const int lane = g__ & 63;                                                              \
   const int i0 = (bxg__ * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane;                \
-  const int j = by__ * COL_ROWS + (int)threadIdx.y / COL_WX + 1;
-static inline dim3 grid1_halo(const KP &P) {
-  const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + COL_ROWS - 1) / COL_ROWS, rpx = (nby + 7) / 8;
+  const int j = by__ * ROWS__ + (int)threadIdx.y / COL_WX + 1;
+static inline dim3 grid1_halo_r(const KP &P, int rows) {
+  const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + rows - 1) / rows, rpx = (nby + 7) / 8;
   return dim3((unsigned)(8 * rpx * nbx), 1, 1);
 }
+static inline dim3 grid1_halo(const KP &P) { return grid1_halo_r(P, COL_ROWS); }
+static inline dim3 blk_col_r(int rows) { return dim3(64, rows * COL_WX, 1); }
 static inline dim3 blk_col() { return dim3(64, COL_ROWS * COL_WX, 1); }
 #define HALO_COL (int)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 62 + ((blockIdx.x * blockDim.x + threadIdx.x) & 63))
 static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.jml + 3) / 4, 1); }

@@ -1,0 +1,59 @@
+"""developer tool (GPU box): per-kernel times of several library variants measured INTERLEAVED in one process.
+Run-to-run and box-to-box differences on the pool are +-5 % (clocks); variants timed in separate processes cannot be
+ranked closer than that.  Here the state is built once, every variant gets its own context (60 GB each at the default
+size) and the variants take turns: R rounds of (profiled step of A, of B, ...); reported: min and median per kernel.
+usage: python tools/kbench.py [--workload W] [--rounds R] [--kernels a,b,...] tag[=lib.so][:ENV=V ...] ...
+(an ENV of a spec is set while that variant's context is created and while it runs)"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from extpom_amd import dist as pdist
+from extpom_amd.model import PomGpu
+from extpom_amd import lib as _lib
+_lib._SIGS.pop("pomgpu_rccl_available", None)     # older variant libraries do not export it
+
+args = sys.argv[1:]
+wl, rounds, kernels = "basin2048", 5, None
+while args and args[0].startswith("--"):
+    if args[0] == "--workload": wl = args[1]
+    elif args[0] == "--rounds": rounds = int(args[1])
+    elif args[0] == "--kernels": kernels = args[1].split(",")
+    args = args[2:]
+case, im, jm, kb, _ = bench.WORKLOADS[wl]
+tile = pdist.tile_for_rank(0, 1, im, jm)
+st0 = bench.build_state(wl, tile)
+g0 = bench.gpu_initialise(st0, 0, None)      # finishes the initial state with the default library
+g0.close()
+variants = []
+for spec in args:
+    parts = spec.split(":")
+    tag, _, lib = parts[0].partition("=")
+    env = dict(p.split("=", 1) for p in parts[1:])
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    g = PomGpu(st0, device=0, libpath=os.path.join(ROOT, lib) if lib else None)
+    g.run(2); g.sync()
+    for k, v in old.items():
+        os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    variants.append((tag, env, g, {}))
+for r in range(rounds):
+    for tag, env, g, acc in variants:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        g.prof_begin(); g.run(1); prof = g.prof_end()
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        prof.pop("msg_round", None)
+        ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
+        acc.setdefault("internal", []).append(sum(v[1] for k, v in prof.items() if not k.startswith(ext)))
+        acc.setdefault("external", []).append(sum(v[1] for k, v in prof.items() if k.startswith(ext)))
+        for k, v in prof.items():
+            acc.setdefault(k[2:], []).append(v[1])
+names = ["internal", "external"] + sorted((k for k in variants[0][3] if k not in ("internal", "external") and (kernels is None or k in kernels)),
+                                          key=lambda k: -min(variants[0][3][k]))
+if kernels is None:
+    names = names[:22]
+print(f"{'min / median (ms)':22s}" + "".join(f"{t[0]:>18s}" for t in variants))
+for n in names:
+    print(f"{n:22s}" + "".join(f"{min(t[3].get(n, [0])):9.3f}/{statistics.median(t[3].get(n, [0])):7.3f} " for t in variants))
