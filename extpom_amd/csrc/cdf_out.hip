@@ -113,7 +113,7 @@ static int write_file(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m
       continue;
     }
     const int nlev = v.src == PLANE2D ? 1 : v.nlev;
-    const double *dev = v.src == PLANE2D ? P.b2 + (size_t)v.slot * P.n2 : P.b3 + (size_t)v.slot * P.n3;
+    const double *dev = v.src == PLANE2D ? P.b2 + (size_t)v.slot * P.n2 : P.b3 + (size_t)v.slot * P.a3;
     host.resize((size_t)nlev * P.n2);
     if (hipMemcpyAsync(host.data(), dev, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { bad = 1; break; }

@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(256) k_realvertvl_col(KP P) {
 // issues 14 loads per cell and runs at 78 % L1/TA busy; here seven aligned 16-byte loads serve two
 // cells and every i+-1 operand is a neighbour-lane value.  Needs an even leading dimension.
 #define LD2(ptr, ii, jj, kk) (*(const double2 *)&(ptr)[IX3(ii, jj, kk)])
-#define A3(name) (P.b3 + (size_t)P3_##name * P.n3)
+#define A3(name) (P.b3 + (size_t)P3_##name * P.a3)
 __device__ __forceinline__ double aam_point(const KP &P, double dx, double dy, double u_c, double u_e, double u_n, double u_ne, double u_s,
                                             double u_se, double v_c, double v_n, double v_e, double v_ne, double v_w, double v_nw) {
   return P.horcon * dx * dy *

@@ -959,12 +959,12 @@ __global__ void __launch_bounds__(128) k_profuv_reg(KP P) {
   const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
   const int iw = i > 1 ? i - 1 : 1, js = j > 1 ? j - 1 : 1;
   const int in_ = V ? i : iw, jn_ = V ? js : j;            // the second column of the averages
-  double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.n3;
+  double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.a3;
   // per-level accesses as (uniform plane pointer)[32-bit column offset]: the plane pointer is scalar, so
   // the ~2*KBT loads of phase A share ONE offset register instead of holding a 64-bit address each
   // (32-bit BYTE offsets: the form the compiler maps onto the scalar-base + vector-offset addressing mode)
   const unsigned col = 8u * (unsigned)((j - 1) * P.iml + (i - 1)), col2 = 8u * (unsigned)((js - 1) * P.iml + (i - 1));
-  const double *kmp = P.b3 + (size_t)P3_km * P.n3;
+  const double *kmp = P.b3 + (size_t)P3_km * P.a3;
 #define PLANE(ptr, k, off) (*(double *)((char *)((ptr) + (size_t)((k)-1) * P.n2) + (off)))
   const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
   double ee[KBT], gg[KBT];
@@ -1084,7 +1084,7 @@ __global__ void k_uv_filter(KP P) {
 template <int KBT, int V>
 __global__ void __launch_bounds__(128) k_int_uvmean_reg(KP P) {
   COL2
-  double *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.n3;
+  double *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.a3;
   const int kbm1 = P.kbm1;
   double x[KBT - 1];
 #define KC(k) ((k) < kbm1 ? (k) : kbm1)
@@ -1117,8 +1117,8 @@ template <int KBT, int V>
 __global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
   COL2
   if (i > P.im || j > P.jm) return;
-  const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.n3;
-  double *b = P.b3 + (size_t)(V ? P3_vb : P3_ub) * P.n3, *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.n3;
+  const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.a3;
+  double *b = P.b3 + (size_t)(V ? P3_vb : P3_ub) * P.a3, *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.a3;
   const int kb = P.kb, kbm1 = P.kbm1;
   constexpr int CH = 8, NL = KBT - 1, NCH = (NL + CH - 1) / CH;
   double dk[NL], uo[NL], t0[CH], t1[CH];

@@ -16,7 +16,7 @@ struct ProfState { std::vector<ProfPair> pending; std::vector<ProfPair> free_; c
 static ProfState *PS(pomgpu_ctx *c) { return (ProfState *)c->prof_state; }
 
 #define SLOT2(c, n) ((c)->P.b2 + (size_t)(n) * (c)->P.n2)
-#define SLOT3(c, n) ((c)->P.b3 + (size_t)(n) * (c)->P.n3)
+#define SLOT3(c, n) ((c)->P.b3 + (size_t)(n) * (c)->P.a3)
 #define D2(c, name) SLOT2(c, P2_##name)
 #define D3(c, name) SLOT3(c, P3_##name)
 
@@ -198,6 +198,15 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   P.iml = d->im_local; P.jml = d->jm_local;
   P.W = d->n_west == -1; P.E = d->n_east == -1; P.S = d->n_south == -1; P.N = d->n_north == -1;
   P.n2 = (size_t)P.iml * P.jml; P.n3 = P.n2 * P.kb;
+  // The arrays of blk3d are n3 doubles apart on the host.  On the device a padding may be put between them
+  // (POMGPU_PAD3 = 4-KiB pages): at the benchmark size the arrays are an exact multiple of 16 MiB apart, so that the ~10
+  // arrays a kernel reads at one (i,j,k) sit at the same offset of the memory interleave; upload / download copy
+  // array by array then
+  {
+    const char *e = getenv("POMGPU_PAD3");
+    const long pages = e ? atol(e) : 0;
+    P.a3 = P.n3 + (pages > 0 ? (size_t)pages * 512 : 0);
+  }
   set_band_geometry(P);
   size_t off = 0; int s = 0;
 #define BD_(name, shape) P.bdoff[s++] = off; off += BDN_##shape;
@@ -226,7 +235,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   alloc(&P.r1, (size_t)POM_NBLK1D * P.kb);
   alloc(&P.b2, (size_t)POM_NBLK2D * P.n2);
   const bool only2d = (flags & POMGPU_CTX_2D) != 0;
-  if (!only2d) alloc(&P.b3, (size_t)POM_NBLK3D * P.n3);
+  if (!only2d) alloc(&P.b3, (size_t)POM_NBLK3D * P.a3);
   alloc(&P.bd, nbd);
   for (int n = 0; n < POMGPU_NSCR3 && !only2d; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
@@ -340,7 +349,11 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
-  if (b3) HIPCHK(c, hipMemcpyAsync(P.b3, b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyHostToDevice, c->stream));
+  if (b3) {
+    if (P.a3 == P.n3) HIPCHK(c, hipMemcpyAsync(P.b3, b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyHostToDevice, c->stream));
+    else for (int n = 0; n < POM_NBLK3D; n++)
+      HIPCHK(c, hipMemcpyAsync(SLOT3(c, n), b3 + (size_t)n * P.n3, sizeof(double) * P.n3, hipMemcpyHostToDevice, c->stream));
+  }
   if (bd) {
     const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
     HIPCHK(c, hipMemcpyAsync(P.bd, bd, sizeof(double) * nbd, hipMemcpyHostToDevice, c->stream));
@@ -361,7 +374,11 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
   restore_materialize(c);
   if (b1) HIPCHK(c, hipMemcpyAsync(b1, P.b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyDeviceToHost, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(b2, P.b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyDeviceToHost, c->stream));
-  if (b3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
+  if (b3) {
+    if (P.a3 == P.n3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
+    else for (int n = 0; n < POM_NBLK3D; n++)
+      HIPCHK(c, hipMemcpyAsync(b3 + (size_t)n * P.n3, SLOT3(c, n), sizeof(double) * P.n3, hipMemcpyDeviceToHost, c->stream));
+  }
   if (bd) {
     const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
     HIPCHK(c, hipMemcpyAsync(bd, P.bd, sizeof(double) * nbd, hipMemcpyDeviceToHost, c->stream));
@@ -471,7 +488,7 @@ static double *dev3(pomgpu_ctx *c, const double *host) {
   if (!c->host3 || !host) return NULL;
   const ptrdiff_t off = host - c->host3;
   if (off < 0 || (size_t)off >= (size_t)POM_NBLK3D * c->P.n3 || (size_t)off % c->P.n3) return NULL;
-  return c->P.b3 + off;
+  return SLOT3(c, (size_t)off / c->P.n3);
 }
 static double *dev2(pomgpu_ctx *c, const double *host) {
   if (!c->host2 || !host) return NULL;

@@ -29,6 +29,7 @@ struct KP {
   int im, jm, kb, imm1, jmm1, kbm1, kbm2, iml, jml;
   int W, E, S, N;            // 1 where the tile edge is a physical boundary (n_west == -1 ...)
   size_t n2, n3;
+  size_t a3;                 // distance between two arrays of blk3d in HBM, doubles (n3 + padding, pomgpu_create)
   double *b1, *b2, *b3, *bd; // device mirrors of blk1d, blk2d, blk3d, bdry
   double *r1;                // 1.0 / b1 element by element (k_coef_static): reciprocals of dz, dzz for divi()
   double *s3[POMGPU_NSCR3];
@@ -71,9 +72,9 @@ typedef const double __attribute__((address_space(4))) *pomgpu_cptr;
 #define R1(name, k) P.r1[(size_t)P1_##name * P.kb + ((k)-1)]
 #endif
 #define F2(name, i, j) P.b2[(size_t)P2_##name * P.n2 + IX2(i, j)]
-#define F3(name, i, j, k) P.b3[(size_t)P3_##name * P.n3 + IX3(i, j, k)]
+#define F3(name, i, j, k) P.b3[(size_t)P3_##name * P.a3 + IX3(i, j, k)]
 #define A2(name) (P.b2 + (size_t)P2_##name * P.n2)
-#define A3(name) (P.b3 + (size_t)P3_##name * P.n3)
+#define A3(name) (P.b3 + (size_t)P3_##name * P.a3)
 #define G3(p, i, j, k) (p)[IX3(i, j, k)]
 #define G2(p, i, j) (p)[IX2(i, j)]
 

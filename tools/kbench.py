@@ -37,6 +37,8 @@ for spec in args:
     for k, v in old.items():
         os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     variants.append((tag, env, g, {}))
+    b3, b2 = g.device_ptr("aam"), g.device_ptr(list(__import__("extpom_amd.layout", fromlist=["P2"]).P2)[0])
+    print(f"{tag}: blk3d at 0x{b3:x} (mod 2MiB {b3 % (2 << 20)}, mod 1GiB {(b3 % (1 << 30)) >> 20} MiB), blk2d at 0x{b2:x}", flush=True)
 for r in range(rounds):
     for tag, env, g, acc in variants:
         old = {k: os.environ.get(k) for k in env}
