@@ -150,8 +150,18 @@ __device__ __forceinline__ void c_roundtrip(const KP &P, const int i, const int 
 __global__ void k_roundtrip(KP P, double *a, const double *b, int fix_kb) {
   MARCH3(c_roundtrip(P, i, j, k, a, b, fix_kb))
 }
+// one level only (the deferred round trip of rho, pomgpu_api.hip: its level kb, which dens never rewrites)
+__global__ void k_roundtrip_level(KP P, double *a, const double *b, int k) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.iml || j > P.jml) return;
+  double x = G3(a, i, j, k);
+  const double y = G3(b, i, j, k);
+  x = x - y;
+  G3(a, i, j, k) = x + y;
+}
 __device__ __forceinline__ void c_roundtrip(const KP &P, const int i, const int j, const int k, double *a, const double *b, int fix_kb) {
-  double x = G3(a, i, j, (fix_kb && k == P.kb) ? P.kbm1 : k);
+  if (fix_kb == 2 && k == P.kb) return;                                // fix_kb = 2: levels 1..kbm1 only
+  double x = G3(a, i, j, (fix_kb == 1 && k == P.kb) ? P.kbm1 : k);
   const double y = G3(b, i, j, k);
   x = x - y;
   G3(a, i, j, k) = x + y;
@@ -425,11 +435,12 @@ __device__ __forceinline__ void c_advt2_diff(const KP &P, const int i, const int
 // (bounds_forcing.f:1086-1120) and dens (solver.f:1162-1209): 14 reads + 5 writes per cell instead
 // of the 38 array passes of the five separate kernels.
 __device__ __forceinline__ double dens_point(const KP &P, double si, double ti, int i, int j, int k);
-__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst);
-__global__ void k_ts_update(KP P, double fold, double fnew, int rt, int store_rst) {
-  MARCH3(c_ts_update(P, i, j, k, fold, fnew, rt, store_rst))
+// TAU: 1 = taurstrb, taurstrf hold the values tau_b, tau_f everywhere (pomgpu_ctx::tau_known): not read
+template <int TAU> __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst, double tau_b, double tau_f);
+template <int TAU> __global__ void k_ts_update(KP P, double fold, double fnew, int rt, int store_rst, double tau_b, double tau_f) {
+  MARCH3(c_ts_update<TAU>(P, i, j, k, fold, fnew, rt, store_rst, tau_b, tau_f))
 }
-__device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst) {
+template <int TAU> __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int j, const int k, double fold, double fnew, int rt, int store_rst, double tau_b, double tau_f) {
   const bool act = (i <= P.im && j <= P.jm), lev = (k <= P.kbm1);
   const double m = F2(fsm, i, j);
   double uf = F3(uf, i, j, k), vf = F3(vf, i, j, k);
@@ -451,7 +462,7 @@ __device__ __forceinline__ void c_ts_update(const KP &P, const int i, const int 
     if (act) {                                                         // restore_interior
       const double tr = fold * F3(trstrb, i, j, k) + fnew * F3(trstrf, i, j, k);
       const double sr = fold * F3(srstrb, i, j, k) + fnew * F3(srstrf, i, j, k);
-      const double ta = fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
+      const double ta = TAU ? fold * tau_b + fnew * tau_f : fold * F3(taurstrb, i, j, k) + fnew * F3(taurstrf, i, j, k);
       if (store_rst) {                                                 // else left to k_restore_fields (on demand)
         F3(trstr, i, j, k) = tr;
         F3(srstr, i, j, k) = sr;
@@ -798,6 +809,7 @@ void launch_aam(pomgpu_ctx *c) {
   }
 }
 void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb) { LAUNCH(c, k_roundtrip, gridm(c->P), blk2(), c->P, a, b, fix_kb); }
+void launch_roundtrip_level(pomgpu_ctx *c, double *a, const double *b, int k) { LAUNCH(c, k_roundtrip_level, grid2(c->P), blk2(), c->P, a, b, k); }
 void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf) {
   LAUNCH(c, k_advq_flux, gridm(c->P), blk2(), c->P, q, qb, xf, yf);
 }
@@ -826,7 +838,10 @@ void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, gridm(c->P
 void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, gridm(c->P), blk2(), c->P, dst, src); }
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, gridm(c->P), blk2(), c->P, fb, fc, ff); }
 void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst) {
-  LAUNCH(c, k_ts_update, gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst);
+  if (c->tau_known[0] && c->tau_known[1] && !getenv("POMGPU_TAU_ARRAYS"))
+    LAUNCHN(c, "k_ts_update", (k_ts_update<1>), gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst, c->tau_val[0], c->tau_val[1]);
+  else
+    LAUNCHN(c, "k_ts_update", (k_ts_update<0>), gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst, 0., 0.);
 }
 void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew) { LAUNCH(c, k_restore_fields, gridm(c->P), blk2(), c->P, fold, fnew); }
 void launch_mask_ts(pomgpu_ctx *c) { LAUNCH(c, k_mask_ts, gridm(c->P), blk2(), c->P); }

@@ -325,10 +325,11 @@ __global__ void k_profq_prod_lines(KP P) {
 // in vector registers), two register sets alternating as current / next level.
 // FP: 0 = the production term comes from s3[0] (k_profq_prod), 1 = formed here for interior columns, 0 on the rim (one
 // tile), 2 = formed here for interior columns, s3[0] on the rim (tiles, the library's exchange).  FF: fused filter.
-struct LevQ { double t, s, rho, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn, kq1, prod; };
+struct LevQ { double t, s, rho, rm, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn, kq1, prod; };
 struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
+// rho_rt: rho is still to make its round trip through rho - rmean (pomgpu_ctx::rho_rt_pending): applied to the loaded value
 template <int FP, int FF>
-__global__ void __launch_bounds__(128) k_profq(KP P) {
+__global__ void __launch_bounds__(128) k_profq(KP P, int rho_rt) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
@@ -385,6 +386,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P) {
   const unsigned o_abs = ffil ? BOFF_NONE : oc;             // |q2b|, |q2lb| on the way down: rewritten on the way up where the filter is fused
   const unsigned o_fil = ffil ? oc : BOFF_NONE, o_uv = ffil ? BOFF_NONE : oc;
   const unsigned o_pr = (FP == 0 || (FP == 2 && !pin)) ? oc : BOFF_NONE;
+  const unsigned o_rm = rho_rt ? oc : BOFF_NONE;            // rmean is requested only where it is used (outside the buffer: no traffic)
   // boundary values of the two solves -- :1296-1297, :1417-1425
   const double vbot = P.kappa * (1 + F1(z, kbm1)) * dh * F3(q2, i, j, kbm1);
   const double ufbot = F3(uf, i, j, kb);
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P) {
   double ucm = 0., uem = 0., vcm = 0., vnm = 0.;   // u(i), u(i+1), v(j), v(j+1) of level k-1
   auto lev = [&](LevQ &L, int k) {              // k = 1..kb; every operand, every lane
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
-    L.t = bld(bt, oc, lv); L.s = bld(bs_, oc, lv); L.rho = bld(brho, oc, lv);
+    L.t = bld(bt, oc, lv); L.s = bld(bs_, oc, lv); L.rho = bld(brho, oc, lv); L.rm = bld(BUF3(A3(rmean)), o_rm, lv);
     L.q2b = bld(bq2b, oc, lv); L.q2lb = bld(bq2lb, oc, lv); L.q2 = bld(bq2, oc, lv);
     L.km = bld(bkm, oc, lv); L.kh = bld(bkh, oc, lv);
     L.uf = bld(buf, oc, lv); L.vf = bld(bvf, oc, lv);
@@ -411,7 +413,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P) {
     const double kqp = cur.kq1;
     // ---- level-local quantities
     double cck = 0., rhok = 0.;
-    if (k <= kbm1) { cck = profq_cc_v(P, cur.t, cur.s, hij, k); rhok = cur.rho; }
+    if (k <= kbm1) { cck = profq_cc_v(P, cur.t, cur.s, hij, k); rhok = rho_rt ? (cur.rho - cur.rm) + cur.rm : cur.rho; }
     double q2b = cur.q2b;
     double l, gh = 0.;
     double uck = 0., uek = 0., vck = 0., vnk = 0., bg = 0.;
@@ -1196,8 +1198,8 @@ void launch_profq_prod(pomgpu_ctx *c, int lines_only) {
   const int len = P.im > P.jm ? P.im : P.jm;
   LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P);
 }
-void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter) {
-#define PQ(FP, FF) LAUNCHN(c, "k_profq", (k_profq<FP, FF>), colgrid(c->P), colblk(), c->P)
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
+#define PQ(FP, FF) LAUNCHN(c, "k_profq", (k_profq<FP, FF>), colgrid(c->P), colblk(), c->P, rho_rt)
   if (fuse_filter) { if (fuse_prod == 0) PQ(0, 1); else if (fuse_prod == 1) PQ(1, 1); else PQ(2, 1); }
   else { if (fuse_prod == 0) PQ(0, 0); else if (fuse_prod == 1) PQ(1, 0); else PQ(2, 0); }
 #undef PQ

@@ -153,7 +153,14 @@ static void ext_buffers(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NGEN; n++) P.x2[n] = P.y2[n] = c->ext_parity ? c->alt2[n] : P.b2 + (size_t)X2_SLOT[n] * P.n2;
 }
 // trstr, srstr, taurstr of the last internal step, if k_ts_update skipped them
+// rho's deferred round trip (levels 1..kbm1; level kb was done when it was deferred)
+static void rho_materialize(pomgpu_ctx *c) {
+  if (!c->rho_rt_pending || (c->flags & POMGPU_CTX_2D)) return;
+  c->rho_rt_pending = 0;
+  launch_roundtrip(c, SLOT3(c, P3_rho), SLOT3(c, P3_rmean), 2);
+}
 static void restore_materialize(pomgpu_ctx *c) {
+  rho_materialize(c);
   if (!c->rst_pending) return;
   c->rst_pending = 0;
   launch_restore_fields(c, c->rst_fold, c->rst_fnew);
@@ -350,6 +357,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
   if (b3) {
+    c->tau_known[0] = c->tau_known[1] = 0;                      // taurstrb, taurstrf are the caller's now
     if (P.a3 == P.n3) HIPCHK(c, hipMemcpyAsync(P.b3, b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyHostToDevice, c->stream));
     else for (int n = 0; n < POM_NBLK3D; n++)
       HIPCHK(c, hipMemcpyAsync(SLOT3(c, n), b3 + (size_t)n * P.n3, sizeof(double) * P.n3, hipMemcpyHostToDevice, c->stream));
@@ -408,6 +416,8 @@ extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
 }
 extern "C" int pomgpu_upload_3d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK3D);
+  if (s == P3_taurstrb) c->tau_known[0] = 0;
+  if (s == P3_taurstrf) c->tau_known[1] = 0;
   HIPCHK(c, hipMemcpyAsync(SLOT3(c, s), h, sizeof(double) * c->P.n3, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return POMGPU_OK;
@@ -548,18 +558,30 @@ static void seq_advct(pomgpu_ctx *c, int sum2d = 0, int defer_xch = 0) {   // so
   launch_advct_c(c);
   xch(c, 1, D3(c, advy), P.kb);                               // :405
 }
-static void seq_baropg(pomgpu_ctx *c, int sum2d = 0) {        // solver.f:848-940
-  launch_baropg(c, sum2d);
-  launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :854 + :937
+// defer_rt (pomgpu_advance, mode 3): the in-place round trip rho = rho - rmean ... rho = rho + rmean (:854 + :937) changes
+// the stored rho by a rounding.  Before dens rewrites rho at the end of the same step only profq reads it, so the three
+// array passes of k_roundtrip are replaced by one extra read of rmean inside k_profq; level kb, which dens does not
+// write, makes its round trip here.  Anything else that wants rho first gets it materialised (rho_materialize).
+static void seq_rho_roundtrip(pomgpu_ctx *c, int defer_rt) {
+  if (defer_rt) {
+    launch_roundtrip_level(c, D3(c, rho), D3(c, rmean), c->P.kb);
+    c->rho_rt_pending = 1;
+  } else {
+    launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);
+  }
 }
-static void seq_baropg_mcc(pomgpu_ctx *c, int sum2d = 0) {    // solver.f:943-1159
+static void seq_baropg(pomgpu_ctx *c, int sum2d = 0, int defer_rt = 0) {        // solver.f:848-940
+  launch_baropg(c, sum2d);
+  seq_rho_roundtrip(c, defer_rt);                             // :854 + :937
+}
+static void seq_baropg_mcc(pomgpu_ctx *c, int sum2d = 0, int defer_rt = 0) {    // solver.f:943-1159
   KP &P = c->P;
   if (c->order) {                                             // :958-959 order2d_mpi(d), order3d_mpi(rho - rmean), one message per neighbour
     launch_order_pack(c, c->ord_send[0], c->ord_send[1]);
     c->order(c->order_user, c->ord_send[0], (P.kb + 1) * P.jml, c->ord_send[1], (P.kb + 1) * P.iml, c->ord_recv[0], c->ord_recv[1]);
   }
   launch_baropg_mcc(c, sum2d);
-  launch_roundtrip(c, D3(c, rho), D3(c, rmean), 0);           // :954 + :1164
+  seq_rho_roundtrip(c, defer_rt);                             // :954 + :1164
 }
 static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair, int zero_else) {   // solver.f:411-477
   KP &P = c->P;
@@ -580,15 +602,15 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
     launch_profq_prod(c, 1);
     if (with_w) xch(c, 4, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2, D3(c, w), P.kb);
     else xch(c, 3, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2);
-    launch_profq(c, 2, fuse_filter);                          // owned columns form prod inside the solve
+    launch_profq(c, 2, fuse_filter, c->rho_rt_pending);       // owned columns form prod inside the solve
     return;
   }
   if (with_w) xch(c, 3, P.s2[4], 1, ufkb, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
   else xch(c, 2, P.s2[4], 1, ufkb, 1);                        // :1289-1290
-  if (!c->exch) { launch_profq(c, 1, fuse_filter); return; }  // one tile: prod is formed inside the solve kernel
+  if (!c->exch) { launch_profq(c, 1, fuse_filter, c->rho_rt_pending); return; }  // one tile: prod is formed inside the solve kernel
   launch_profq_prod(c, 0);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
-  launch_profq(c, 0, fuse_filter);
+  launch_profq(c, 0, fuse_filter, c->rho_rt_pending);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
   launch_copy_kb(c, fb);                                      // solver.f:496 / :618
@@ -631,11 +653,13 @@ static int restore_prepare(pomgpu_ctx *c, double *fold_out, double *fnew_out) { 
     if (n < 1 || n > POMGPU_MAXREC || !c->rec_t[n])
       return fail(c, POMGPU_EINVAL, "restore_interior: record %d was not supplied (pomgpu_set_restore_record)", n);
     launch_restore_load(c, c->rec_t[n], c->rec_s[n], 1. / trst);
+    c->tau_known[1] = 1; c->tau_val[1] = 1. / trst;             // "taurstrf = 1./trst", the whole array
     return POMGPU_OK;
   };
   if (k.iint == 2) { int rc = load((k.iint / irst) + 1); if (rc) return rc; }
   if (k.iint == 2 || (irst > 0 && k.iint % irst == 0)) {
     launch_restore_shift(c);
+    c->tau_known[0] = c->tau_known[1]; c->tau_val[0] = c->tau_val[1];
     if (k.iint != k.iend) { int rc = load((k.iint + irst) / irst + 1); if (rc) return rc; }
   }
   *fnew_out = k.time / trst - ntime;
@@ -667,14 +691,15 @@ extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
 }
 // sum2d (pomgpu_advance on one tile): advct and baropg leave the vertical integrals that mode_interaction
 // would otherwise gather by reading advx, advy, drhox, drhoy again (advance.f:152-168)
-static int lateral_viscosity(pomgpu_ctx *c, int sum2d) {      // advance.f:96-141
+static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      // advance.f:96-141
   NEED_HOT(c);
+  rho_materialize(c);                                         // a deferred round trip no step has consumed (baropg reads rho)
   KP &P = c->P;
   if (P.mode != 2) {
     const bool lib_x = c->tp.on && c->exch && !getenv("POMGPU_ADVCT_SPLIT");
     seq_advct(c, sum2d, lib_x);                               // lib_x: advx, advy travel with aam below
-    if (P.npg == 1) seq_baropg(c, sum2d);
-    else if (P.npg == 2) seq_baropg_mcc(c, sum2d);
+    if (P.npg == 1) seq_baropg(c, sum2d, defer_rt);
+    else if (P.npg == 2) seq_baropg_mcc(c, sum2d, defer_rt);
     else {                                                    // advance.f:117-120
       fprintf(stderr, "\nError: invalid value for npg\n");
       c->con.error_status = 1;
@@ -1090,6 +1115,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       int rc = restore_prepare(c, &fold, &fnew);              // :452 (record handling)
       if (rc) return rc;
       launch_ts_update(c, fold, fnew, k.nadv == 2, 0);        // :444-454 in one pass; trstr/srstr/taurstr on demand
+      c->rho_rt_pending = 0;                                  // dens has rewritten rho(1..kbm1)
       c->rst_pending = 1; c->rst_fold = fold; c->rst_fnew = fnew;
     }
     if (c->P.kb >= 6 && c->P.kb <= 64 && !getenv("POMGPU_THOMAS_SCRATCH")) {
@@ -1270,7 +1296,10 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
   const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
   const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
-  if ((rc = lateral_viscosity(c, sum2d))) return rc;
+  // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)
+  const pom_blkcon &k0 = c->con;
+  const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !c->exch && !getenv("POMGPU_RHO_ROUNDTRIP");   // one tile: on tiles k_profq_prod(_lines) read rho as well
+  if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
   for (int iext = 1; iext <= c->con.isplit; iext++) {
     c->con.iext = iext;

@@ -390,6 +390,14 @@ struct pomgpu_ctx {
   double *ord_send[2], *ord_recv[2];   // [0] east/west: (kb+1) x jml, [1] north/south: (kb+1) x iml
   double *alt2[POMGPU_NGEN]; // second buffer set of ua, va, d, el, elb, uab, vab (fused external step)
   int ext_parity;            // 1 while the current generation of those five lives in alt2
+  // taurstrb / taurstrf (index 0 / 1): known to hold one value everywhere restore_interior looks, because the library wrote
+  // it itself ("taurstrf = 1./trst", bounds_forcing.f:1043,1065; the shift :1054-1056 hands f's value to b).  k_ts_update then
+  // forms taurstr from the two scalars instead of reading two 3-D arrays.  Any upload of those arrays ends the knowledge.
+  int tau_known[2];
+  double tau_val[2];
+  // rho's round trip through rho - rmean (baropg, solver.f:854,937) has not been stored for levels 1..kbm1: inside
+  // pomgpu_advance its only reader before dens rewrites rho is k_profq, which applies it to what it loads
+  int rho_rt_pending;
   int rst_pending;           // trstr/srstr/taurstr of the last step exist only as (rst_fold, rst_fnew) weights
   double rst_fold, rst_fnew;
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
@@ -499,6 +507,7 @@ void launch_advct_b(pomgpu_ctx *c);
 void launch_advct_c(pomgpu_ctx *c);
 void launch_aam(pomgpu_ctx *c);
 void launch_roundtrip(pomgpu_ctx *c, double *a, const double *b, int fix_kb);
+void launch_roundtrip_level(pomgpu_ctx *c, double *a, const double *b, int k);
 void launch_advq_flux(pomgpu_ctx *c, const double *q, const double *qb, double *xf, double *yf);
 void launch_advq_step(pomgpu_ctx *c, const double *q, const double *qb, double *qf, const double *xf, const double *yf, int zero_else);
 void launch_q_filter(pomgpu_ctx *c, int mask);
@@ -512,7 +521,7 @@ void launch_mask3(pomgpu_ctx *c, double *a, const double *m2);
 void launch_smol(pomgpu_ctx *c, const double *ff);
 void launch_copy3(pomgpu_ctx *c, double *dst, const double *src);
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff);
-void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst);
+void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst);   // uses c->tau_known / tau_val
 void launch_restore_fields(pomgpu_ctx *c, double fold, double fnew);
 void launch_mask_ts(pomgpu_ctx *c);
 void launch_mask_uv(pomgpu_ctx *c);
@@ -530,7 +539,7 @@ void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
 void launch_profq_prod(pomgpu_ctx *c, int lines_only);
-void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter);
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt = 0);
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
