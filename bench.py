@@ -77,7 +77,18 @@ KERNEL_PASSES = {
     "k_realvertvl": 4,       # a20
 }
 P_STEP = 133                 # algorithmic 3-D passes per internal step (mode=3 nadv=2 nitera=1)
-HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0        # measured float4-copy ceiling (same guide); SURVEY 8(d): report both
+
+
+def _libc_version():
+    import ctypes
+    try:
+        f = ctypes.CDLL("libc.so.6").gnu_get_libc_version
+        f.restype = ctypes.c_char_p
+        return "glibc " + f().decode()
+    except Exception:                     # noqa: BLE001
+        return "unknown"
 
 
 def build_state(workload, tile):
@@ -393,7 +404,7 @@ def main():
                 rec = json.load(open(tf)).get(f"{args.workload}/{world}/{dom}")
                 traffic = rec["bytes_per_launch"] if rec else None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(ach / HBM_COPY_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": passes * 8 * tile_cells, "launches": nl,
                     "avg_launch_ms": round(tms / nl, 4)}
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
@@ -414,8 +425,11 @@ def main():
                        "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0},
             "roofline": roof,
             "step_algorithmic_GBps": round(step_gbs, 1), "step_frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4),
+            "step_frac_of_measured_copy_ceiling": round(step_gbs / HBM_COPY_GBS, 4),
             "internal_mode": {"device_ms_per_step": round(int_ms, 3), "cell_updates_per_s": (tile_cells / (int_ms * 1e-3)) if int_ms else None,
                               "algorithmic_GBps": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
+                              "frac_of_peak": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if int_ms else None,
+                              "frac_of_measured_copy_ceiling": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if int_ms else None,
                               "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
             "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
             # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what
@@ -425,6 +439,7 @@ def main():
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,
+            "host_libc": _libc_version(),     # bit-parity with the reference leans on this libm's pow (THIRD_PARTY_NOTICES.md)
         }
         if not args.no_cpu_baseline and world == 1:
             port = cpu_baseline(args.workload)

@@ -5,6 +5,8 @@
 // so bit-parity with the reference needs this exact algorithm, not merely an accurate x**1.5.
 // Values are the table words of Ubuntu GLIBC 2.35-0ubuntu3 (x86-64), printed as hex floats /
 // 64-bit words; regenerate with tools/dump_glibc_pow_tables.py.
+// Derived from glibc (LGPL-2.1-or-later; upstream ARM optimized-routines, MIT / Apache-2.0 WITH LLVM-exception):
+// see THIRD_PARTY_NOTICES.md at the repository root.
 #pragma once
 #define GPOW_LN2HI 0x1.62e42fefa3800p-1
 #define GPOW_LN2LO 0x1.ef35793c76730p-45

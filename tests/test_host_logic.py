@@ -127,3 +127,19 @@ def test_domain_stats_partial_sums_add_up_over_tiles():
     iml, jml = decomp.local_size(41, 35, 2, 2)
     parts = sum(sums(cut_tile(g, decomp.make_tile(r, 41, 35, iml, jml, n_proc=4))) for r in range(4))
     np.testing.assert_allclose(parts, whole, rtol=1e-12, atol=0)
+
+
+def test_host_libm_is_the_one_the_pow_clone_restates(tmp_path):
+    """bit-parity with the reference leans on glibc's (not correctly rounded) pow: `dens` calls it for abs(sr)**1.5 and the
+    HIP kernel restates glibc 2.35's algorithm (THIRD_PARTY_NOTICES.md).  A host with another libm changes what "the
+    reference" computes -- so (i) the libc version is pinned here and stated on the bench line, (ii) the restatement
+    (tools/check_glibc_pow_clone.c, the same code as gpow15 in k_adv.hip) equals this host's pow() on 2.2e7 arguments."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.gnu_get_libc_version.restype = ctypes.c_char_p
+    ver = libc.gnu_get_libc_version().decode()
+    assert ver.startswith("2.35"), f"glibc {ver}: the pow tables were read out of 2.35 -- re-run tools/dump_glibc_pow_tables.py and the parity tests"
+    exe = tmp_path / "chkpow"
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_glibc_pow_clone.c"), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300).stdout
+    assert "x**1.5: 0 mismatches" in out and "general x**y: 0 mismatches" in out, out
