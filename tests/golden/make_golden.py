@@ -2,7 +2,7 @@
 (oracle/_ref/libpomref_65x49x21.so, built from the unmodified sources by oracle/build_ref.sh) on
 the inputs of extpom_amd.cases.  Run from the repo root in a container that has /root/reference:
 
-    oracle/build_ref.sh 65 49 21 && oracle/build_ref.sh 256 192 50 && python tests/golden/make_golden.py [kb50]
+    oracle/build_ref.sh 65 49 21 && oracle/build_ref.sh 256 192 50 && python tests/golden/make_golden.py [kb50 | forced]
 
 The fixture holds, per configuration and checkpoint step, the SHA-256 of every restart-list field
 (the prognostic state, reference io_pnetcdf.F:1724-1886) exactly as the reference left it in its
@@ -55,7 +55,42 @@ CONFIGS_KB50 = {
 }
 
 
+# One configuration stepped by the reference's OWN `advance` (advance.f:6-59) instead of the harness's restatement of its
+# sequence: surface_forcing and lateral_bc run as the reference calls them (their PnetCDF readers are the input hooks of
+# oracle/ref_traps.c, fed the records of extpom_amd.cases), print_section / write_output / write_restart stay silent
+# because iprint and irestart lie beyond the run (prtd1 = 0.5 d -> iprint = 120 steps at dti = 360 s).
+FORCED = ("seamount", dict(dte=6.0, isplit=60, days=1.0, prtd1=0.5), [1, 2, 10, 11, 30, 31])
+
+
+def generate_forced():
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
+    case, nml, checkpoints = FORCED
+    st = make_case(case, 65, 49, 21, **nml)
+    ref_finish_initial(st)
+    make_forcing_records(st, 4)
+    make_lateral_records(st, 8)
+    lib = RefLib(65, 49, 21)
+    lib.mpi_init()
+    lib.put(st)
+    assert int(lib.con["iprint"][0]) > max(checkpoints) and int(lib.con["irestart"][0]) > max(checkpoints)
+    cfg = {"case": case, "nml": nml, "forcing_records": 4, "lateral_records": 8, "steps": {}}
+    for n in range(1, max(checkpoints) + 1):
+        lib.con["iint"][0] = n
+        lib.call("advance")                      # the reference's own subroutine
+        if n in checkpoints:
+            lib.get(st)
+            cfg["steps"][str(n)] = {f: digest(st.field(f)) for f in RESTART_2D + RESTART_3D}
+            cfg["steps"][str(n)]["bdry"] = digest(st.bdry)
+    assert int(lib.con["error_status"][0]) == 0
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "forced_advance_65x49x21.json"), "w") as f:
+        json.dump({"grid": [65, 49, 21], "fields": RESTART_2D + RESTART_3D, "config": cfg}, f, indent=1, sort_keys=True)
+    print("forced_advance done", flush=True)
+
+
 def main():
+    if "forced" in sys.argv[1:]:
+        return generate_forced()
     if "kb50" not in sys.argv[1:]:
         generate(65, 49, 21, CONFIGS, PLANES, "seamount_65x49x21")
     generate(256, 192, 50, CONFIGS_KB50, {}, "kb50_256x192x50")

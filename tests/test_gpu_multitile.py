@@ -47,3 +47,15 @@ def test_rccl_transport_on_a_periodic_single_rank():
     must give bit-identical fields."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_rccl_self.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL-SELF-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["seamount_2x2", "hook"], ["seamount_2x2", "transport"], ["seamount_2x2_npg2", "transport"], ["island_2x2", "transport"],
+                                  ["seamount_2x2_isplit10", "wide"], ["seamount_2x2_isplit10_npg2", "wide"]])
+def test_hip_tiles_equal_the_references_own_mpi_run(args):
+    """four ranks on GPU 0, the reference's own tile size (34 x 26 on 65x49x21): every restart-list field of every rank,
+    ghost cells included, hashes to what the REFERENCE left on that rank of a four-process MPICH run
+    (tests/golden/tiles_65x49x21_2x2.json) -- with the per-point hooks, the library exchange and the wide-halo mode"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tiles_golden_worker.py")] + args, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "TILES-GOLDEN-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

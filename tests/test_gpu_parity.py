@@ -478,3 +478,34 @@ def test_config4_2048x1536x50_full_size():
         assert not np.any((x if x.ndim == 2 else x[:49]) * (1.0 - a.fsm)), f
     assert a.error_status == c.error_status == 0
     beat("done")
+
+
+def test_gpu_equals_the_references_own_advance_with_file_forcing():
+    """the HIP path (pomgpu_advance with the forcing and lateral records in HBM) against digests of the reference's OWN
+    `advance` subroutine (tests/golden/forced_advance_65x49x21.json, make_golden.py forced)"""
+    import json
+    import os
+    from extpom_amd.cases import make_forcing_records, make_lateral_records
+    OracleTile, oracle_finish_initial = _oracle()
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", "forced_advance_65x49x21.json")))
+    cfg = gold["config"]
+    im, jm, kb = gold["grid"]
+    st = make_case(cfg["case"], im, jm, kb, **cfg["nml"])
+    oracle_finish_initial(st)
+    make_forcing_records(st, cfg["forcing_records"])
+    make_lateral_records(st, cfg["lateral_records"])
+    g = _gpu(st)
+    g.set_forcing_records()
+    g.set_lateral_records()
+    checkpoints = sorted(int(s) for s in cfg["steps"])
+    for n in range(1, checkpoints[-1] + 1):
+        if n % 10 == 0:
+            g.set_lateral_records(first=n // 10 + 2, count=1)      # the record lateral_bc asks for at this step
+        g.run(1)
+        if n in checkpoints:
+            g.download()
+            want = cfg["steps"][str(n)]
+            bad = [f for f in gold["fields"] if _digest(st.field(f)) != want[f]]
+            assert not bad and _digest(st.bdry) == want["bdry"], f"step {n}: {bad}"
+    g.close()
