@@ -331,7 +331,7 @@ def main():
             exchange = "library exchange, host-staged mover (rehearsal)"
         else:
             if H.connect_rccl(g, tile, rank, world):
-                exchange = "library exchange, native RCCL send/recv on the kernels' stream"
+                exchange = "library exchange, native RCCL send/recv on the kernels' stream (+ a second stream and communicator for the early part of the wide exchange and wr)"
             elif os.environ.get("POM_BENCH_ALLOW_P2P") == "1":   # developer switch: torch.distributed's RCCL P2P carries the same messages
                 print(f"bench[{rank}]: native RCCL transport unavailable; using torch.distributed P2P", file=sys.stderr)
                 bench_halo = H.DeviceHalo(g, tile, dev)
@@ -370,7 +370,7 @@ def main():
     g.prof_begin(only=None if args.profile_all else dom)
     barrier()
     deadline("timed steps", 120.0 + 2.0 * args.steps)          # generous: a step takes tens of milliseconds
-    rounds0 = g.exchange_rounds()
+    rounds0, rounds0s = g.exchange_rounds(), g.exchange_rounds_side()
     t0 = time.perf_counter()
     g.run(args.steps)
     g.sync()
@@ -410,6 +410,7 @@ def main():
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
         ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
         msg_ms = prof.pop("msg_round", (0, 0.0))[1]           # the message rounds of the profiled step (N > 1): not a kernel
+        msg_side_ms = prof.pop("msg_round_side", (0, 0.0))[1] # ... those on the library's second stream: beside kernels, not between them
         int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
         ext_ms = sum(v[1] for k, v in prof.items() if k.startswith(ext))
         step_gbs = P_STEP * 8.0 * cells / (dt / args.steps) / 1e9
@@ -422,7 +423,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
-                       "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0},
+                       "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0,
+                       "message_rounds_per_step_on_side_stream": (g.exchange_rounds_side() - rounds0s) / args.steps if world > 1 else 0},
             "roofline": roof,
             "step_algorithmic_GBps": round(step_gbs, 1), "step_frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_frac_of_measured_copy_ceiling": round(step_gbs / HBM_COPY_GBS, 4),
@@ -435,7 +437,8 @@ def main():
             # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what
             # the message rounds and the waiting for neighbours cost
             "kernel_ms_sum_rank0": round(sum(v[1] for v in prof.values()), 3),
-            "message_rounds_ms_rank0": round(msg_ms, 3),          # transfers + waiting for the neighbours, same profiled step
+            "message_rounds_ms_rank0": round(msg_ms, 3),          # transfers + waiting for the neighbours, same profiled step: EXPOSED (kernels' stream)
+            "message_rounds_side_stream_ms_rank0": round(msg_side_ms, 3),   # HIDDEN: on the second stream, beside lateral_viscosity / the next step
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,

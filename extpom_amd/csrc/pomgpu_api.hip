@@ -61,25 +61,28 @@ int pomgpu_prof_slot(pomgpu_ctx *c, const char *name) {
   return c->nprof++;
 }
 void pomgpu_prof_pre(pomgpu_ctx *c) {
+  const hipStream_t st = c->cur;                              // the stream the bracketed work goes to
   if (c->parent) c = c->parent;
   ProfState *ps = PS(c);
   ProfPair p;
   if (!ps->free_.empty()) { p = ps->free_.back(); ps->free_.pop_back(); }
   else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
   p.slot = -1;
-  (void)hipEventRecord(p.a, c->stream);
+  (void)hipEventRecord(p.a, st);
   ps->pending.push_back(p);
 }
 void pomgpu_prof_post(pomgpu_ctx *c, int slot) {
+  const hipStream_t st = c->cur;
   if (c->parent) c = c->parent;
   ProfState *ps = PS(c);
   ProfPair &p = ps->pending.back();
   p.slot = slot;
-  (void)hipEventRecord(p.b, c->stream);
+  (void)hipEventRecord(p.b, st);
 }
 static void prof_drain(pomgpu_ctx *c) {
   ProfState *ps = PS(c);
   (void)hipStreamSynchronize(c->stream);
+  if (c->side) (void)hipStreamSynchronize(c->side);
   for (size_t n = 0; n < ps->pending.size(); n++) {
     ProfPair &p = ps->pending[n];
     float ms = 0.f;
@@ -159,7 +162,9 @@ static void rho_materialize(pomgpu_ctx *c) {
   c->rho_rt_pending = 0;
   launch_roundtrip(c, SLOT3(c, P3_rho), SLOT3(c, P3_rmean), 2);
 }
+static void side_join(pomgpu_ctx *c);
 static void restore_materialize(pomgpu_ctx *c) {
+  side_join(c);                                               // whoever asks for materialised state also waits for the side stream
   rho_materialize(c);
   if (!c->rst_pending) return;
   c->rst_pending = 0;
@@ -230,6 +235,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return POMGPU_EHIP; }
     c->own_stream = true;
   }
+  c->cur = c->stream;
   c->prof_state = new ProfState();
   PS(c)->filter[0] = 0;
   bool ok = true;
@@ -277,6 +283,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side) (void)hipStreamSynchronize(c->side);
   wide_free(c);
   pomgpu_tp_free(c);
   KP &P = c->P;
@@ -298,6 +305,10 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
     for (auto &p : ps->free_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete ps;
   }
+  if (c->side) {
+    (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_early); (void)hipEventDestroy(c->ev_side);
+    (void)hipStreamDestroy(c->side);
+  }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   free(c);
 }
@@ -315,6 +326,7 @@ static int pull_err(pomgpu_ctx *c) {
 }
 extern "C" int pomgpu_sync(pomgpu_ctx *c) {
   if (!c) return POMGPU_EINVAL;
+  side_join(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return c->launch_err ? POMGPU_EHIP : POMGPU_OK;
 }
@@ -674,10 +686,28 @@ static int seq_restore_interior(pomgpu_ctx *c) {              // bounds_forcing.
   return POMGPU_OK;
 }
 
+// ---- the side stream --------------------------------------------------------------------------------------------------
+// side_begin: what is enqueued from here on goes to the side stream, after everything the main stream holds so far;
+// side_end(ev): back to the main stream; `ev` marks the end of the side work.  side_join: the main stream waits for it.
+static void side_begin(pomgpu_ctx *c) {
+  (void)hipEventRecord(c->ev_fork, c->stream);
+  (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+  c->cur = c->side;
+  if (c->wide.x) c->wide.x->cur = c->side;
+}
+static void side_end(pomgpu_ctx *c, hipEvent_t ev) {
+  (void)hipEventRecord(ev, c->side);
+  c->cur = c->stream;
+  if (c->wide.x) c->wide.x->cur = c->stream;
+}
+static void side_join(pomgpu_ctx *c) {                        // everything the side stream holds, before the main stream goes on
+  if (c->early_started) { (void)hipStreamWaitEvent(c->stream, c->ev_early, 0); c->early_started = 0; }
+  if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }
+}
 #define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
 static void wide_flush(pomgpu_ctx *c);
 #define NEED_HOT(c) NEED_RAW(c); ext_canonical(c); wide_flush(c)   /* the entry points pomgpu_advance strings together */
-#define NEED(c) NEED_HOT(c); restore_materialize(c)
+#define NEED(c) NEED_HOT(c); side_join(c); restore_materialize(c)
 
 extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
   NEED_HOT(c);
@@ -842,6 +872,12 @@ static const int WIDE_BACK[] = {P2_adx2d, P2_ady2d, P2_advua, P2_advva, P2_elf, 
 // south / north edge; a tile on such an edge continues them from its neighbours along the edge
 static const int WIDE_BD_J[] = {PB_uabw, PB_elw, PB_vabw, PB_uabe, PB_ele, PB_vabe};
 static const int WIDE_BD_I[] = {PB_vabs, PB_els, PB_uabs, PB_vabn, PB_eln, PB_uabn};
+// The same HALO list in two parts.  LATE: what lateral_viscosity and the vertical integrals of mode_interaction produce in
+// THIS step (advance.f:96-168).  EARLY: everything else -- final when the step starts (the external mode and mode_internal
+// of the step before wrote them; surface_forcing / lateral_bc, if they run, come first) -- most of the bytes.
+static const int WIDE_HALO_LATE[] = {P2_adx2d, P2_ady2d, P2_drx2d, P2_dry2d, P2_aam2d};
+static const int WIDE_HALO_EARLY[] = {P2_ua, P2_va, P2_uab, P2_vab, P2_el, P2_elb, P2_d, P2_vfluxf, P2_e_atmos, P2_wusurf, P2_wvsurf, P2_wubot,
+                                      P2_wvbot};
 #define NEL(a) ((int)(sizeof(a) / sizeof((a)[0])))
 static bool wide_travels_every_step(int slot2d) {
   for (int n = 0; n < NEL(WIDE_HALO); n++) if (WIDE_HALO[n] == slot2d) return true;
@@ -880,6 +916,9 @@ static void table_free(RectTable &T) { (void)hipFree(T.dev); T.dev = NULL; T.ngr
 static void wide_free(pomgpu_ctx *c) {
   pomgpu_wide &Wd = c->wide;
   table_free(Wd.gather_pack); table_free(Wd.gather_unpack); table_free(Wd.scatter);
+  table_free(Wd.early_pack); table_free(Wd.early_unpack); table_free(Wd.late_pack); table_free(Wd.late_unpack);
+  Wd.split = 0;
+  c->early_started = 0;
   if (Wd.x) { pomgpu_destroy(Wd.x); Wd.x = NULL; }
   Wd.on = 0;
 }
@@ -898,11 +937,12 @@ static void wide_rect(const KP &P, int w, int d, int &sx, int &sy, int &rx, int 
 // Job lists for one set of arrays: `halo` slots get the tile's own cells and the neighbours' blocks, `local` slots
 // the tile's own cells only; with_bd adds the open-boundary lines.  pack/unpack go around one message round.
 static void wide_jobs(pomgpu_ctx *c, const int *halo, int nhalo, const int *local, int nlocal, bool with_bd, JobList &pack,
-                      JobList &unpack, size_t *scount, size_t *rcount) {
+                      JobList &unpack, size_t *scount, size_t *rcount, double *const *snd = NULL, double *const *rcv = NULL) {
   const KP &P = c->P;
   const pomgpu_wide &Wd = c->wide;
   const KP &X = Wd.x->P;
   const pomgpu_transport &T = c->tp;
+  if (!snd) { snd = T.send; rcv = T.recv; }
   auto tile = [&](int s, int i, int j) { return P.b2 + (size_t)s * P.n2 + (size_t)(j - 1) * P.iml + (size_t)(i - 1); };
   auto ext = [&](int s, int i, int j) { return X.b2 + (size_t)s * X.n2 + (size_t)(j + Wd.oy - 1) * X.iml + (size_t)(i + Wd.ox - 1); };
   pack.begin();                                               // own cells, ghost cells included
@@ -922,20 +962,20 @@ static void wide_jobs(pomgpu_ctx *c, const int *halo, int nhalo, const int *loca
       wide_rect(P, Wd.w, d, sx, sy, rx, ry, ni, nj);
       size_t o = 0;
       for (int n = 0; n < nhalo; n++) {
-        pack.add(tile(halo[n], sx, sy), P.iml, T.send[d] + o, ni, ni, nj);
-        unpack.add(T.recv[d] + o, ni, ext(halo[n], rx, ry), X.iml, ni, nj);
+        pack.add(tile(halo[n], sx, sy), P.iml, snd[d] + o, ni, ni, nj);
+        unpack.add(rcv[d] + o, ni, ext(halo[n], rx, ry), X.iml, ni, nj);
         o += (size_t)ni * nj;
       }
       if (with_bd && cls == 1)                                // from S / N: the continuation of the west / east edge lines
         for (int n = 0; n < NEL(WIDE_BD_J); n++) {
-          pack.add(P.bd + P.bdoff[WIDE_BD_J[n]] + (sy - 1), nj, T.send[d] + o, nj, nj, 1);
-          unpack.add(T.recv[d] + o, nj, X.bd + X.bdoff[WIDE_BD_J[n]] + (ry + Wd.oy - 1), nj, nj, 1);
+          pack.add(P.bd + P.bdoff[WIDE_BD_J[n]] + (sy - 1), nj, snd[d] + o, nj, nj, 1);
+          unpack.add(rcv[d] + o, nj, X.bd + X.bdoff[WIDE_BD_J[n]] + (ry + Wd.oy - 1), nj, nj, 1);
           o += (size_t)nj;
         }
       if (with_bd && cls == 0)                                // from W / E: the continuation of the south / north edge lines
         for (int n = 0; n < NEL(WIDE_BD_I); n++) {
-          pack.add(P.bd + P.bdoff[WIDE_BD_I[n]] + (sx - 1), ni, T.send[d] + o, ni, ni, 1);
-          unpack.add(T.recv[d] + o, ni, X.bd + X.bdoff[WIDE_BD_I[n]] + (rx + Wd.ox - 1), ni, ni, 1);
+          pack.add(P.bd + P.bdoff[WIDE_BD_I[n]] + (sx - 1), ni, snd[d] + o, ni, ni, 1);
+          unpack.add(rcv[d] + o, ni, X.bd + X.bdoff[WIDE_BD_I[n]] + (rx + Wd.ox - 1), ni, ni, 1);
           o += (size_t)ni;
         }
       scount[d] = rcount[d] = o;
@@ -1015,9 +1055,55 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
     wide_free(c);
     return rc;
   }
+  // the two-part gather on two streams (the default where the transport can serve a second stream)
+  if (!c->side && !getenv("POMGPU_NO_OVERLAP")) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = NULL;
+    else {
+      (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming);
+    }
+  }
+  if (c->side && pomgpu_tp_side_ok(c) && !getenv("POMGPU_NO_OVERLAP")) {
+    size_t need2[8];
+    const size_t per2 = (size_t)NEL(WIDE_HALO_EARLY) * (w + 1);
+    need2[0] = need2[1] = per2 * P.jm + edge;
+    need2[2] = need2[3] = per2 * P.im + edge;
+    need2[4] = need2[5] = need2[6] = need2[7] = per2 * (w + 1);
+    // the wr exchange of the end of the step shares these buffers (same stream, so never at the same time)
+    const size_t wrn[8] = {(size_t)P.kb * P.jm, (size_t)P.kb * P.jm, (size_t)P.kb * P.im, (size_t)P.kb * P.im, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb};
+    for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < wrn[d8]) need2[d8] = wrn[d8];
+    if ((rc = pomgpu_tp_reserve2(c, need2))) { wide_free(c); return rc; }
+    JobList epk, eup, lpk, lup;
+    wide_jobs(c, WIDE_HALO_EARLY, NEL(WIDE_HALO_EARLY), WIDE_LOCAL, NEL(WIDE_LOCAL), true, epk, eup, Wd.e_scount, Wd.e_rcount, T.send2, T.recv2);
+    wide_jobs(c, WIDE_HALO_LATE, NEL(WIDE_HALO_LATE), NULL, 0, false, lpk, lup, Wd.l_scount, Wd.l_rcount);
+    if ((rc = table_upload(c, epk, Wd.early_pack)) || (rc = table_upload(c, eup, Wd.early_unpack)) || (rc = table_upload(c, lpk, Wd.late_pack)) ||
+        (rc = table_upload(c, lup, Wd.late_unpack))) {
+      wide_free(c);
+      return rc;
+    }
+    Wd.split = 1;
+  }
   Wd.static_done = 0;
   Wd.on = 1;
   return POMGPU_OK;
+}
+// The early part of the gather, on the side stream: called by pomgpu_advance once the step's forcing is in place, so that
+// its pack kernels, its message round and its unpack kernels run beside lateral_viscosity (advance.f:96-141) on the main
+// stream.  Nothing between here and wide_begin touches the arrays of WIDE_HALO_EARLY / WIDE_LOCAL / the boundary lines,
+// nor the extended tile.
+static int wide_early_start(pomgpu_ctx *c) {
+  pomgpu_wide &Wd = c->wide;
+  if (!Wd.on || !Wd.split || Wd.pending || c->early_started) return POMGPU_OK;
+  int rc;
+  if (!Wd.static_done && (rc = wide_static(c))) return rc;
+  side_begin(c);
+  table_run(c, Wd.early_pack);
+  rc = pomgpu_tp_move_side(c, Wd.e_scount, Wd.e_rcount);
+  if (!rc) table_run(c, Wd.early_unpack);
+  side_end(c, c->ev_early);
+  c->early_started = 1;
+  return rc;
 }
 // The 2-D part of one internal step on the extended tile.  wide_begin: the rest of mode_interaction after the
 // vertical integrals (advance.f:170-199); the isplit calls of mode_external then work on the extended tile
@@ -1028,9 +1114,17 @@ static int wide_begin(pomgpu_ctx *c) {
   pomgpu_ctx *x = Wd.x;
   int rc;
   if (!Wd.static_done && (rc = wide_static(c))) return rc;
-  table_run(c, Wd.gather_pack);
-  if ((rc = pomgpu_tp_move(c, Wd.scount, Wd.rcount))) return rc;
-  table_run(c, Wd.gather_unpack);
+  if (c->early_started) {                                     // the rest of the gather here, then wait for the part that ran beside
+    table_run(c, Wd.late_pack);
+    if ((rc = pomgpu_tp_move(c, Wd.l_scount, Wd.l_rcount))) return rc;
+    table_run(c, Wd.late_unpack);
+    (void)hipStreamWaitEvent(c->stream, c->ev_early, 0);
+    c->early_started = 0;
+  } else {
+    table_run(c, Wd.gather_pack);
+    if ((rc = pomgpu_tp_move(c, Wd.scount, Wd.rcount))) return rc;
+    table_run(c, Wd.gather_unpack);
+  }
   x->con = c->con; x->lramp = c->lramp;
   sync_scalars(x);
   if (x->P.mode != 2) seq_advave(x);                          // advance.f:170 (the extended tile has no exchange: fused kernels)
@@ -1145,7 +1239,23 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
   launch_int_tail(c);                                         // :525-531
   launch_coef_dt(c);                                          // dt changed: refresh the derived coefficients
   launch_realvertvl(c);                                       // :534
-  xch(c, 1, D3(c, wr), P.kbm1);                               // solver.f:2055
+  if (c->tp.on && c->exch && c->wide.split && !getenv("POMGPU_WR_MAIN")) {
+    // solver.f:2055 on the side stream: nobody on the hot path reads wr's ghost cells (a diagnostic for the output
+    // file), so the round runs beside check_velocity and the next step's lateral_viscosity; the next step's early gather
+    // follows it on the same stream, and whoever looks at the state waits for it (side_join)
+    side_join(c);                                             // at most one piece of side work outstanding per event
+    side_begin(c);
+    double *arr[1] = {D3(c, wr)};
+    const int nz[1] = {P.kbm1};
+    const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
+    size_t cnt[8];
+    for (int d = 0; d < 8; d++) cnt[d] = c->tp.nbr[d] >= 0 ? (size_t)P.kbm1 * len[d] : 0;
+    if (!launch_halo_pack8(c, arr, nz, 1, c->tp.send2) && !pomgpu_tp_move_side(c, cnt, cnt)) (void)launch_halo_unpack8(c, arr, nz, 1, (const double *const *)c->tp.recv2);
+    side_end(c, c->ev_side);
+    c->side_pending = 1;
+  } else {
+    xch(c, 1, D3(c, wr), P.kbm1);                             // solver.f:2055
+  }
   return POMGPU_OK;
 }
 extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, int *jmax) {   // advance.f:611-641
@@ -1296,6 +1406,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
   const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
   const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
+  if ((rc = wide_early_start(c))) return rc;                  // most of the wide exchange, beside lateral_viscosity
   // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)
   const pom_blkcon &k0 = c->con;
   const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !c->exch && !getenv("POMGPU_RHO_ROUNDTRIP");   // one tile: on tiles k_profq_prod(_lines) read rho as well

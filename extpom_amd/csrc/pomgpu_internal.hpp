@@ -357,6 +357,9 @@ struct pomgpu_transport {
   void *rccl;                // RcclComm* (transport.hip), NULL with a callback transport
   double *send[8], *recv[8];
   size_t cap[8];             // capacity of each staging buffer, doubles
+  double *send2[8], *recv2[8];   // staging buffers of the side stream's rounds (they overlap rounds on the main stream)
+  size_t cap2[8];
+  long rounds_side;          // message rounds served on the side stream
   long rounds;               // message rounds served so far
 };
 // One rectangular block copy: ni x nj doubles from src (row stride ld_s) to dst (row stride ld_d).
@@ -370,6 +373,11 @@ struct pomgpu_wide {
   pomgpu_ctx *x;
   RectTable gather_pack, gather_unpack, scatter;   // per internal step
   size_t scount[8], rcount[8];
+  // the same gather in two parts: EARLY = every array that is final when the step starts (most of the bytes; side stream,
+  // beside lateral_viscosity), LATE = the vertical integrals lateral_viscosity / mode_interaction produce (main stream)
+  RectTable early_pack, early_unpack, late_pack, late_unpack;
+  size_t e_scount[8], e_rcount[8], l_scount[8], l_rcount[8];
+  int split;                 // the two-part tables exist and the transport can serve the side stream
   int pending;               // the 2-D state of the running external loop lives in x (between wide_begin and the last substep)
   int static_done;           // every blk2d array (grid metrics, masks ...) has been widened since the last upload
 };
@@ -379,6 +387,14 @@ struct pomgpu_ctx {
   int device;
   hipStream_t stream;
   bool own_stream;
+  // Second stream (pomgpu_set_wide_external creates it): message rounds whose arrays are ready early, or whose ghost cells
+  // nobody waits for, run there beside the kernels of the main stream -- their pack / unpack kernels included -- over a
+  // second communicator, joined by events (no host synchronisation).  `cur` is the stream LAUNCH and the profiler use:
+  // the main stream except while work for the side stream is being enqueued.
+  hipStream_t cur, side;
+  hipEvent_t ev_fork, ev_early, ev_side;
+  int early_started;         // this step's early part of the wide exchange is in flight on the side stream (ev_early ends it)
+  int side_pending;          // work on the side stream that the main stream has not waited for yet (ev_side ends it)
   pom_blkcon con;            // host copy of blkcon (iint, iext, error_status live here)
   int lramp;
   double *rec_t[POMGPU_MAXREC + 1], *rec_s[POMGPU_MAXREC + 1];
@@ -432,7 +448,7 @@ void pomgpu_launch_check(pomgpu_ctx *c, const char *name);   // a refused launch
   do {                                                                           \
     int _s = (c)->prof_on ? pomgpu_prof_slot((c), #kern) : -1;                   \
     if (_s >= 0) pomgpu_prof_pre(c);                                             \
-    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->cur, __VA_ARGS__);             \
     pomgpu_launch_check((c), #kern);                                             \
     if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
   } while (0)
@@ -442,7 +458,7 @@ void pomgpu_launch_check(pomgpu_ctx *c, const char *name);   // a refused launch
   do {                                                                           \
     int _s = (c)->prof_on ? pomgpu_prof_slot((c), name) : -1;                    \
     if (_s >= 0) pomgpu_prof_pre(c);                                             \
-    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);          \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->cur, __VA_ARGS__);             \
     pomgpu_launch_check((c), name);                                              \
     if (_s >= 0) pomgpu_prof_post((c), _s);                                      \
   } while (0)
@@ -566,6 +582,9 @@ int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8);
 int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const char *librccl_path);
 void pomgpu_tp_free(pomgpu_ctx *c);
 int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need);                       // grow the staging buffers
+int pomgpu_tp_reserve2(pomgpu_ctx *c, const size_t *need);                      // ... those of the side stream
+int pomgpu_tp_side_ok(pomgpu_ctx *c);                                           // can rounds run on the side stream (second communicator / callback mover)?
+int pomgpu_tp_move_side(pomgpu_ctx *c, const size_t *scount, const size_t *rcount);   // send2 / recv2, on c->side
 // k_reduce.hip
 void launch_check_velocity(pomgpu_ctx *c);
 void launch_domain_stats(pomgpu_ctx *c, double *out_dev);

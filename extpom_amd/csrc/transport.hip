@@ -32,9 +32,10 @@ struct RcclApi {
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   const char *(*GetErrorString)(ncclResult_t);
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *);   // optional (RCCL >= 2.18): the side stream's communicator
 };
 static RcclApi g_rccl;
-struct RcclComm { ncclComm_t comm; int rank, nranks; };
+struct RcclComm { ncclComm_t comm, comm2; int rank, nranks; };
 
 static int rccl_load(const char *path) {
   if (g_rccl.lib) return 0;
@@ -57,6 +58,7 @@ static int rccl_load(const char *path) {
   SYM(Recv, "ncclRecv")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  *(void **)(&a.CommSplit) = dlsym(h, "ncclCommSplit");       // absent in old libraries: no side-stream rounds then
   g_rccl = a;
   return 0;
 }
@@ -67,6 +69,7 @@ void pomgpu_tp_free(pomgpu_ctx *c) {
 #ifndef POMGPU_EMU
   if (T.rccl) {
     RcclComm *r = (RcclComm *)T.rccl;
+    if (g_rccl.lib && r->comm2) (void)g_rccl.CommDestroy(r->comm2);
     if (g_rccl.lib && r->comm) (void)g_rccl.CommDestroy(r->comm);
     delete r;
     T.rccl = NULL;
@@ -75,6 +78,8 @@ void pomgpu_tp_free(pomgpu_ctx *c) {
   for (int d = 0; d < 8; d++) {
     (void)hipFree(T.send[d]); (void)hipFree(T.recv[d]);
     T.send[d] = T.recv[d] = NULL; T.cap[d] = 0;
+    (void)hipFree(T.send2[d]); (void)hipFree(T.recv2[d]);
+    T.send2[d] = T.recv2[d] = NULL; T.cap2[d] = 0;
   }
   T.on = 0;
 }
@@ -93,6 +98,66 @@ int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need) {
     T.cap[d] = need[d];
   }
   return POMGPU_OK;
+}
+
+int pomgpu_tp_reserve2(pomgpu_ctx *c, const size_t *need) {
+  pomgpu_transport &T = c->tp;
+  for (int d = 0; d < 8; d++) {
+    if (T.nbr[d] < 0 || need[d] <= T.cap2[d]) continue;
+    if (T.cap2[d] && c->side) (void)hipStreamSynchronize(c->side);
+    (void)hipFree(T.send2[d]); (void)hipFree(T.recv2[d]);
+    T.send2[d] = T.recv2[d] = NULL; T.cap2[d] = 0;
+    if (hipMalloc((void **)&T.send2[d], need[d] * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&T.recv2[d], need[d] * sizeof(double)) != hipSuccess)
+      return pomgpu_fail(c, POMGPU_ENOMEM, "transport: cannot allocate %zu-byte staging buffers (side stream)", need[d] * sizeof(double));
+    T.cap2[d] = need[d];
+  }
+  return POMGPU_OK;
+}
+// Rounds on the side stream need a communicator of their own (one communicator serves one stream at a time); a callback
+// mover (tests) is synchronous and can serve any stream.
+int pomgpu_tp_side_ok(pomgpu_ctx *c) {
+  pomgpu_transport &T = c->tp;
+  if (!T.on || !c->side) return 0;
+  if (T.fn) return 1;
+#ifndef POMGPU_EMU
+  RcclComm *r = (RcclComm *)T.rccl;
+  return r && r->comm2 != NULL;
+#else
+  return 0;
+#endif
+}
+// One message round on the SIDE stream: send2[d] -> neighbour d, recv2[d] <- neighbour d.  Every rank must issue its
+// side-stream rounds in the same order (they do: one early gather and one wr exchange per internal step).
+int pomgpu_tp_move_side(pomgpu_ctx *c, const size_t *scount, const size_t *rcount) {
+  pomgpu_transport &T = c->tp;
+  if (!pomgpu_tp_side_ok(c)) return pomgpu_fail(c, POMGPU_EINVAL, "transport: no side stream");
+  T.rounds_side++;
+  const int slot = c->prof_on ? pomgpu_prof_slot(c, "msg_round_side") : -1;
+  if (slot >= 0) pomgpu_prof_pre(c);                          // c->cur is the side stream here
+  if (T.fn) {                                                 // test movers work on the stream they know: hand the data over completed
+    (void)hipStreamSynchronize(c->side);
+    T.fn(T.user, T.send2, scount, T.recv2, rcount);
+    if (slot >= 0) pomgpu_prof_post(c, slot);
+    return POMGPU_OK;
+  }
+#ifndef POMGPU_EMU
+  RcclComm *r = (RcclComm *)T.rccl;
+  ncclResult_t e = g_rccl.GroupStart();
+  for (int d = 0; d < 8 && e == ncclSuccess; d++)
+    if (T.nbr[d] >= 0 && scount[d]) e = g_rccl.Send(T.send2[d], scount[d], ncclDouble, T.nbr[d], r->comm2, c->side);
+  for (int d = 0; d < 8 && e == ncclSuccess; d++) {
+    const int f = POMGPU_OPP[d];
+    if (T.nbr[f] >= 0 && rcount[f]) e = g_rccl.Recv(T.recv2[f], rcount[f], ncclDouble, T.nbr[f], r->comm2, c->side);
+  }
+  const ncclResult_t e2 = g_rccl.GroupEnd();
+  if (slot >= 0) pomgpu_prof_post(c, slot);
+  if (e == ncclSuccess) e = e2;
+  if (e != ncclSuccess) return pomgpu_fail(c, POMGPU_EHIP, "transport: RCCL round (side stream) failed: %s", g_rccl.GetErrorString(e));
+  return POMGPU_OK;
+#else
+  return pomgpu_fail(c, POMGPU_ENODEV, "transport: no mover in the host build");
+#endif
 }
 
 // One message round.  send[d] / recv[d]: device buffers (any, not only the staging buffers); counts in doubles.
@@ -182,10 +247,12 @@ int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8) {
   if (need[3] < ord[1]) need[3] = ord[1];
   T.on = 1;
   T.rounds = 0;
+  T.rounds_side = 0;
   return pomgpu_tp_reserve(c, need);
 }
 
 extern "C" long pomgpu_exchange_rounds(pomgpu_ctx *c) { return c ? c->tp.rounds : 0; }
+extern "C" long pomgpu_exchange_rounds_side(pomgpu_ctx *c) { return c ? c->tp.rounds_side : 0; }
 
 int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const char *librccl_path) {
 #ifndef POMGPU_EMU
@@ -194,11 +261,17 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   RcclComm *r = new RcclComm();
-  r->rank = rank; r->nranks = nranks; r->comm = NULL;
+  r->rank = rank; r->nranks = nranks; r->comm = NULL; r->comm2 = NULL;
   const ncclResult_t e = g_rccl.CommInitRank(&r->comm, nranks, id, rank);
   if (e != ncclSuccess) {
     delete r;
     return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: ncclCommInitRank: %s", g_rccl.GetErrorString(e));
+  }
+  // the side stream's communicator: the same ranks, split off the first (collective, like the init above).  Without
+  // ncclCommSplit the library keeps every round on the main stream.
+  if (g_rccl.CommSplit && !getenv("POMGPU_NO_SIDE_COMM")) {
+    const ncclResult_t e2 = g_rccl.CommSplit(r->comm, 0, rank, &r->comm2, NULL);
+    if (e2 != ncclSuccess) { r->comm2 = NULL; fprintf(stderr, "pomgpu: ncclCommSplit: %s -- message rounds stay on one stream\n", g_rccl.GetErrorString(e2)); }
   }
   c->tp.rccl = r;
   c->tp.fn = NULL;

@@ -69,6 +69,7 @@ _SIGS = {
     "pomgpu_rccl_unique_id": (_I, [_P, ctypes.c_char_p]),
     "pomgpu_rccl_init": (_I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.c_char_p]),
     "pomgpu_exchange_rounds": (ctypes.c_long, [_P]),
+    "pomgpu_exchange_rounds_side": (ctypes.c_long, [_P]),
     "pomgpu_set_wide_external": (_I, [_P, _I, _I, _I]),
     "pomgpu_halo_pack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),
     "pomgpu_halo_unpack": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, _I, _P, _P]),

@@ -145,6 +145,10 @@ class PomGpu:
     def exchange_rounds(self) -> int:
         return int(self.L.pomgpu_exchange_rounds(self.h))
 
+    def exchange_rounds_side(self) -> int:
+        """message rounds the library served on its second stream (beside kernels of the main stream)"""
+        return int(self.L.pomgpu_exchange_rounds_side(self.h))
+
     def set_wide_external(self, on: bool, min_im: int, min_jm: int) -> bool:
         """collective; False when the tiles are too narrow (the per-point exchanges stay in use)"""
         rc = self.L.pomgpu_set_wide_external(self.h, 1 if on else 0, int(min_im), int(min_jm))

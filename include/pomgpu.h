@@ -163,6 +163,8 @@ int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, c
                      const char *librccl_path);
 /* message rounds served by the transport since it was set (measurement) */
 long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
+/* ... of them on the library's second stream (the early part of the wide exchange, wr): beside kernels, not between them */
+long pomgpu_exchange_rounds_side(pomgpu_ctx *ctx);
 
 /* Wide-halo external mode (needs a transport).  It starts in pomgpu_mode_interaction and ends with the
  * pomgpu_mode_external call of the last substep (iext = isplit) -- the reference's own sequence in `advance`, and

@@ -49,22 +49,31 @@ def run(mover, wide):
         assert g.set_wide_external(True, IM, JM)
     g.run(STEPS)
     g.download()
-    n = g.exchange_rounds()
+    n, ns = g.exchange_rounds(), g.exchange_rounds_side()
     out = {f: st.field(f).copy() for f in BLK2D + BLK3D if f not in SCRATCH}
     err = int(st.error_status)
     g.close()
-    return out, n, err
+    return out, n, err, ns
 
 
 def main():
-    ref, n_ref, err = run("copy", False)
+    ref, n_ref, err, _ = run("copy", False)
     assert err == 0 and n_ref > 100, (err, n_ref)
     assert np.isfinite(ref["u"]).all() and np.abs(ref["u"]).max() > 0
-    for mover, wide in (("rccl", False), ("copy", True), ("rccl", True)):
-        got, n, err = run(mover, wide)
+    for mover, wide, overlap in (("rccl", False, True), ("copy", True, True), ("rccl", True, True), ("rccl", True, False)):
+        # overlap: the early part of the wide exchange and the wr round on the library's second stream, over the second
+        # (split) communicator -- two rounds per internal step beside the kernels; POMGPU_NO_OVERLAP keeps one stream
+        if overlap:
+            os.environ.pop("POMGPU_NO_OVERLAP", None)
+        else:
+            os.environ["POMGPU_NO_OVERLAP"] = "1"
+        got, n, err, ns = run(mover, wide)
+        os.environ.pop("POMGPU_NO_OVERLAP", None)
         bad = [f for f in ref if not np.array_equal(ref[f], got[f])]
         assert err == 0 and not bad, (mover, wide, err, bad[:10])
-        print(f"{mover} wide={wide}: {n} message rounds (per-point, copy mover: {n_ref}), fields identical")
+        assert ns == (2 * STEPS if wide and overlap else 0), (mover, wide, overlap, ns)
+        print(f"{mover} wide={wide} overlap={overlap}: {n} message rounds on the kernels' stream + {ns} on the side stream "
+              f"(per-point, copy mover: {n_ref}), fields identical")
     print("RCCL-SELF-OK")
 
 
