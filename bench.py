@@ -48,7 +48,7 @@ KERNEL_PASSES = {
     "k_advt2x2_col": 10,     # a13 for T and S together: R tb,tclim,sb,sclim,u,v,w,aam W uf,vf
     "k_advq_col": 7,         # a9, one tile: R q,qb,u,v,w,aam W qf
     "k_advt2_col": 7,        # a13: R fb,fclim,u,v,w,aam W ff
-    "k_ts_update": 19,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,6 restore fields W t,tb,s,sb,rho
+    "k_ts_update": 17,       # a15+restore_interior+a16: R uf,vf,t,tb,s,sb,tclim,sclim,4 restore fields (taurstrb/f are known scalars once the library has loaded a record) W t,tb,s,sb,rho
     "k_profq_prod": 9,       # R km,kh,t,s,rho,u,v (+1 k-shifted reuse counted once) W prod  -> 7R+1W (+1)
     "k_advq_flux": 7,        # a9 first half: R q,qb,u,v,aam W xflux,yflux
     "k_advq_step": 6,        # a9 second half: R q,qb,w,xflux,yflux W qf
