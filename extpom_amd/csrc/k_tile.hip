@@ -641,92 +641,138 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
 // (k_profuv_reg) then need only their right-hand side and km.  Column-marching, halo-lane wavefronts:
 // the level loop carries the vertical fluxes, the (i-1) / (i+1) operands are neighbour-lane values.
 // Columns outside the interior get the reference's left-over vertical flux (:744-751, :801-808).
-struct LevUV { double w_c, w_s, u_c, v_c, u_s, v_n, ub, vb, advx, advy, drhox, drhoy; };   // w, u_c, v_c at level k+1; the rest at k
+// Operands of iteration k.  Shared with the rows next to this one through the workgroup's LDS slabs: w, u, v of level
+// k+1 (c: own row, h: this wavefront's share of the two rows outside the workgroup); own row only, level k: ub, vb, advx,
+// advy, drhox, drhoy.  The row south of u and the row north of v are needed at level k -- one level behind what is being
+// parked -- so the slabs rotate through THREE buffers: level L lives in slab (L-1) % 3, iteration k fills the slab of
+// level k+1 and reads that of level k, and the slab it will overwrite two iterations later is out of everybody's reach
+// behind two barriers.  (PMC before: 14.8 array passes of HBM-side traffic for 11 algorithmic -- the three neighbour rows
+// were never L2 hits.)
+struct LevUV { double c[3], h[ROWSHARE_SLOTS(3)], ub, vb, advx, advy, drhox, drhoy; };
 // Same loop discipline as k_advt2_col: one batch of loads per level, issued a whole iteration ahead and never inside a
 // branch, stores of lanes without an output column aimed outside the buffer, buffer addressing, two register sets.
-__global__ void __launch_bounds__(64 * COL_ROWS * COL_WX) k_advuv_col(KP P) {
-  HALO_XCD_DECODE
-  if (j > P.jm) return;                                     // whole wavefront (one row)
-  const bool out = (lane >= 1 && lane <= 62 && i0 <= P.im);
+__global__ void __launch_bounds__(64 * LDS_ROWS) k_advuv_col(KP P) {
+  constexpr int NS = 3, NH = ROWSHARE_SLOTS(NS), W = 0, U = 1, V = 2;
+  HALO_XCD_DECODE_R(LDS_ROWS)
+  const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
+  const bool jvalid = j <= P.jm;                            // rows beyond the tile shadow row jm and store nothing
+  const int jc = j <= P.jml ? j : P.jml;
+  const bool out = jvalid && (lane >= 1 && lane <= 62 && i0 <= P.im);
 #ifdef POMGPU_EMU
   if (!out) return;
 #endif
   const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
   const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
-  const int js = j > 1 ? j - 1 : 1, jn = j < P.jml ? j + 1 : P.jml;
-  const bool in = out && (i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1);
+  const int js = jc > 1 ? jc - 1 : 1, jn = jc < P.jml ? jc + 1 : P.jml;
+  const bool in = out && (i >= 2 && i <= P.imm1 && jc >= 2 && jc <= P.jmm1);
   const int kb = P.kb, kbm1 = P.kbm1;
   // column-resident coefficients
-  const double aru = F2(aru, i, j), arv = F2(arv, i, j);
-  const double dt_c = F2(dt, i, j), dt_w = F2(dt, iw, j), dt_s = F2(dt, i, js);
-  const double cd_c = F2(cor, i, j) * dt_c, cd_s = F2(cor, i, js) * dt_s;                  // cor*dt of this column and of (i,j-1)
+  const double aru = F2(aru, i, jc), arv = F2(arv, i, jc);
+  const double dt_c = F2(dt, i, jc), dt_w = F2(dt, iw, jc), dt_s = F2(dt, i, js);
+  const double cd_c = F2(cor, i, jc) * dt_c, cd_s = F2(cor, i, js) * dt_s;                  // cor*dt of this column and of (i,j-1)
   const double hcu = P.grav * .125 * (dt_c + dt_w) *
-                     (F2(egf, i, j) - F2(egf, iw, j) + F2(egb, i, j) - F2(egb, iw, j) + (F2(e_atmos, i, j) - F2(e_atmos, iw, j)) * 2.) *
-                     (F2(dy, i, j) + F2(dy, iw, j));                                          // :765-770
+                     (F2(egf, i, jc) - F2(egf, iw, jc) + F2(egb, i, jc) - F2(egb, iw, jc) + (F2(e_atmos, i, jc) - F2(e_atmos, iw, jc)) * 2.) *
+                     (F2(dy, i, jc) + F2(dy, iw, jc));                                          // :765-770
   const double hcv = P.grav * .125 * (dt_c + dt_s) *
-                     (F2(egf, i, j) - F2(egf, i, js) + F2(egb, i, j) - F2(egb, i, js) + (F2(e_atmos, i, j) - F2(e_atmos, i, js)) * 2.) *
-                     (F2(dx, i, j) + F2(dx, i, js));                                          // :822-827
-  const double hb = F2(h, i, j) + F2(etb, i, j), hf = F2(h, i, j) + F2(etf, i, j);
-  const double sau = (hb + F2(h, iw, j) + F2(etb, iw, j)) * aru;                            // :758
+                     (F2(egf, i, jc) - F2(egf, i, js) + F2(egb, i, jc) - F2(egb, i, js) + (F2(e_atmos, i, jc) - F2(e_atmos, i, js)) * 2.) *
+                     (F2(dx, i, jc) + F2(dx, i, js));                                          // :822-827
+  const double hb = F2(h, i, jc) + F2(etb, i, jc), hf = F2(h, i, jc) + F2(etf, i, jc);
+  const double sau = (hb + F2(h, iw, jc) + F2(etb, iw, jc)) * aru;                            // :758
   const double sav = (hb + F2(h, i, js) + F2(etb, i, js)) * arv;                            // :815
-  const InvD sdu = inv_of((hf + F2(h, iw, j) + F2(etf, iw, j)) * aru), sdv = inv_of((hf + F2(h, i, js) + F2(etf, i, js)) * arv);   // :781, :838
-  const BufA bw = BUF3(A3(w)), bu = BUF3(A3(u)), bv = BUF3(A3(v)), bub = BUF3(A3(ub)), bvb = BUF3(A3(vb)), bax = BUF3(A3(advx)),
-             bay = BUF3(A3(advy)), bdx = BUF3(A3(drhox)), bdy = BUF3(A3(drhoy)), buf = BUF3(A3(uf)), bvf = BUF3(A3(vf));
-  const unsigned oc = BOFF2(i, j), os = BOFF2(i, js), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  const InvD sdu = inv_of((hf + F2(h, iw, jc) + F2(etf, iw, jc)) * aru), sdv = inv_of((hf + F2(h, i, js) + F2(etf, i, js)) * arv);   // :781, :838
+  BufA bs[NS], bh[NH];
+  const double *ps[NS] = {A3(w), A3(u), A3(v)};
+#pragma unroll
+  for (int x = 0; x < NS; x++) bs[x] = BUF3(ps[x]);
+  const BufA bub = BUF3(A3(ub)), bvb = BUF3(A3(vb)), bax = BUF3(A3(advx)), bay = BUF3(A3(advy)), bdx = BUF3(A3(drhox)), bdy = BUF3(A3(drhoy)),
+             buf = BUF3(A3(uf)), bvf = BUF3(A3(vf));
+  const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
+#pragma unroll
+  for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
+  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
   const unsigned ost = out ? oc : BOFF_NONE;
-  auto load = [&](LevUV &L, int k) {                        // operands of level k (w, u_c, v_c: level k+1)
+#ifndef POMGPU_EMU
+  __shared__ double slab[3][NS][ROWSHARE_ROWS][64];
+#else
+  const unsigned os = BOFF2(i, js), on = BOFF2(i, jn);
+#endif
+  auto load = [&](LevUV &L, int k) {                        // shared operands of level k+1, own-row operands of level k
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb, lv1 = lv + lvb;
-    L.w_c = bld(bw, oc, lv1); L.w_s = bld(bw, os, lv1); L.u_c = bld(bu, oc, lv1); L.v_c = bld(bv, oc, lv1);
-    L.u_s = bld(bu, os, lv);  L.v_n = bld(bv, on, lv);
+#pragma unroll
+    for (int x = 0; x < NS; x++) L.c[x] = bld(bs[x], oc, lv1);
+#pragma unroll
+    for (int q = 0; q < NH; q++) L.h[q] = bld(bh[q], S.hoff[q], lv1);
     L.ub = bld(bub, oc, lv);  L.vb = bld(bvb, oc, lv);
     L.advx = bld(bax, oc, lv); L.advy = bld(bay, oc, lv); L.drhox = bld(bdx, oc, lv); L.drhoy = bld(bdy, oc, lv);
   };
-  double u_k = F3(u, i, j, 1), v_k = F3(v, i, j, 1);       // u, v of this column at level k
+  auto park = [&](const double (&cv)[3], const double (&hv)[NH], const int sl) {
+#ifndef POMGPU_EMU
+#pragma unroll
+    for (int x = 0; x < NS; x++) slab[sl][x][r + 1][lane] = cv[x];
+#pragma unroll
+    for (int q = 0; q < NH; q++) slab[sl][S.hop[q]][S.hrow[q]][lane] = hv[q];
+#endif
+  };
+  // level 1 of u, v (and w, unused) into slab 0: what the first iteration reads as its "level k" neighbours
+  double u_k, v_k;                                          // u, v of this column at level k
+  {
+    double c1[3], h1[NH];
+#pragma unroll
+    for (int x = 0; x < NS; x++) c1[x] = bld(bs[x], oc, 0u);
+#pragma unroll
+    for (int q = 0; q < NH; q++) h1[q] = bld(bh[q], S.hoff[q], 0u);
+    park(c1, h1, 0);
+    u_k = c1[U]; v_k = c1[V];
+  }
   double fu_k = 0., fv_k = 0.;                              // vertical fluxes at level k (0 at the surface)
-#ifdef ADVUV_DZ_AHEAD
-  InvD dzn; dzn.b = F1(dz, 1); dzn.y = R1(dz, 1);
-#endif
-  auto step = [&](const int k, const LevUV &c, LevUV &nxt) {
+  auto step = [&](const int k, const int sl, const LevUV &c, LevUV &nxt) {   // sl = k % 3: the slab of level k+1
     load(nxt, k + 1 <= kbm1 ? k + 1 : kbm1);                // in flight during this iteration (the last one re-requests level kbm1)
-#ifdef ADVUV_DZ_AHEAD
-    const InvD dzk = dzn;
-    dzn.b = F1(dz, k + 1 <= kbm1 ? k + 1 : kbm1); dzn.y = R1(dz, k + 1 <= kbm1 ? k + 1 : kbm1);
+    park(c.c, c.h, sl);
+    const int slm = sl == 0 ? 2 : sl - 1;                   // the slab of level k
+#ifndef POMGPU_EMU
+    __syncthreads();
+    const double w_s = slab[sl][W][S.ss][lane], u_s = slab[slm][U][S.ss][lane], v_n = slab[slm][V][S.sn][lane];
+#else
+    const double w_s = bld(bs[W], os, (unsigned)k * lvb), u_s = bld(bs[U], os, (unsigned)(k - 1) * lvb), v_n = bld(bs[V], on, (unsigned)(k - 1) * lvb);
 #endif
-    const double w_w = halo_w(c.w_c, [&] { return F3(w, iw, j, k + 1); });
-    const double tc = cd_c * (c.v_n + v_k);                                                 // cor*dt*(v(i,j+1,k)+v(i,j,k))
-    const double tw = halo_w(tc, [&] { return F2(cor, iw, j) * F2(dt, iw, j) * (F3(v, iw, jn, k) + F3(v, iw, j, k)); });
-    const double u_e = halo_e(u_k, [&] { return F3(u, ie, j, k); });
-    const double u_se = halo_e(c.u_s, [&] { return F3(u, ie, js, k); });
+    const double w_c = c.c[W], u_c = c.c[U], v_c = c.c[V];  // level k+1
+    const double w_w = halo_w(w_c, [&] { return F3(w, iw, jc, k + 1); });
+    const double tc = cd_c * (v_n + v_k);                                                   // cor*dt*(v(i,j+1,k)+v(i,j,k))
+    const double tw = halo_w(tc, [&] { return F2(cor, iw, jc) * F2(dt, iw, jc) * (F3(v, iw, jn, k) + F3(v, iw, jc, k)); });
+    const double u_e = halo_e(u_k, [&] { return F3(u, ie, jc, k); });
+    const double u_se = halo_e(u_s, [&] { return F3(u, ie, js, k); });
     // vertical fluxes at level k+1 (:744-751, :801-808); zero below kbm1, and where the column has no west / south neighbour
     double fu_n = 0., fv_n = 0.;
     if (k + 1 <= kbm1) {
-      if (i >= 2) fu_n = .25 * (c.w_c + w_w) * (c.u_c + u_k);
-      if (j >= 2) fv_n = .25 * (c.w_c + c.w_s) * (c.v_c + v_k);
+      if (i >= 2) fu_n = .25 * (w_c + w_w) * (u_c + u_k);
+      if (jc >= 2) fv_n = .25 * (w_c + w_s) * (v_c + v_k);
     }
     double ru = fu_k, rv = fv_k;                                                            // outside the interior: the flux itself
     if (in) {
-#ifndef ADVUV_DZ_AHEAD
       InvD dzk; dzk.b = F1(dz, k); dzk.y = R1(dz, k);
-#endif
       ru = divi(sau * c.ub - 2. * P.dti2 * (c.advx + divi((fu_k - fu_n) * aru, dzk) - aru * .25 * (tc + tw) + hcu + c.drhox), sdu);   // :758-782
       rv = divi(sav * c.vb -
-                    2. * P.dti2 * (c.advy + divi((fv_k - fv_n) * arv, dzk) + arv * .25 * (cd_c * (u_e + u_k) + cd_s * (u_se + c.u_s)) + hcv + c.drhoy),
+                    2. * P.dti2 * (c.advy + divi((fv_k - fv_n) * arv, dzk) + arv * .25 * (cd_c * (u_e + u_k) + cd_s * (u_se + u_s)) + hcv + c.drhoy),
                 sdv);                                                                       // :815-839
     }
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
     bst(buf, ost, lv, ru);
     bst(bvf, ost, lv, rv);
     fu_k = fu_n; fv_k = fv_n;
-    u_k = c.u_c; v_k = c.v_c;
+    u_k = u_c; v_k = v_c;
   };
   LevUV ra, rb;
   load(ra, 1);
   rb = ra;
-  for (int k = 1; k <= kbm1; k += 2) {
-    step(k, ra, rb);
-    if (k + 1 <= kbm1) step(k + 1, rb, ra);
+  for (int k = 1; k <= kbm1; k += 6) {                      // six iterations: two register sets x three slabs
+    step(k, 1, ra, rb);
+    if (k + 1 <= kbm1) step(k + 1, 2, rb, ra);
+    if (k + 2 <= kbm1) step(k + 2, 0, ra, rb);
+    if (k + 3 <= kbm1) step(k + 3, 1, rb, ra);
+    if (k + 4 <= kbm1) step(k + 4, 2, ra, rb);
+    if (k + 5 <= kbm1) step(k + 5, 0, rb, ra);
   }
-  if (out) { F3(uf, i, j, kb) = 0.; F3(vf, i, j, kb) = 0.; }
+  if (out) { F3(uf, i, jc, kb) = 0.; F3(vf, i, jc, kb) = 0.; }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -776,7 +822,7 @@ void launch_advct_fix(pomgpu_ctx *c, const double *from_w, const double *from_s)
   const int len = P.im > P.jm ? P.im : P.jm;
   LAUNCH(c, k_advct_fix, dim3((len + 63) / 64, P.kbm1, 1), dim3(64, 1, 1), c->P, from_w, from_s);
 }
-void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo(c->P), blk_col(), c->P); }
+void launch_advuv_col(pomgpu_ctx *c) { LAUNCH(c, k_advuv_col, grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P); }
 void launch_advt2_rows(pomgpu_ctx *c, const double *fb, const double *f, const double *fc, double *ff) {
   {
     TFields A; A.fb[0] = A.fb[1] = fb; A.f[0] = A.f[1] = f; A.fcl[0] = A.fcl[1] = fc; A.ff[0] = A.ff[1] = ff;
