@@ -97,12 +97,12 @@ def build_state(workload, tile):
     return make_case(case, im, jm, kb, tile=tile, **NML)
 
 
-def gpu_initialise(st, device, stream):
+def gpu_initialise(st, device, stream, libpath=None):
     """the reference's initialisation tail (dens, baropg, bottom friction ...) with the HIP kernels"""
     from extpom_amd.cases import finish_initial
     from extpom_amd.layout import P3
     from extpom_amd.model import PomGpu
-    g = PomGpu(st, device=device, stream=stream)
+    g = PomGpu(st, device=device, stream=stream, libpath=libpath)
     P = lambda a: __import__("ctypes").c_void_p(a.ctypes.data)
 
     def dens(s, si, ti, rho):
@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--reference", action="store_true", help="internal: with --cpu-sample, time oracle/_ref instead of the oracle")
     ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle sample and print it (no GPU)")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
+    ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
+                    help="f32: BASELINE configs[4]'s STUDY variant (libpomgpu_f32.so: 3-D arrays stored as fp32, arithmetic and the external "
+                         "mode fp64; one GPU).  Not a parity path (DESIGN.md section 8) and never the headline: the line says so in `dtype`")
     args = ap.parse_args()
     if args.cpu_sample:
         v, what, n, dt = _reference_sample(args.workload) if args.reference else _cpu_sample(args.workload)
@@ -298,7 +301,12 @@ def main():
         ts = torch.cuda.Stream()
         torch.cuda.set_stream(ts)
         stream = ts.cuda_stream
-    g = gpu_initialise(st, local, stream)
+    f32 = args.storage == "f32"
+    if f32 and world > 1:
+        print("bench: --storage f32 is a one-GPU study (the fp32-storage variant has no tile exchange)", file=sys.stderr)
+        sys.exit(2)
+    from extpom_amd import lib as _L
+    g = gpu_initialise(st, local, stream, _L.LIBPATH_F32 if f32 else None)
     exchange = "none"
     # N > 1: a rank that is lost, or a message round whose partner never posts, would leave the others waiting inside
     # RCCL for ever.  Every phase -- connecting, the first steps (RCCL sets its channels up lazily), the timed steps --
@@ -397,15 +405,15 @@ def main():
         passes = KERNEL_PASSES.get(dom + "/tiles" if split else dom)
         roof = None
         if nl and passes:
-            ach = passes * 8.0 * tile_cells / (tms / nl * 1e-3) / 1e9
+            ach = passes * (4.0 if f32 else 8.0) * tile_cells / (tms / nl * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and not f32:
                 rec = json.load(open(tf)).get(f"{args.workload}/{world}/{dom}")
                 traffic = rec["bytes_per_launch"] if rec else None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(ach / HBM_COPY_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": passes * 8 * tile_cells, "launches": nl,
+                    "algorithmic_bytes_per_launch": passes * (4 if f32 else 8) * tile_cells, "launches": nl,
                     "avg_launch_ms": round(tms / nl, 4)}
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
         ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
@@ -413,13 +421,15 @@ def main():
         msg_side_ms = prof.pop("msg_round_side", (0, 0.0))[1] # ... those on the library's second stream: beside kernels, not between them
         int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
         ext_ms = sum(v[1] for k, v in prof.items() if k.startswith(ext))
-        step_gbs = P_STEP * 8.0 * cells / (dt / args.steps) / 1e9
+        BPV = 4.0 if f32 else 8.0                              # bytes per stored 3-D value
+        step_gbs = P_STEP * BPV * cells / (dt / args.steps) / 1e9
         share = sorted(((k, v[1]) for k, v in prof.items()), key=lambda kv: -kv[1])
         tot = sum(v for _, v in share) or 1.0
         out = {
             "metric": "3D cell-updates/sec (whole internal step incl. the isplit external substeps)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32-storage of the 3-D arrays / f64 arithmetic and external mode (STUDY variant, not a parity path)" if f32 else "f64",
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
@@ -429,9 +439,9 @@ def main():
             "step_algorithmic_GBps": round(step_gbs, 1), "step_frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4),
             "step_frac_of_measured_copy_ceiling": round(step_gbs / HBM_COPY_GBS, 4),
             "internal_mode": {"device_ms_per_step": round(int_ms, 3), "cell_updates_per_s": (tile_cells / (int_ms * 1e-3)) if int_ms else None,
-                              "algorithmic_GBps": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
-                              "frac_of_peak": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if int_ms else None,
-                              "frac_of_measured_copy_ceiling": round(P_STEP * 8.0 * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if int_ms else None,
+                              "algorithmic_GBps": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
+                              "frac_of_peak": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if int_ms else None,
+                              "frac_of_measured_copy_ceiling": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if int_ms else None,
                               "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
             "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
             # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what

@@ -133,6 +133,9 @@ static void stats_for_file(pomgpu_ctx *c, const pomgpu_file_meta *m, double *s8)
 }
 
 extern "C" int pomgpu_write_output(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m) {   // io_pnetcdf.F:57-410
+#ifdef POMGPU_STORE_F32
+  if (c) return pomgpu_fail(c, POMGPU_EINVAL, "write_output: not in the fp32-storage variant (download and write from the host)");
+#endif
   if (!c || !path || !m) return POMGPU_EINVAL;
   (void)hipSetDevice(c->device);
   const KP &P = c->P;
@@ -181,6 +184,9 @@ extern "C" int pomgpu_write_output(pomgpu_ctx *c, const char *path, const pomgpu
 }
 
 extern "C" int pomgpu_write_restart(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m) {   // io_pnetcdf.F:1661-2083
+#ifdef POMGPU_STORE_F32
+  if (c) return pomgpu_fail(c, POMGPU_EINVAL, "write_restart: not in the fp32-storage variant (download and write from the host)");
+#endif
   if (!c || !path || !m) return POMGPU_EINVAL;
   (void)hipSetDevice(c->device);
   const KP &P = c->P;

@@ -800,7 +800,12 @@ void launch_advct_b(pomgpu_ctx *c) { LAUNCH(c, k_advct_b, gridm(c->P), blk2(), c
 void launch_advct_c(pomgpu_ctx *c) { LAUNCH(c, k_advct_c, gridm(c->P), blk2(), c->P); }
 void launch_aam(pomgpu_ctx *c) {
   const KP &P = c->P;
-  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
+#ifdef POMGPU_STORE_F32
+  const bool pair_ok = false;                                 // k_aam_pair reads u, v as pairs of doubles
+#else
+  const bool pair_ok = true;
+#endif
+  if (pair_ok && P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
     const long nbands = (P.jml + P.g_rb - 1) / P.g_rb, rounds = (nbands + 7) / 8;
     const long bpl = (long)((P.iml / 2 + 61) / 62) * (P.g_rb / 4);
     LAUNCHN(c, "k_aam_pair", k_aam_pair, dim3((unsigned)(8 * rounds * P.kb * bpl), 1, 1), blk2(), c->P);

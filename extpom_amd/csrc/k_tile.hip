@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advt2_col(KP P, TFields A) {
   const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
 #pragma unroll
   for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
-  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
   const unsigned ost = in ? oc : BOFF_NONE;
 #ifndef POMGPU_EMU
   __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advq_col(KP P, QFields A, int
   const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
 #pragma unroll
   for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
-  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
   // interior columns get the new value, every other owned column a zero (zero_else) or nothing
   const unsigned ost = in ? oc : ((zero_else && icol) ? oc : BOFF_NONE);
 #ifndef POMGPU_EMU
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
   const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
 #pragma unroll
   for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
-  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
   const unsigned ost = (out && jrow) ? oc : BOFF_NONE;      // rim rows are zeroed after the loop
 #ifndef POMGPU_EMU
   __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advuv_col(KP P) {
   const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
 #pragma unroll
   for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
-  const unsigned oc = BOFF2(i, jc), lvb = (unsigned)(P.n2 * 8);
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
   const unsigned ost = out ? oc : BOFF_NONE;
 #ifndef POMGPU_EMU
   __shared__ double slab[3][NS][ROWSHARE_ROWS][64];

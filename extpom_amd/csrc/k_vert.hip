@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int rho_rt) {
 #define bpr BUF3(P.s3[0])
 #define be1 BUF3(P.s3[4])
 #define be2 BUF3(P.s3[5])
-  const unsigned oc = BOFF2(i, j), oe = BOFF2(ie, j), on = BOFF2(i, jn), lvb = (unsigned)(P.n2 * 8);
+  const unsigned oc = BOFF2(i, j), oe = BOFF2(ie, j), on = BOFF2(i, jn), lvb = LVB;
   const unsigned o_k = repl ? BOFF_NONE : oc;               // new km, kh, kq: not on physical-edge columns
   const unsigned o_abs = ffil ? BOFF_NONE : oc;             // |q2b|, |q2lb| on the way down: rewritten on the way up where the filter is fused
   const unsigned o_fil = ffil ? oc : BOFF_NONE, o_uv = ffil ? BOFF_NONE : oc;
@@ -965,9 +965,9 @@ __global__ void __launch_bounds__(128) k_profuv_reg(KP P) {
   // per-level accesses as (uniform plane pointer)[32-bit column offset]: the plane pointer is scalar, so
   // the ~2*KBT loads of phase A share ONE offset register instead of holding a 64-bit address each
   // (32-bit BYTE offsets: the form the compiler maps onto the scalar-base + vector-offset addressing mode)
-  const unsigned col = 8u * (unsigned)((j - 1) * P.iml + (i - 1)), col2 = 8u * (unsigned)((js - 1) * P.iml + (i - 1));
+  const unsigned col = POMGPU_ST_BYTES * (unsigned)((j - 1) * P.iml + (i - 1)), col2 = POMGPU_ST_BYTES * (unsigned)((js - 1) * P.iml + (i - 1));
   const double *kmp = P.b3 + (size_t)P3_km * P.a3;
-#define PLANE(ptr, k, off) (*(double *)((char *)((ptr) + (size_t)((k)-1) * P.n2) + (off)))
+#define PLANE(ptr, k, off) REF3((pomgpu_st *)((char *)((pomgpu_st *)(ptr) + (size_t)((k)-1) * P.n2) + (off)), 0)
   const int kb = P.kb, kbm1 = P.kbm1, kbm2 = P.kbm2;
   double ee[KBT], gg[KBT];
 #define KC(k) ((k) < kbm1 ? (k) : kbm1)

@@ -142,7 +142,48 @@ static void sync_scalars(pomgpu_ctx *c) {
 }
 
 // ---- life cycle -------------------------------------------------------------------------------
-extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.1 (gfx950)"; }
+#ifdef POMGPU_STORE_F32
+extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.2 (gfx950) fp32-storage variant"; }
+#define F32_REFUSE(c, what) return fail(c, POMGPU_EINVAL, what ": not in the fp32-storage variant (3-D arrays are not doubles there)")
+#else
+extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.2 (gfx950)"; }
+#define F32_REFUSE(c, what)
+#endif
+// host <-> device copies of one 3-D array.  fp64 (the product): a plain copy.  fp32-storage variant: through a staging
+// array of doubles (a scratch slot: n3 * 8 bytes) and a conversion kernel, so that the C ABI moves doubles either way.
+#ifdef POMGPU_STORE_F32
+__global__ void k_cvt_to_st(pomgpu_st *dst, const double *src, size_t n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = (pomgpu_st)src[t];
+}
+__global__ void k_cvt_from_st(double *dst, const pomgpu_st *src, size_t n) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = (double)src[t];
+}
+#endif
+static int copy3_h2d(pomgpu_ctx *c, double *slot, const double *host) {
+  const size_t n3 = c->P.n3;
+#ifdef POMGPU_STORE_F32
+  double *stage = c->P.s3[POMGPU_NSCR3 - 1];
+  HIPCHK(c, hipMemcpyAsync(stage, host, sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_cvt_to_st, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, c->stream, (pomgpu_st *)slot, (const double *)stage, n3);
+#else
+  HIPCHK(c, hipMemcpyAsync(slot, host, sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+#endif
+  return POMGPU_OK;
+}
+static int copy3_d2h(pomgpu_ctx *c, double *host, const double *slot) {
+  const size_t n3 = c->P.n3;
+#ifdef POMGPU_STORE_F32
+  double *stage = c->P.s3[POMGPU_NSCR3 - 1];
+  hipLaunchKernelGGL(k_cvt_from_st, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, c->stream, stage, (const pomgpu_st *)slot, n3);
+  HIPCHK(c, hipMemcpyAsync(host, stage, sizeof(double) * n3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));                 // the staging array is reused by the next copy
+#else
+  HIPCHK(c, hipMemcpyAsync(host, slot, sizeof(double) * n3, hipMemcpyDeviceToHost, c->stream));
+#endif
+  return POMGPU_OK;
+}
 
 // ---- the two generations of ua, va, d, el, elb (fused external step, k_ext.hip) -------------------
 // ext_parity == 0: the current generation is in the blk2d arrays; == 1: in alt2.  KP.x2 (read) and
@@ -370,9 +411,17 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
   if (b3) {
     c->tau_known[0] = c->tau_known[1] = 0;                      // taurstrb, taurstrf are the caller's now
+#ifndef POMGPU_STORE_F32
     if (P.a3 == P.n3) HIPCHK(c, hipMemcpyAsync(P.b3, b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyHostToDevice, c->stream));
-    else for (int n = 0; n < POM_NBLK3D; n++)
-      HIPCHK(c, hipMemcpyAsync(SLOT3(c, n), b3 + (size_t)n * P.n3, sizeof(double) * P.n3, hipMemcpyHostToDevice, c->stream));
+    else
+#endif
+    for (int n = 0; n < POM_NBLK3D; n++) {
+      const int rc3 = copy3_h2d(c, SLOT3(c, n), b3 + (size_t)n * P.n3);
+      if (rc3) return rc3;
+#ifdef POMGPU_STORE_F32
+      HIPCHK(c, hipStreamSynchronize(c->stream));             // one staging array
+#endif
+    }
   }
   if (bd) {
     const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
@@ -395,9 +444,14 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
   if (b1) HIPCHK(c, hipMemcpyAsync(b1, P.b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyDeviceToHost, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(b2, P.b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyDeviceToHost, c->stream));
   if (b3) {
+#ifndef POMGPU_STORE_F32
     if (P.a3 == P.n3) HIPCHK(c, hipMemcpyAsync(b3, P.b3, sizeof(double) * POM_NBLK3D * P.n3, hipMemcpyDeviceToHost, c->stream));
-    else for (int n = 0; n < POM_NBLK3D; n++)
-      HIPCHK(c, hipMemcpyAsync(b3 + (size_t)n * P.n3, SLOT3(c, n), sizeof(double) * P.n3, hipMemcpyDeviceToHost, c->stream));
+    else
+#endif
+    for (int n = 0; n < POM_NBLK3D; n++) {
+      const int rc3 = copy3_d2h(c, b3 + (size_t)n * P.n3, SLOT3(c, n));
+      if (rc3) return rc3;
+    }
   }
   if (bd) {
     const size_t nbd = P.bdoff[PB__count - 1] + (size_t)P.iml * P.kb;
@@ -430,7 +484,7 @@ extern "C" int pomgpu_upload_3d(pomgpu_ctx *c, int s, const double *h) {
   SLOTCHK(c, s, POM_NBLK3D);
   if (s == P3_taurstrb) c->tau_known[0] = 0;
   if (s == P3_taurstrf) c->tau_known[1] = 0;
-  HIPCHK(c, hipMemcpyAsync(SLOT3(c, s), h, sizeof(double) * c->P.n3, hipMemcpyHostToDevice, c->stream));
+  { const int rc3 = copy3_h2d(c, SLOT3(c, s), h); if (rc3) return rc3; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return POMGPU_OK;
 }
@@ -442,7 +496,7 @@ extern "C" int pomgpu_download_2d(pomgpu_ctx *c, int s, double *h) {
 }
 extern "C" int pomgpu_download_3d(pomgpu_ctx *c, int s, double *h) {
   SLOTCHK(c, s, POM_NBLK3D);
-  HIPCHK(c, hipMemcpyAsync(h, SLOT3(c, s), sizeof(double) * c->P.n3, hipMemcpyDeviceToHost, c->stream));
+  { const int rc3 = copy3_d2h(c, h, SLOT3(c, s)); if (rc3) return rc3; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return POMGPU_OK;
 }
@@ -475,6 +529,7 @@ extern "C" int pomgpu_set_restore_record(pomgpu_ctx *c, int n, const double *tr,
   return POMGPU_OK;
 }
 extern "C" int pomgpu_set_exchange(pomgpu_ctx *c, pomgpu_exchange_fn fn, void *user) {
+  if (c && fn) { F32_REFUSE(c, "set_exchange"); }
   if (!c) return POMGPU_EINVAL;
   c->exch = fn;
   c->exch_user = user;
@@ -831,6 +886,7 @@ static int tp_install(pomgpu_ctx *c, const int *nbr8) {
 }
 extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_transport_fn fn, void *user) {
   NEED_HOT(c);
+  if (fn) { F32_REFUSE(c, "set_transport"); }
   wide_free(c);
   pomgpu_tp_free(c);
   if (!fn) {                                                  // no mover: back to the hooks / a single tile
@@ -842,6 +898,7 @@ extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_trans
 }
 extern "C" int pomgpu_rccl_init(pomgpu_ctx *c, const void *id128, int rank, int nranks, const int *nbr8, const char *librccl_path) {
   NEED_HOT(c);
+  F32_REFUSE(c, "rccl_init");
   wide_free(c);
   pomgpu_tp_free(c);
   int rc = pomgpu_tp_rccl(c, id128, rank, nranks, librccl_path);

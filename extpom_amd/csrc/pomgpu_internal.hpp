@@ -54,6 +54,33 @@ struct KP {
 };
 enum pomgpu_x2 { X2_ua, X2_va, X2_d, X2_el, X2_elb, X2_uab, X2_vab };
 
+// ---- storage type of the 3-D arrays -----------------------------------------------------------------------------------
+// The product (libpomgpu.so) keeps every array in fp64, like the reference.  -DPOMGPU_STORE_F32 builds the variant of
+// BASELINE configs[4] ("fp32 internal mode / fp64 external mode"): the arrays of blk3d and the 3-D scratch arrays are
+// STORED as fp32 (half the bytes of the HBM-bound internal mode), every value is widened to fp64 on load and rounded on
+// store, all arithmetic -- the Thomas solves, the vertical integrals, the whole 2-D external mode with its arrays -- stays
+// fp64.  Same sources: the accessors below hand out proxies instead of references, the buffer helpers move 4 bytes per
+// element, upload / download convert.  Array k of blk3d still starts k * a3 * 8 bytes into the block (it fills the first
+// half of its slot), so every `double *` that names a 3-D array keeps its meaning as a handle.  Not in this variant:
+// tiles / transports, the output writer, the two-columns-per-lane aam kernel (they index 3-D arrays as raw doubles).
+#ifdef POMGPU_STORE_F32
+typedef float pomgpu_st;
+#else
+typedef double pomgpu_st;
+#endif
+#define POMGPU_ST_BYTES ((unsigned)sizeof(pomgpu_st))
+#ifdef POMGPU_STORE_F32
+struct Ref3 {
+  pomgpu_st *p;
+  __device__ __forceinline__ operator double() const { return (double)*p; }
+  __device__ __forceinline__ const Ref3 &operator=(double v) const { *p = (pomgpu_st)v; return *this; }
+  __device__ __forceinline__ const Ref3 &operator=(const Ref3 &o) const { *p = *o.p; return *this; }
+};
+#define REF3(ptr, idx) (Ref3{(pomgpu_st *)(ptr) + (idx)})
+#else
+#define REF3(ptr, idx) ((ptr)[(idx)])
+#endif
+
 // ---- Fortran-style accessors (1-based), `P` is the KP in scope ------------------------------
 #define IX2(i, j) ((size_t)((j)-1) * (size_t)P.iml + (size_t)((i)-1))
 #define IX3(i, j, k) ((size_t)((k)-1) * P.n2 + IX2(i, j))
@@ -72,10 +99,10 @@ typedef const double __attribute__((address_space(4))) *pomgpu_cptr;
 #define R1(name, k) P.r1[(size_t)P1_##name * P.kb + ((k)-1)]
 #endif
 #define F2(name, i, j) P.b2[(size_t)P2_##name * P.n2 + IX2(i, j)]
-#define F3(name, i, j, k) P.b3[(size_t)P3_##name * P.a3 + IX3(i, j, k)]
+#define F3(name, i, j, k) REF3(P.b3 + (size_t)P3_##name * P.a3, IX3(i, j, k))
 #define A2(name) (P.b2 + (size_t)P2_##name * P.n2)
 #define A3(name) (P.b3 + (size_t)P3_##name * P.a3)
-#define G3(p, i, j, k) (p)[IX3(i, j, k)]
+#define G3(p, i, j, k) REF3(p, IX3(i, j, k))
 #define G2(p, i, j) (p)[IX2(i, j)]
 
 enum pom_bdry_slot_dev {
@@ -181,9 +208,10 @@ typedef unsigned int pomgpu_u32x2 __attribute__((ext_vector_type(2)));
 struct BufA { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ BufA buf_of(const double *p, size_t doubles) {
   BufA b;
-  b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (unsigned)(doubles * 8), 0x00020000);   // raw buffer, no swizzle
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (unsigned)(doubles * POMGPU_ST_BYTES), 0x00020000);   // raw buffer, no swizzle
   return b;
 }
+#ifndef POMGPU_STORE_F32
 __device__ __forceinline__ double bld(const BufA &b, unsigned voff, unsigned soff) {
   const pomgpu_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
   return __hiloint2double((int)v.y, (int)v.x);
@@ -193,6 +221,14 @@ __device__ __forceinline__ void bst(const BufA &b, unsigned voff, unsigned soff,
   v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
   __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
 }
+#else
+__device__ __forceinline__ double bld(const BufA &b, unsigned voff, unsigned soff) {
+  return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst(const BufA &b, unsigned voff, unsigned soff, double x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)x), b.r, (int)voff, (int)soff, 0);
+}
+#endif
 #else
 struct BufA { double *p; };
 static inline BufA buf_of(const double *p, size_t) { BufA b; b.p = (double *)p; return b; }
@@ -205,7 +241,8 @@ static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { 
 // for vmcnt(0), i.e. for the prefetch batch that was just issued.
 #define BOFF_NONE 0xFFFFFFF0u
 #define BUF3(p) buf_of((p), P.n3)
-#define BOFF2(i, j) (unsigned)(((unsigned)((j)-1) * (unsigned)P.iml + (unsigned)((i)-1)) * 8u)   /* byte offset of (i,j) inside a level */
+#define BOFF2(i, j) (unsigned)(((unsigned)((j)-1) * (unsigned)P.iml + (unsigned)((i)-1)) * POMGPU_ST_BYTES)   /* byte offset of (i,j) inside a level */
+#define LVB (unsigned)(P.n2 * POMGPU_ST_BYTES)                                              /* byte distance between two levels */
 
 // ---- rows of a workgroup shared through LDS ---------------------------------------------------------------------------
 // A column kernel with a j-stencil needs every such operand of rows j-1, j, j+1.  Loaded per wavefront (one row each)

@@ -10,6 +10,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, "csrc", "libpomgpu.so")
+# the study variant of BASELINE configs[4]: 3-D arrays stored as fp32, arithmetic and the 2-D external mode fp64
+# (same sources, -DPOMGPU_STORE_F32); never the default, never loaded unless asked for by path
+LIBPATH_F32 = os.path.join(HERE, "csrc", "libpomgpu_f32.so")
 
 
 class PomGpuError(RuntimeError):

@@ -79,6 +79,12 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in pomgpu.h but not exported"
     from extpom_amd import lib as binding
     assert set(binding.EXPORTS) <= set(declared)
+    # the fp32-storage study variant (BASELINE configs[4], same sources with -DPOMGPU_STORE_F32) exports the same C ABI
+    lib32 = ctypes.CDLL(ge.build_hip(f32=True))
+    for name in declared:
+        assert hasattr(lib32, name), f"{name} missing from libpomgpu_f32.so"
+    lib32.pomgpu_version.restype = lib.pomgpu_version.restype = ctypes.c_char_p
+    assert b"fp32-storage" in lib32.pomgpu_version() and b"fp32" not in lib.pomgpu_version()
     # no device here: context creation must refuse, not fall back
     from extpom_amd.lib import Dims
     h = ctypes.c_void_p()
