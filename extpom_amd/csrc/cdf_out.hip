@@ -17,6 +17,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#ifndef POMGPU_EMU
+#include <thread>
+#endif
 
 #include "pomgpu.h"
 #include "pomgpu_internal.hpp"
@@ -84,16 +87,94 @@ int write_be(int fd, const double *x, size_t n, uint64_t off, std::vector<uint64
 }
 }  // namespace
 
+// Writing a file does not hold the model up ("async D2H on a copy stream").  The call (i) lays the file out
+// (header, full length) at once, so that other ranks may open it after the caller's barrier, (ii) takes a SNAPSHOT of
+// every array the file holds with device-to-device copies on the kernels' stream (a few ms at HBM speed; the model may
+// overwrite the arrays right after), records an event and returns; (iii) a host thread waits for that event on a copy
+// stream of its own, brings the snapshot over through a pinned buffer, swaps bytes and pwrites.  pomgpu_io_wait() joins
+// it (also called by pomgpu_sync, the next write and pomgpu_destroy) and reports its I/O status.  POMGPU_IO_SYNC=1, a
+// snapshot that does not fit, and the host emulation keep the old synchronous path.
+struct IoJob {
+  Spec S;
+  std::string path;
+  int fd = -1, im = 0, jm = 0, iml = 0, jml = 0, kb = 0, i0 = 1, j0 = 1, im_global = 0, jm_global = 0, create = 0, device = 0;
+  size_t n2 = 0;
+  double *snap = NULL;                 // device: the snapshot, variables back to back in the order of S.vars
+  std::vector<double> b1;              // blk1d (host copy taken at the call)
+#ifndef POMGPU_EMU
+  std::thread th;
+  hipEvent_t ev = NULL;
+  hipStream_t st = NULL;
+#endif
+  int rc = 0, active = 0;
+};
+static size_t var_doubles(const IoJob &J, const Var &v) { return v.src == PLANE2D ? J.n2 : (v.src == VOLUME3D ? (size_t)v.nlev * J.n2 : 0); }
+// rows of one variable (host copy `host`, leading dimensions iml x jml) into the file
+static int put_var(const IoJob &J, const Var &v, const double *host, std::vector<uint64_t> &tmp) {
+  const int nlev = v.src == PLANE2D ? 1 : v.nlev;
+  int bad = 0;
+  for (int k = 0; k < nlev && !bad; k++)
+    for (int j = 0; j < J.jm && !bad; j++) {
+      const uint64_t cell = ((uint64_t)k * J.jm_global + (uint64_t)(J.j0 - 1 + j)) * J.im_global + (uint64_t)(J.i0 - 1);
+      bad |= write_be(J.fd, host + ((size_t)k * J.jml + j) * J.iml, (size_t)J.im, v.begin + cell * 8, tmp);
+    }
+  return bad;
+}
+#ifndef POMGPU_EMU
+static void io_worker(IoJob *J) {
+  (void)hipSetDevice(J->device);
+  int bad = 0;
+  size_t big = 0;
+  for (const Var &v : J->S.vars) { const size_t n = var_doubles(*J, v); if (n > big) big = n; }
+  double *pin = NULL;
+  if (big && hipHostMalloc((void **)&pin, big * sizeof(double), hipHostMallocDefault) != hipSuccess) bad = 1;
+  if (!bad && hipStreamWaitEvent(J->st, J->ev, 0) != hipSuccess) bad = 1;
+  std::vector<uint64_t> tmp;
+  size_t off = 0;
+  for (const Var &v : J->S.vars) {
+    const size_t n = var_doubles(*J, v);
+    if (!n) continue;
+    if (!bad && (hipMemcpyAsync(pin, J->snap + off, n * sizeof(double), hipMemcpyDeviceToHost, J->st) != hipSuccess ||
+                 hipStreamSynchronize(J->st) != hipSuccess)) bad = 1;
+    if (!bad) bad |= put_var(*J, v, pin, tmp);
+    off += n;
+  }
+  if (pin) (void)hipHostFree(pin);
+  if (close(J->fd)) bad = 1;
+  J->fd = -1;
+  J->rc = bad;
+}
+#endif
+extern "C" int pomgpu_io_wait(pomgpu_ctx *c) {
+  if (!c) return POMGPU_EINVAL;
+  IoJob *J = (IoJob *)c->io_job;
+  if (!J) return POMGPU_OK;
+  int rc = POMGPU_OK;
+#ifndef POMGPU_EMU
+  if (J->active) {
+    J->th.join();
+    if (J->rc) rc = fail(c, POMGPU_EINVAL, "write: I/O error on %s", J->path.c_str());
+  }
+  (void)hipFree(J->snap);
+  if (J->ev) (void)hipEventDestroy(J->ev);
+  if (J->st) (void)hipStreamDestroy(J->st);
+#endif
+  delete J;
+  c->io_job = NULL;
+  return rc;
+}
+
 static int write_file(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m, Spec &S) {
   const KP &P = c->P;
   if (m->i0 < 1 || m->j0 < 1 || m->i0 + P.im - 1 > m->im_global || m->j0 + P.jm - 1 > m->jm_global)
     return fail(c, POMGPU_EINVAL, "write: the tile (%d..%d, %d..%d) does not fit the global grid %d x %d", m->i0, m->i0 + P.im - 1, m->j0,
                 m->j0 + P.jm - 1, m->im_global, m->jm_global);
+  { const int rcw = pomgpu_io_wait(c); if (rcw) return rcw; }  // one file in flight at a time
   const std::string h = header(S);
   const int fd = open(path, m->create ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
   if (fd < 0) return fail(c, POMGPU_EINVAL, "write: cannot open %s", path);
   std::vector<uint64_t> tmp;
-  std::vector<double> host, row;
+  std::vector<double> host;
   int bad = 0;
   if (m->create) {
     size_t left = h.size(); const char *p = h.data(); off_t off = 0;
@@ -101,30 +182,59 @@ static int write_file(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m
     const Var &last = S.vars.back();                                   // full length even where no tile has written yet
     if (!bad && ftruncate(fd, (off_t)(last.begin + var_bytes(S, last)))) bad = 1;
   }
+  IoJob *J = new IoJob();
+  J->path = path; J->fd = fd; J->im = P.im; J->jm = P.jm; J->iml = P.iml; J->jml = P.jml; J->kb = P.kb; J->n2 = P.n2;
+  J->i0 = m->i0; J->j0 = m->j0; J->im_global = m->im_global; J->jm_global = m->jm_global; J->create = m->create; J->device = c->device;
+  // scalars and the vertical grid: small, written here
+  J->b1.resize((size_t)POM_NBLK1D * P.kb);
+  if (hipMemcpyAsync(J->b1.data(), P.b1, sizeof(double) * J->b1.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
   for (const Var &v : S.vars) {
     if (bad) break;
     if (v.src == SCALAR) { if (m->create) bad |= write_be(fd, &v.value, 1, v.begin, tmp); continue; }
-    if (v.src == LEVELS1D) {
-      if (!m->create) continue;
-      host.resize(P.kb);
-      if (hipMemcpyAsync(host.data(), P.b1 + (size_t)v.slot * P.kb, sizeof(double) * P.kb, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-          hipStreamSynchronize(c->stream) != hipSuccess) { bad = 1; break; }
-      bad |= write_be(fd, host.data(), (size_t)v.nlev, v.begin, tmp);
-      continue;
-    }
-    const int nlev = v.src == PLANE2D ? 1 : v.nlev;
-    const double *dev = v.src == PLANE2D ? P.b2 + (size_t)v.slot * P.n2 : P.b3 + (size_t)v.slot * P.a3;
-    host.resize((size_t)nlev * P.n2);
-    if (hipMemcpyAsync(host.data(), dev, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) { bad = 1; break; }
-    for (int k = 0; k < nlev && !bad; k++)
-      for (int j = 0; j < P.jm && !bad; j++) {
-        const uint64_t cell = ((uint64_t)k * m->jm_global + (uint64_t)(m->j0 - 1 + j)) * m->im_global + (uint64_t)(m->i0 - 1);
-        bad |= write_be(fd, host.data() + ((size_t)k * P.jml + j) * P.iml, (size_t)P.im, v.begin + cell * 8, tmp);
-      }
+    if (v.src == LEVELS1D && m->create) bad |= write_be(fd, J->b1.data() + (size_t)v.slot * P.kb, (size_t)v.nlev, v.begin, tmp);
   }
-  if (close(fd)) bad = 1;
-  return bad ? fail(c, POMGPU_EINVAL, "write: I/O error on %s", path) : POMGPU_OK;
+  size_t total = 0;
+  for (const Var &v : S.vars) total += var_doubles(*J, v);
+  bool async = !bad && total > 0 && !getenv("POMGPU_IO_SYNC");
+#ifdef POMGPU_EMU
+  async = false;
+#else
+  if (async && hipMalloc((void **)&J->snap, total * sizeof(double)) != hipSuccess) { J->snap = NULL; (void)hipGetLastError(); async = false; }
+#endif
+  auto dev_of = [&](const Var &v) { return v.src == PLANE2D ? P.b2 + (size_t)v.slot * P.n2 : P.b3 + (size_t)v.slot * P.a3; };
+  if (!async) {                                                        // the synchronous path: variable by variable through pageable memory
+    for (const Var &v : S.vars) {
+      const size_t n = var_doubles(*J, v);
+      if (bad || !n) continue;
+      host.resize(n);
+      if (hipMemcpyAsync(host.data(), dev_of(v), sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess) { bad = 1; break; }
+      bad |= put_var(*J, v, host.data(), tmp);
+    }
+    if (close(fd)) bad = 1;
+    J->fd = -1;
+    c->io_job = J;
+    (void)pomgpu_io_wait(c);
+    return bad ? fail(c, POMGPU_EINVAL, "write: I/O error on %s", path) : POMGPU_OK;
+  }
+#ifndef POMGPU_EMU
+  size_t off = 0;
+  for (const Var &v : S.vars) {                                        // the snapshot, on the kernels' stream
+    const size_t n = var_doubles(*J, v);
+    if (!n) continue;
+    if (hipMemcpyAsync(J->snap + off, dev_of(v), n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) bad = 1;
+    off += n;
+  }
+  if (hipEventCreateWithFlags(&J->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(J->ev, c->stream) != hipSuccess ||
+      hipStreamCreateWithFlags(&J->st, hipStreamNonBlocking) != hipSuccess) bad = 1;
+  J->S = S;
+  c->io_job = J;
+  if (bad) { (void)close(fd); J->fd = -1; (void)pomgpu_io_wait(c); return fail(c, POMGPU_EHIP, "write: cannot start the copy of %s", path); }
+  J->active = 1;
+  J->th = std::thread(io_worker, J);
+#endif
+  return POMGPU_OK;
 }
 
 static void stats_for_file(pomgpu_ctx *c, const pomgpu_file_meta *m, double *s8) {

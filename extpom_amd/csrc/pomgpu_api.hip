@@ -325,6 +325,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);
+  (void)pomgpu_io_wait(c);
   wide_free(c);
   pomgpu_tp_free(c);
   KP &P = c->P;
@@ -369,6 +370,7 @@ extern "C" int pomgpu_sync(pomgpu_ctx *c) {
   if (!c) return POMGPU_EINVAL;
   side_join(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  { const int rio = pomgpu_io_wait(c); if (rio) return rio; }
   return c->launch_err ? POMGPU_EHIP : POMGPU_OK;
 }
 

@@ -470,6 +470,7 @@ struct pomgpu_ctx {
   pomgpu_wide wide;
   pomgpu_ctx *parent;        // the tile's context, for the extended tile (errors and profile entries go there)
   int flags;                 // POMGPU_CTX_2D: no 3-D arrays (the extended tile of the wide-halo external mode)
+  void *io_job;              // the output / restart file being written behind the model's back (cdf_out.hip), NULL = none
   int launch_err;            // first hipError_t a kernel launch returned (0 = none); reported by the next sync / get_con
   char err[512];
 };

@@ -64,6 +64,9 @@ module pomgpu_iface
     integer(c_int) function pomgpu_set_lateral_record(ctx, n, arrays) bind(C, name='pomgpu_set_lateral_record')
       import; type(c_ptr), value :: ctx; integer(c_int), value :: n; type(c_ptr) :: arrays(20)
     end function
+    integer(c_int) function pomgpu_io_wait(ctx) bind(C, name='pomgpu_io_wait')
+      import; type(c_ptr), value :: ctx
+    end function
     integer(c_int) function pomgpu_write_output(ctx, path, meta) bind(C, name='pomgpu_write_output')
       import; type(c_ptr), value :: ctx, path; type(pomgpu_file_meta) :: meta
     end function

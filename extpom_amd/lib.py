@@ -80,6 +80,7 @@ _SIGS = {
     "pomgpu_halo_unpack8": (_I, [_P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_I), _I, ctypes.POINTER(ctypes.c_void_p)]),
     "pomgpu_check_velocity": (_I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pomgpu_run": (_I, [_P, _I]),
+    "pomgpu_io_wait": (_I, [_P]),
     "pomgpu_write_output": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(FileMeta)]),
     "pomgpu_write_restart": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(FileMeta)]),
     "pomgpu_domain_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double), _I]),

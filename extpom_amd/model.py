@@ -172,6 +172,10 @@ class PomGpu:
         fn = self.L.pomgpu_write_output if kind == "output" else self.L.pomgpu_write_restart
         self._chk(fn(self.h, str(path).encode(), ctypes.byref(m)), "write_" + kind)
 
+    def io_wait(self):
+        """join the host thread that is writing the last output / restart file (sync, the next write and close do it too)"""
+        self._chk(self.L.pomgpu_io_wait(self.h), "io_wait")
+
     def set_order_exchange(self, fn):
         """fn(send_east, n_east, send_north, n_north, recv_west, recv_south): device addresses (baropg_mcc's
         order2d_mpi / order3d_mpi, packed by the library) -- see extpom_amd.halo.Halo.device_order_hook"""

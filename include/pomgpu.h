@@ -211,6 +211,10 @@ typedef struct pomgpu_file_meta {
   int create;                 /* 1: create the file and write header + scalars + own patch; 0: own patch only */
   const double *stats;        /* vtot atot mtot stot tavg savg eavg ekin, or NULL */
 } pomgpu_file_meta;
+/* The two writers return once the file is laid out and a snapshot of its arrays has been taken on the device; a host
+ * thread brings the snapshot over on a copy stream and writes it while the model goes on.  pomgpu_io_wait joins it and
+ * returns its status (pomgpu_sync, the next write and pomgpu_destroy call it too). */
+int pomgpu_io_wait(pomgpu_ctx *ctx);
 int pomgpu_write_output(pomgpu_ctx *ctx, const char *path, const pomgpu_file_meta *meta);    /* write_output_pnetcdf */
 int pomgpu_write_restart(pomgpu_ctx *ctx, const char *path, const pomgpu_file_meta *meta);   /* write_restart_pnetcdf */
 
