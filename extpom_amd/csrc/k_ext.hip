@@ -622,7 +622,7 @@ __device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, in
 // on the last substep only.  uab, vab are then read at neighbour cells while this kernel rewrites them: they are
 // double-buffered like ua, va, d, el, elb.
 template <int FUSE_ADV>
-__global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) {
+__device__ __forceinline__ void ext_step_body(const KP &P, int store_f, int rim_rows) {   // the substep is P.iext
   if ((int)blockIdx.y < rim_rows) {
     ext_rim_cell(P, (int)((blockIdx.y * blockDim.y + threadIdx.y) * (gridDim.x * blockDim.x) + blockIdx.x * blockDim.x + threadIdx.x), store_f, FUSE_ADV);
     return;
@@ -747,6 +747,74 @@ __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_row
     F2(vtf, i, j) = F2(vtf, i, j) + v * (dn + (h_m1 + es)) * P.isp2i;
   }
 }
+template <int FUSE_ADV>
+__global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) { ext_step_body<FUSE_ADV>(P, store_f, rim_rows); }
+
+// ---- all the external substeps of an internal step in ONE launch (small tiles) ------------------------------------------
+// On a small tile a substep's kernel is a few wavefronts per CU on a chain of dependent loads: ~20 us each, 30 of them per
+// internal step, whatever the grid size (256x256x30: 0.68 of 1.34 ms per step) -- a launch boundary costs more than the
+// work.  When every workgroup of the substep's grid is resident at once (k_ext_step<1> holds 245 VGPRs: two 256-thread
+// workgroups per CU, 512 on the chip), k_ext_loop keeps them there and walks the substeps itself: the same body, the two
+// buffer generations swapped in registers, and a grid-wide barrier in between (MI355X_MICROARCH.md, "barrier-counter":
+// every storing wavefront drains its stores, the workgroup meets, one lane releases at agent scope -- the XCD's L2 writes
+// its dirty lines back --, adds to a counter, polls it with relaxed loads, acquires -- the CU's L1 is invalidated -- and
+// the workgroup goes on).  Every spin is bounded: a workgroup that waits too long raises the abort word, which every
+// other poll also watches, sets the error flag and all of them leave; the host then reports the step as failed.
+#ifndef POMGPU_EMU
+__device__ __forceinline__ bool ext_grid_barrier(unsigned *bar, unsigned target) {   // bar[0] arrivals, bar[1] abort; false = give up
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wavefront's stores have left
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int good = 1;
+    for (unsigned spin = 0;; spin++) {
+      if ((int)(__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spin > (1u << 22)) {   // ~1 s: something is not resident
+        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+// Two views of the arguments, one per buffer generation, taken once: a KP whose pointers are swapped inside the loop lived
+// in vector registers (260 VGPRs: one workgroup per CU, and a 256x256 tile needs two)
+template <int FUSE_ADV>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_ext_loop(KP P, int rim_rows, int first, int last, unsigned *bar, unsigned base, int *d_err) {
+  const unsigned nblk = gridDim.x * gridDim.y;
+  unsigned tgt = base;
+  for (int n = first; n <= last; n += 2) {
+    {
+      KP Q = P;
+      Q.iext = n;
+      ext_step_body<FUSE_ADV>(Q, n == P.isplit, rim_rows);
+    }
+    if (n == last) break;
+    tgt += nblk;
+    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) *d_err = 1; return; }
+    {
+      KP Q = P;
+#pragma unroll
+      for (int g = 0; g < POMGPU_NGEN; g++) { Q.x2[g] = P.y2[g]; Q.y2[g] = P.x2[g]; }
+      Q.iext = n + 1;
+      ext_step_body<FUSE_ADV>(Q, n + 1 == P.isplit, rim_rows);
+    }
+    if (n + 1 == last) break;
+    tgt += nblk;
+    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) *d_err = 1; return; }
+  }
+}
+#endif
 __global__ void k_ext_step_rim(KP P, int store_f) {
   ext_rim_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f, 0);
 }
@@ -818,6 +886,43 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
   g.y += rim_rows;
   if (fuse_adv) LAUNCHN(c, "k_ext_step_adv", k_ext_step<1>, g, blk2(), Q, store_f, rim_rows);
   else LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, rim_rows);
+}
+// every substep first..last in one launch, or 0 when the tile is too large for all its workgroups to be resident (the
+// caller then launches the substeps one by one).  Q: as for launch_ext_step (y2 = the other buffer set).
+int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last) {
+#ifdef POMGPU_EMU
+  (void)c; (void)Q; (void)first; (void)last;
+  return 0;
+#else
+  // Opt-in (POMGPU_EXT_LOOP=1): measured on MI355X it does not pay.  256x256 (325 workgroups, two per CU): 1.40 ms for the
+  // 30 substeps against 0.64 ms as 30 launches -- ~45 us per barrier once every workgroup has ~20 KB of freshly written
+  // lines for the L2 write-back of the release and 325 lanes poll one counter; 65x49 (28 workgroups): 0.35 against 0.39 ms,
+  // nothing on the step.  A launch boundary on this chip (~1.5-2 us + the ~20 us the substep's dependent loads take anyway)
+  // is cheaper than this barrier; an XCD-hierarchical one (MI355X_MICROARCH.md: ~6 us + the publish) would be the next try.
+  if (!getenv("POMGPU_EXT_LOOP") || last <= first) return 0;
+  static int occ = -1, ncu = 0;
+  if (occ < 0) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, c->device) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ext_loop<1>, 256, 0) != hipSuccess) { occ = 0; return 0; }
+    ncu = pr.multiProcessorCount;
+    if (occ > 2) occ = 2;                                     // never count on more than the register file certainly gives (245 VGPRs)
+  }
+  const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
+  dim3 g = grid2_halo(Q);
+  const int per_row = (int)g.x * 256, rim_rows = (n + per_row - 1) / per_row;
+  g.y += rim_rows;
+  const long blocks = (long)g.x * g.y;
+  if (occ < 1 || blocks > (long)ncu * occ * 7 / 8) return 0;  // a margin: a workgroup that is not resident never reaches the barrier
+  if (!c->ext_bar) {
+    if (hipMalloc((void **)&c->ext_bar, 2 * sizeof(unsigned)) != hipSuccess) { c->ext_bar = NULL; return 0; }
+    (void)hipMemsetAsync(c->ext_bar, 0, 2 * sizeof(unsigned), c->cur);
+    c->ext_bar_base = 0;
+  }
+  LAUNCHN(c, "k_ext_loop", k_ext_loop<1>, g, blk2(), Q, rim_rows, first, last, c->ext_bar, c->ext_bar_base, c->d_err);
+  c->ext_bar_base += (unsigned)(blocks * (last - first));
+  return 1;
+#endif
 }
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy2, grid2(c->P), blk2(), c->P, dst, src); }
 void launch_int_tail(pomgpu_ctx *c) { LAUNCH(c, k_int_tail, grid2(c->P), blk2(), c->P); }

@@ -338,7 +338,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   (void)hipFree(P.m8);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
-  (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats);
+  (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats); (void)hipFree(c->ext_bar);
   for (int k = 0; k < 3; k++) for (int sl = 0; sl < 4; sl++) { (void)hipFree(c->frc_dev[k][sl][0]); (void)hipFree(c->frc_dev[k][sl][1]); }
   for (int sl = 0; sl < 4; sl++) (void)hipFree(c->lat_dev[sl]);
   ProfState *ps = PS(c);
@@ -847,6 +847,25 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   launch_ext_update(c);                                       // :295-347
   if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
   return POMGPU_OK;
+}
+// every external substep of the step in one launch (k_ext_loop): one tile -- or the extended tile of the wide-halo mode --
+// whose workgroups are all resident at once; 0 = not applicable, the caller loops over mode_external
+static int ext_loop_all(pomgpu_ctx *c) {
+  pomgpu_ctx *t = c;
+  if (c->wide.on) { if (!c->wide.pending) return 0; t = c->wide.x; t->con.isplit = c->con.isplit; }
+  else if (c->exch) return 0;
+  KP &P = t->P;
+  const int isplit = c->con.isplit;
+  if (getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE") || isplit < 2) return 0;
+  P.iext = 1;
+  KP Q = P;
+  for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = t->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : t->alt2[n];
+  if (!launch_ext_loop(t, Q, 1, isplit)) return 0;
+  if (isplit & 1) t->ext_parity ^= 1;                         // one generation swap per substep
+  ext_buffers(t);
+  c->con.iext = isplit; t->con.iext = isplit; P.iext = isplit; c->P.iext = isplit;
+  if (c->wide.on) wide_flush(c);                              // the tile's arrays, ghost cells included, are current again
+  return 1;
 }
 // ---- the library's own exchange (include/pomgpu.h "transport") -----------------------------------------------
 // every exchange point: pack8 -> one message round -> unpack8, all on the stream (parallel_mpi.f:154-351)
@@ -1471,6 +1490,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !c->exch && !getenv("POMGPU_RHO_ROUNDTRIP");   // one tile: on tiles k_profq_prod(_lines) read rho as well
   if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
+  if (!ext_loop_all(c))
   for (int iext = 1; iext <= c->con.isplit; iext++) {
     c->con.iext = iext;
     if ((rc = mode_external(c, 0))) return rc;                // ... to the last substep

@@ -470,6 +470,8 @@ struct pomgpu_ctx {
   pomgpu_wide wide;
   pomgpu_ctx *parent;        // the tile's context, for the extended tile (errors and profile entries go there)
   int flags;                 // POMGPU_CTX_2D: no 3-D arrays (the extended tile of the wide-halo external mode)
+  unsigned *ext_bar;         // device: arrival counter + abort word of k_ext_loop's grid barrier (k_ext.hip)
+  unsigned ext_bar_base;     // the counter's value when the next k_ext_loop starts (every workgroup arrives once per barrier)
   void *io_job;              // the output / restart file being written behind the model's back (cdf_out.hip), NULL = none
   int launch_err;            // first hipError_t a kernel launch returned (0 = none); reported by the next sync / get_con
   char err[512];
@@ -548,6 +550,7 @@ void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
+int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last);   // 1 = launched (all substeps first..last), 0 = not applicable
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate
 void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf);
