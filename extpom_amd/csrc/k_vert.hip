@@ -237,12 +237,19 @@ __device__ __forceinline__ double profq_cc_v(const KP &P, double t, double s_, d
   cc = cc / sqrt((1. - .01642 * p / cc) * (1. - 0.40 * p / sq(cc)));
   return cc;
 }
-__device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, double ccm, double cck) {   // :1327-1330
-  return P.grav * (F3(rho, i, j, k - 1) - F3(rho, i, j, k)) / (F1(dzz, k - 1) * h_(i, j)) +
+// rho_rt: rho's round trip through rho - rmean has been deferred (pomgpu_ctx::rho_rt_pending): applied to what is loaded
+__device__ __forceinline__ double profq_rho(const KP &P, int i, int j, int k, int rho_rt) {
+  const double r = F3(rho, i, j, k);
+  if (!rho_rt) return r;
+  const double m = F3(rmean, i, j, k);
+  return (r - m) + m;
+}
+__device__ __forceinline__ double profq_boygr(const KP &P, int i, int j, int k, double ccm, double cck, int rho_rt = 0) {   // :1327-1330
+  return P.grav * (profq_rho(P, i, j, k - 1, rho_rt) - profq_rho(P, i, j, k, rho_rt)) / (F1(dzz, k - 1) * h_(i, j)) +
          sq(P.grav) * 2. / (sq(ccm) + sq(cck));
 }
 // (2) shear + buoyancy production (exchanged before the solves) -- :1359-1373   scratch: s3[0]=prod
-__global__ void k_profq_prod(KP P) {
+__global__ void k_profq_prod(KP P, int rho_rt) {
   COL2
   if (i > P.im || j > P.jm) return;
   double *prod = P.s3[0];
@@ -258,7 +265,7 @@ __global__ void k_profq_prod(KP P) {
   double ccm = profq_cc(P, i, j, 1);
   for (int k = 2; k <= P.kbm1; k++) {
     const double cck = profq_cc(P, i, j, k);
-    const double bg = profq_boygr(P, i, j, k, ccm, cck);
+    const double bg = profq_boygr(P, i, j, k, ccm, cck, rho_rt);
     const double km = F3(km, i, j, k);
     double p = km * .25 * sef *
                    (sq(u_(i, j, k) - u_(i, j, k - 1) + u_(i + 1, j, k) - u_(i + 1, j, k - 1)) +
@@ -274,7 +281,7 @@ __global__ void k_profq_prod(KP P) {
 // (fuse_prod = 2); the exchange at :1374 only needs the lines it sends (columns 2 / imm1, rows 2 / jmm1) and zeros
 // on the rim where no neighbour will write.  One thread per (cell of a line, level): a column walk here would be
 // eight lines of threads each waiting out 50 levels of dependent loads.
-__global__ void k_profq_prod_lines(KP P) {
+__global__ void k_profq_prod_lines(KP P, int rho_rt) {
   const int t = TID_I, line = (int)blockIdx.y, k = (int)blockIdx.z + 1;        // lines: i = 1, 2, imm1, im, then j = 1, 2, jmm1, jm
   int i, j;
   if (line < 4) { if (t > P.jm) return; j = t; i = line == 0 ? 1 : (line == 1 ? 2 : (line == 2 ? P.imm1 : P.im)); }
@@ -285,7 +292,7 @@ __global__ void k_profq_prod_lines(KP P) {
     const double dh = h_(i, j) + F2(etf, i, j);
     const double sef = 1., shiw = 0.;
     const double ccm = profq_cc(P, i, j, k - 1), cck = profq_cc(P, i, j, k);
-    const double bg = profq_boygr(P, i, j, k, ccm, cck);
+    const double bg = profq_boygr(P, i, j, k, ccm, cck, rho_rt);
     const double km = F3(km, i, j, k);
     p = km * .25 * sef *
             (sq(u_(i, j, k) - u_(i, j, k - 1) + u_(i + 1, j, k) - u_(i + 1, j, k - 1)) +
@@ -1192,11 +1199,11 @@ void launch_int_uvmean(pomgpu_ctx *c) {
 }
 void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
-void launch_profq_prod(pomgpu_ctx *c, int lines_only) {
-  if (!lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P); return; }
+void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
+  if (!lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P, rho_rt); return; }
   const KP &P = c->P;
   const int len = P.im > P.jm ? P.im : P.jm;
-  LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P);
+  LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P, rho_rt);
 }
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
 #define PQ(FP, FF) LAUNCHN(c, "k_profq", (k_profq<FP, FF>), colgrid(c->P), colblk(), c->P, rho_rt)

@@ -668,7 +668,7 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
   if (lines) {
     // the production term's lines (k_profq_prod_lines) depend on nothing profq_bc or the exchange below delivers:
     // :1289-1290, :1374 (and advance.f:400 for w) travel in ONE round
-    launch_profq_prod(c, 1);
+    launch_profq_prod(c, 1, c->rho_rt_pending);
     if (with_w) xch(c, 4, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2, D3(c, w), P.kb);
     else xch(c, 3, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2);
     launch_profq(c, 2, fuse_filter, c->rho_rt_pending);       // owned columns form prod inside the solve
@@ -677,7 +677,7 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
   if (with_w) xch(c, 3, P.s2[4], 1, ufkb, 1, D3(c, w), P.kb);   // :1289-1290 + advance.f:400
   else xch(c, 2, P.s2[4], 1, ufkb, 1);                        // :1289-1290
   if (!c->exch) { launch_profq(c, 1, fuse_filter, c->rho_rt_pending); return; }  // one tile: prod is formed inside the solve kernel
-  launch_profq_prod(c, 0);
+  launch_profq_prod(c, 0, c->rho_rt_pending);
   xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
   launch_profq(c, 0, fuse_filter, c->rho_rt_pending);
 }
@@ -1487,7 +1487,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   if ((rc = wide_early_start(c))) return rc;                  // most of the wide exchange, beside lateral_viscosity
   // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)
   const pom_blkcon &k0 = c->con;
-  const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !c->exch && !getenv("POMGPU_RHO_ROUNDTRIP");   // one tile: on tiles k_profq_prod(_lines) read rho as well
+  const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !getenv("POMGPU_RHO_ROUNDTRIP");   // rho's readers before dens: k_profq, k_profq_prod(_lines)
   if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
   if (!ext_loop_all(c))

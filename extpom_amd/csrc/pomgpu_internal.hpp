@@ -595,7 +595,7 @@ void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n);
 void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
-void launch_profq_prod(pomgpu_ctx *c, int lines_only);
+void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt = 0);
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt = 0);
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);

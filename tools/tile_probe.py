@@ -69,10 +69,12 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     rounds = (g.exchange_rounds() - r0) / a.steps
     msg = prof.pop("msg_round", (0, 0.0))
+    msg_side = prof.pop("msg_round_side", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
     print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
                       "wide": bool(wide), "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
                       "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
+                      "message_rounds_on_side_stream_per_step": g.exchange_rounds_side() / (a.steps + 3), "stand_in_mover_side_ms": round(msg_side[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
     g.close()
 
