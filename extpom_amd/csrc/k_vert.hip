@@ -335,9 +335,15 @@ __global__ void k_profq_prod_lines(KP P, int rho_rt) {
 struct LevQ { double t, s, rho, rm, q2b, q2lb, q2, km, kh, uf, vf, uc, ue, vc, vn, kq1, prod; };
 struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 // rho_rt: rho is still to make its round trip through rho - rmean (pomgpu_ctx::rho_rt_pending): applied to the loaded value
-template <int FP, int FF>
-__global__ void __launch_bounds__(128) k_profq(KP P, int rho_rt) {
+// ROWS wavefronts (rows) per workgroup, kept on the same level by one s_barrier per two levels (PACE_BARRIER, no fence):
+// the walk down touches 17 arrays x 2 levels, every (array, level) in a 2 MiB page of its own (level stride 25 MB at
+// 2048x1536) -- wavefronts of a CU that drift apart by a few levels cycle through more pages than the CU's first-level
+// TLB holds, and then EVERY access misses (TCP_UTCL1_TRANSLATION_MISS 4.8e7 per launch = 2 of 3 wave accesses, the
+// translation FIFO stalled 27 % of the kernel; 1.7e6 with 8 paced rows -- profiles/round2_tlb_profq.txt).
+template <int FP, int FF, int ROWS>
+__global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
   COL2
+  const int rho_rt = rho_rt_pace & 1, pace = rho_rt_pace & 2;
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
   const int kb = P.kb, kbm1 = P.kbm1;
@@ -514,6 +520,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int rho_rt) {
     lev(ra, 1);
     rb = ra;
     for (int k = 1; k <= kb; k += 2) {
+      if (pace) PACE_BARRIER();
       step(k, ra, rb);
       if (k + 1 <= kb) step(k + 1, rb, ra);
     }
@@ -568,6 +575,7 @@ __global__ void __launch_bounds__(128) k_profq(KP P, int rho_rt) {
     levb(ra, kb);
     rb = ra;
     for (int ki = kb; ki >= 1; ki -= 2) {
+      if (pace) PACE_BARRIER();
       stepb(ki, ra, rb);
       if (ki - 1 >= 1) stepb(ki - 1, rb, ra);
     }
@@ -1206,7 +1214,15 @@ void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
   LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P, rho_rt);
 }
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
-#define PQ(FP, FF) LAUNCHN(c, "k_profq", (k_profq<FP, FF>), colgrid(c->P), colblk(), c->P, rho_rt)
+  // 8 paced rows per workgroup (one workgroup per CU at 2 waves per SIMD) where that still leaves every CU several workgroups
+  // (developer switches: POMGPU_PROFQ_ROWS8 / _ROWS2 force a shape, POMGPU_PROFQ_NOPACE drops the barrier)
+  const int rows8 = !getenv("POMGPU_PROFQ_ROWS2") && (getenv("POMGPU_PROFQ_ROWS8") || (long)((c->P.iml + 63) / 64) * ((c->P.jml + 7) / 8) >= 4 * 256);
+  rho_rt = (rho_rt ? 1 : 0) | (getenv("POMGPU_PROFQ_NOPACE") ? 0 : 2);
+#define PQ(FP, FF)                                                                                                                       \
+  do {                                                                                                                                   \
+    if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, 8>), dim3((c->P.iml + 63) / 64, (c->P.jml + 7) / 8, 1), dim3(64, 8, 1), c->P, rho_rt); \
+    else LAUNCHN(c, "k_profq", (k_profq<FP, FF, 2>), dim3((c->P.iml + 63) / 64, (c->P.jml + 1) / 2, 1), dim3(64, 2, 1), c->P, rho_rt);       \
+  } while (0)
   if (fuse_filter) { if (fuse_prod == 0) PQ(0, 1); else if (fuse_prod == 1) PQ(1, 1); else PQ(2, 1); }
   else { if (fuse_prod == 0) PQ(0, 0); else if (fuse_prod == 1) PQ(1, 0); else PQ(2, 0); }
 #undef PQ

@@ -257,6 +257,12 @@ static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { 
 // Slab rows: 0 = south halo, 1..LDS_ROWS = the workgroup's rows, LDS_ROWS+1 = north halo, LDS_ROWS+2 = sink for the
 // slots a wavefront has no job for.  Host emulation (one lane at a time, no concurrency) reads the rows from memory.
 #ifndef LDS_ROWS
+// keeps the wavefronts of a workgroup on the same level of a level loop (no memory ordering implied or needed)
+#ifdef POMGPU_EMU
+#define PACE_BARRIER() ((void)0)
+#else
+#define PACE_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define LDS_ROWS 8                                          /* rows per workgroup of the row-sharing kernels (kbench: 8 beats 4 and 6 by 8-14 %) */
 #endif
 #define ROWSHARE_SLOTS(NS) ((2 * (NS) + LDS_ROWS - 1) / LDS_ROWS)

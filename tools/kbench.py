@@ -2,7 +2,7 @@
 Run-to-run and box-to-box differences on the pool are +-5 % (clocks); variants timed in separate processes cannot be
 ranked closer than that.  Here the state is built once, every variant gets its own context (60 GB each at the default
 size) and the variants take turns: R rounds of (profiled step of A, of B, ...); reported: min and median per kernel.
-usage: python tools/kbench.py [--workload W] [--rounds R] [--kernels a,b,...] tag[=lib.so][:ENV=V ...] ...
+usage: python tools/kbench.py [--workload W] [--rounds R] [--kernels a,b,...] tag[=lib.so|=@][:ENV=V ...] ...   (=@: the previous variant's context)
 (an ENV of a spec is set while that variant's context is created and while it runs)"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,7 @@ case, im, jm, kb, _ = bench.WORKLOADS[wl]
 tile = pdist.tile_for_rank(0, 1, im, jm)
 st0 = bench.build_state(wl, tile)
 g0 = bench.gpu_initialise(st0, 0, None)      # finishes the initial state with the default library
-g0.close()
+if not os.environ.get('KBENCH_KEEP_G0'): g0.close()
 variants = []
 for spec in args:
     parts = spec.split(":")
@@ -32,7 +32,10 @@ for spec in args:
     env = dict(p.split("=", 1) for p in parts[1:])
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    g = PomGpu(st0, device=0, libpath=os.path.join(ROOT, lib) if lib else None)
+    if lib == "@":                  # same context as the previous variant: only the environment differs (switches read at launch time)
+        g = variants[-1][2]
+    else:
+        g = PomGpu(st0, device=0, libpath=os.path.join(ROOT, lib) if lib else None)
     g.run(2); g.sync()
     for k, v in old.items():
         os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
