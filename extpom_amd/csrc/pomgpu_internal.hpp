@@ -41,6 +41,7 @@ struct KP {
          tbias, tprni, umol, horcon, ispi, isp2i, smoth, sw, time, vmaxl;
   int mode, ntp, nadv, nbct, nbcs, nitera, npg, isplit, iext, iint, iend;
   int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
+  int g_strip;               // row-sharing column kernels: an XCD walks its band in strips this many workgroups wide (0: row by row)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
   // current (read) and next (written) generation of ua, va, d, el, elb, uab, vab for the external-mode kernels
@@ -256,13 +257,13 @@ static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { 
 // its neighbours still read this level's.  Loads per wavefront and level: NS + NO + slots instead of 3*NS + NO.
 // Slab rows: 0 = south halo, 1..LDS_ROWS = the workgroup's rows, LDS_ROWS+1 = north halo, LDS_ROWS+2 = sink for the
 // slots a wavefront has no job for.  Host emulation (one lane at a time, no concurrency) reads the rows from memory.
-#ifndef LDS_ROWS
 // keeps the wavefronts of a workgroup on the same level of a level loop (no memory ordering implied or needed)
 #ifdef POMGPU_EMU
 #define PACE_BARRIER() ((void)0)
 #else
 #define PACE_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+#ifndef LDS_ROWS
 #define LDS_ROWS 8                                          /* rows per workgroup of the row-sharing kernels (kbench: 8 beats 4 and 6 by 8-14 %) */
 #endif
 #define ROWSHARE_SLOTS(NS) ((2 * (NS) + LDS_ROWS - 1) / LDS_ROWS)
@@ -338,24 +339,24 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
 // it row by row, so the ~3 block-rows an XCD has resident at any time are neighbours and the halo rows
 // are L2 hits.  The mapping is only a performance hint: any dispatch order gives the same results.
 // HALO_XCD_DECODE defines i0 (1-based column, halo-lane numbering) and j (1-based row), or returns.
-#ifndef COL_STRIP
-#define COL_STRIP 0                                         /* > 0: an XCD walks its band in strips this many workgroups wide */
-#endif
-#if COL_STRIP > 0
-// strip order: the workgroups an XCD has resident at one time are a tall patch (COL_STRIP wide), so that the row a
-// workgroup reads beyond its own rows is being read by the workgroup above / below it at about the same time (L2 hit)
+// Strip order (P.g_strip > 0): the workgroups an XCD has resident at one time are a patch g_strip wide and several block-rows
+// tall instead of 2-3 whole block-rows, so that the level a workgroup is on is also being read by the workgroups above /
+// below it and beside it at about the same time.  Same-context A/B at 2048 columns (34 workgroups per block-row;
+// profiles/round2_strip_order.txt): width 2 +6..10 %, 4 +-0, 8 -2..5 %, 11-12 -2.5..5 % (advct, advq), 16 -1..3 % against
+// whole rows; set_band_geometry picks the width nearest 12 that divides the row evenly.
 #define HALO_XCD_ORDER                                                                    \
-  const int nfull__ = nbx__ / COL_STRIP, wlast__ = nbx__ - nfull__ * COL_STRIP;           \
-  int s__ = m__ / (rpx__ * COL_STRIP);                                                    \
-  if (s__ > nfull__) s__ = nfull__;                                                       \
-  const int rem__ = m__ - s__ * rpx__ * COL_STRIP, w__ = s__ < nfull__ ? COL_STRIP : (wlast__ > 0 ? wlast__ : 1); \
-  const int byl__ = rem__ / w__, bxg__ = s__ * COL_STRIP + rem__ % w__;                   \
-  if (bxg__ >= nbx__ || byl__ >= rpx__) return;
-#else
-#define HALO_XCD_ORDER                                                                    \
-  const int byl__ = m__ / nbx__, bxg__ = m__ % nbx__;                                     \
-  if (byl__ >= rpx__) return;
-#endif
+  int byl__, bxg__;                                                                       \
+  if (P.g_strip > 0) {                                                                    \
+    const int st__ = P.g_strip, nfull__ = nbx__ / st__, wlast__ = nbx__ - nfull__ * st__; \
+    int s__ = m__ / (rpx__ * st__);                                                       \
+    if (s__ > nfull__) s__ = nfull__;                                                     \
+    const int rem__ = m__ - s__ * rpx__ * st__, w__ = s__ < nfull__ ? st__ : (wlast__ > 0 ? wlast__ : 1); \
+    byl__ = rem__ / w__; bxg__ = s__ * st__ + rem__ % w__;                                \
+    if (bxg__ >= nbx__ || byl__ >= rpx__) return;                                         \
+  } else {                                                                                \
+    byl__ = m__ / nbx__; bxg__ = m__ % nbx__;                                             \
+    if (byl__ >= rpx__) return;                                                           \
+  }
 #define HALO_XCD_DECODE HALO_XCD_DECODE_R(COL_ROWS)
 #define HALO_XCD_DECODE_R(ROWS__)                                                         \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
@@ -531,6 +532,12 @@ static inline void set_band_geometry(KP &P) {
   P.g_rb = (int)rows;
   P.g_nbx = (P.iml + 63) / 64;
   P.g_bpl = P.g_nbx * (int)(rows / 4);
+  // the row-sharing column kernels (HALO_XCD_ORDER): strips about 12 workgroups wide on wide tiles
+  const int nbx = ((P.iml + 61) / 62 + COL_WX - 1) / COL_WX;
+  const int nstr = (nbx + 11) / 12;
+  P.g_strip = nbx >= 20 ? (nbx + nstr - 1) / nstr : 0;
+  const char *es = getenv("POMGPU_COL_STRIP");
+  if (es) P.g_strip = atoi(es);
 }
 
 // kernel launchers implemented in the k_*.hip files (one per fused phase of the step)

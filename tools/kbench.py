@@ -2,7 +2,7 @@
 Run-to-run and box-to-box differences on the pool are +-5 % (clocks); variants timed in separate processes cannot be
 ranked closer than that.  Here the state is built once, every variant gets its own context (60 GB each at the default
 size) and the variants take turns: R rounds of (profiled step of A, of B, ...); reported: min and median per kernel.
-usage: python tools/kbench.py [--workload W] [--rounds R] [--kernels a,b,...] tag[=lib.so|=@][:ENV=V ...] ...   (=@: the previous variant's context)
+usage: python tools/kbench.py [--workload W] [--rounds R] [--kernels a,b,...] tag[=lib.so|=@|=@lib.so][:ENV=V ...] ...   (=@: the previous variant's context; =@lib.so: that context under another build)
 (an ENV of a spec is set while that variant's context is created and while it runs)"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,6 +34,10 @@ for spec in args:
     os.environ.update(env)
     if lib == "@":                  # same context as the previous variant: only the environment differs (switches read at launch time)
         g = variants[-1][2]
+    elif lib.startswith("@"):       # the previous variant's context (its memory) driven by ANOTHER build of the library: the handle is a
+        import copy                 # plain C struct of the same layout -- for variants that differ in kernel code only
+        g = copy.copy(variants[-1][2])
+        g.L = _lib.load(os.path.join(ROOT, lib[1:]))
     else:
         g = PomGpu(st0, device=0, libpath=os.path.join(ROOT, lib) if lib else None)
     g.run(2); g.sync()
