@@ -732,6 +732,7 @@ __global__ void __launch_bounds__(256) k_realvertvl_col(KP P) {
   double w_k = w_(a, b, 1);
   LevR c = realvertvl_load(P, a, b, 1), nxt = c;
   for (int k = 1; k <= kbm1; k++) {
+    PACE_BARRIER();                                          // the workgroup's wavefronts stay on one level (same pages, same DRAM rows)
     if (k + 1 <= kbm1) nxt = realvertvl_load(P, a, b, k + 1);
     const double zzk = F1(zz, k);
 #define TPS(dtv, etv) (zzk * (dtv) + (etv))

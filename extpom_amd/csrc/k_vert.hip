@@ -53,6 +53,7 @@ __global__ void k_baropg(KP P, int sum2d) {
   rx = rx + ox * F1(dz, 1);
   ry = ry + oy * F1(dz, 1);
   for (int k = 2; k <= P.kbm1; k++) {
+    PACE_BARRIER();                                          // the workgroup's wavefronts stay on one level (same pages, same DRAM rows)
     const double rc = F3(rho, i, j, k) - F3(rmean, i, j, k);
     const double rw = F3(rho, i - 1, j, k) - F3(rmean, i - 1, j, k);
     const double rs = F3(rho, i, j - 1, k) - F3(rmean, i, j - 1, k);
@@ -201,6 +202,7 @@ __global__ void k_vertvl(KP P, int mask) {
   double wk = 0.5 * (F2(vfluxb, i, j) + F2(vfluxf, i, j));                                  // :2004
   F3(w, i, j, 1) = mask ? wk * m : wk;
   for (int k = 1; k <= P.kbm1; k++) {
+    PACE_BARRIER();                                          // the workgroup's wavefronts stay on one level (same pages, same DRAM rows)
     wk = wk + F1(dz, k) * ((ce * u_(i + 1, j, k) - cw * u_(i, j, k) + cn * v_(i, j + 1, k) - cs * v_(i, j, k)) / area + det);
     F3(w, i, j, k + 1) = (mask && k + 1 <= P.kbm1) ? wk * m : wk;
   }
@@ -1183,7 +1185,10 @@ __global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 colblk() { return dim3(64, 2, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
-void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, colgrid(c->P), colblk(), c->P, sum2d); }
+// baropg, vertvl: four paced rows per workgroup (same-context A/B against 2 unpaced rows: -2..-3 %; 8 rows: +3 % on baropg)
+#define COLV_G(P) dim3(((P).iml + 63) / 64, ((P).jml + 3) / 4, 1)
+#define COLV_B dim3(64, 4, 1)
+void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, COLV_G(c->P), COLV_B, c->P, sum2d); }
 void launch_baropg_mcc(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg_mcc, colgrid(c->P), colblk(), c->P, sum2d); }
 void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n) {
   const KP &P = c->P;
@@ -1205,7 +1210,7 @@ void launch_int_uvmean(pomgpu_ctx *c) {
   else if (kb <= 56) launch_int_uvmean_reg_t<56>(c);
   else launch_int_uvmean_reg_t<64>(c);
 }
-void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, colgrid(c->P), colblk(), c->P, mask); }
+void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, COLV_G(c->P), COLV_B, c->P, mask); }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
 void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
   if (!lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P, rho_rt); return; }
