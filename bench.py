@@ -248,7 +248,15 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' stdout is passed on line by line: the JSON line to stdout, anything a library wrote there (gloo's
+    # "[Gloo] Rank ..." banners in a rehearsal) to stderr, so that stdout holds the one line the contract asks for
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:
+        t = line.strip()
+        is_json = t.startswith("{") and t.endswith("}")
+        (sys.stdout if is_json else sys.stderr).write(line)
+        (sys.stdout if is_json else sys.stderr).flush()
+    return child.wait()
 
 
 def main():

@@ -306,6 +306,9 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   alloc(&c->d_stats, 8);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
+  if (getenv("POMGPU_DEBUG_ALLOC"))
+    fprintf(stderr, "pomgpu_create: b1 %p r1 %p b2 %p b3 %p bd %p s3[0] %p s3[4] %p s2[0] %p c2[0] %p\n", (void *)P.b1, (void *)P.r1, (void *)P.b2,
+            (void *)P.b3, (void *)P.bd, (void *)P.s3[0], (void *)P.s3[4], (void *)P.s2[0], (void *)P.c2[0]);
   if (!ok) {
     fprintf(stderr, "pomgpu_create: device allocation failed (%zu MB per 3-D array)\n", P.n3 * 8 >> 20);
     pomgpu_destroy(c);
@@ -1477,7 +1480,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
-  { KP g = c->P; set_band_geometry(g); c->P.g_strip = g.g_strip; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, honoured per step (tools/kbench.py)
+  { KP g = c->P; set_band_geometry(g); c->P.g_strip = g.g_strip; c->P.g_rotx = g.g_rotx; c->P.g_roty = g.g_roty; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, honoured per step (tools/kbench.py)
   // advance.f:14-18: file-driven in the reference; here they run once the host has supplied records
   if (c->frc_on && (rc = pomgpu_surface_forcing(c))) return rc;
   if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;
