@@ -41,7 +41,6 @@ struct KP {
          tbias, tprni, umol, horcon, ispi, isp2i, smoth, sw, time, vmaxl;
   int mode, ntp, nadv, nbct, nbcs, nitera, npg, isplit, iext, iint, iend;
   int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
-  int g_rotx, g_roty;        // experiment: XCD x starts g_rotx * x workgroups further along the row / g_roty * x block-rows further down its band
   int g_strip;               // row-sharing column kernels: an XCD walks its band in strips this many workgroups wide (0: row by row)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
@@ -365,11 +364,10 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
   const int nby__ = (P.jml + ROWS__ - 1) / ROWS__;                                        \
   const int rpx__ = (nby__ + 7) / 8, m__ = L__ >> 3;                                      \
   HALO_XCD_ORDER                                                                          \
-  const int by__ = (L__ & 7) * rpx__ + (byl__ + (L__ & 7) * P.g_roty) % rpx__;            \
+  const int by__ = (L__ & 7) * rpx__ + byl__;                                             \
   if (by__ >= nby__) return;                                                              \
   const int lane = g__ & 63;                                                              \
-  const int bxr__ = (bxg__ + (L__ & 7) * P.g_rotx) % nbx__;                               \
-  const int i0 = (bxr__ * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane;                \
+  const int i0 = (bxg__ * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane;                \
   const int j = by__ * ROWS__ + (int)threadIdx.y / COL_WX + 1;
 static inline dim3 grid1_halo_r(const KP &P, int rows) {
   const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + rows - 1) / rows, rpx = (nby + 7) / 8;
@@ -540,8 +538,6 @@ static inline void set_band_geometry(KP &P) {
   P.g_strip = nbx >= 20 ? (nbx + nstr - 1) / nstr : 0;
   const char *es = getenv("POMGPU_COL_STRIP");
   if (es) P.g_strip = atoi(es);
-  P.g_rotx = getenv("POMGPU_COL_ROTX") ? atoi(getenv("POMGPU_COL_ROTX")) : 0;
-  P.g_roty = getenv("POMGPU_COL_ROTY") ? atoi(getenv("POMGPU_COL_ROTY")) : 0;
 }
 
 // kernel launchers implemented in the k_*.hip files (one per fused phase of the step)
