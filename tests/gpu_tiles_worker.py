@@ -1,6 +1,8 @@
 """Launched by tests/test_gpu_multitile.py: 2 ranks, BOTH on GPU 0 (RCCL needs one GPU per rank, so
 the packed edges are staged through the host over gloo), each running the HIP path on its tile with
-the C-ABI exchange hook; rank 0 then compares against the single-tile CPU oracle."""
+the C-ABI exchange hook; rank 0 then compares against the single-tile CPU oracle.
+Mode "rccl" (a node with one GPU per rank): rank r on GPU r, the library's own RCCL transport between the ranks
+(extpom_amd.halo.connect_rccl, both streams and communicators) and the wide-halo external mode -- bench.py's N > 1 path."""
 import os
 import sys
 
@@ -29,7 +31,8 @@ def worker(rank, world, split, port, out, nml):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = rank if mode == "rccl" else 0
+    torch.cuda.set_device(dev)
     from extpom_amd.model import PomGpu
     nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
@@ -39,14 +42,17 @@ def worker(rank, world, split, port, out, nml):
     # the C ABI reads as "create your own", so make a real stream current and hand that over
     ts = torch.cuda.Stream()
     torch.cuda.set_stream(ts)
-    g = PomGpu(st, device=0, stream=ts.cuda_stream)
+    g = PomGpu(st, device=dev, stream=ts.cuda_stream)
     if mode == "hook":
         halo = DeviceHalo(g, tile, torch.device("cuda", 0), staged=True)
         g.set_order_exchange(Halo(tile, staged=True).device_order_hook(torch.device("cuda", 0)))   # baropg_mcc (npg = 2)
     else:                                        # the library serves the exchange points itself (pomgpu_set_transport)
-        from extpom_amd.halo import StagedMover
-        g.set_transport(tile, StagedMover(g, tile, torch.device("cuda", 0)))
-        if mode == "wide":
+        from extpom_amd.halo import StagedMover, connect_rccl
+        if mode == "rccl":
+            assert connect_rccl(g, tile, rank, world), "the RCCL transport could not connect the ranks"
+        else:
+            g.set_transport(tile, StagedMover(g, tile, torch.device("cuda", 0)))
+        if mode in ("wide", "rccl"):
             tiles = [decomp.make_tile(r, IM, JM, iml, jml, n_proc=world) for r in range(world)]
             assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
 
@@ -88,7 +94,7 @@ def main(split, nml, exchange="hook"):
     for r in range(world):
         z = np.load(os.path.join(out, f"tile{r}.npz"))
         io, jo, im, jm = int(z["i_off"]), int(z["j_off"]), int(z["im"]), int(z["jm"])
-        assert int(z["n"]) > (15 if exchange == "wide" else 100), int(z["n"])
+        assert int(z["n"]) > (15 if exchange in ("wide", "rccl") else 100), int(z["n"])
         if r == 0:
             print("message rounds on rank 0:", int(z["n"]))
         sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)
@@ -118,4 +124,4 @@ def main(split, nml, exchange="hook"):
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "x", dict(npg=2) if "npg2" in sys.argv[2:] else {},
-         "wide" if "wide" in sys.argv[2:] else ("transport" if "transport" in sys.argv[2:] else "hook"))
+         "rccl" if "rccl" in sys.argv[2:] else ("wide" if "wide" in sys.argv[2:] else ("transport" if "transport" in sys.argv[2:] else "hook")))

@@ -40,6 +40,23 @@ def test_library_exchange_and_wide_halo_external_mode(args):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [["x", "rccl"], ["xy", "rccl"], ["y", "npg2", "rccl"]])
+def test_rccl_between_distinct_ranks_one_gpu_each(args):
+    """bench.py's N > 1 path as a parity test: rank r on GPU r, the library's RCCL transport (main and side stream, both
+    communicators) and the wide-halo external mode between DIFFERENT ranks; owned cells equal the single-tile oracle bit
+    for bit.  Needs one GPU per rank: skipped on the one-GPU boxes the builder had (the path between two distinct ranks
+    has not run anywhere yet -- DESIGN.md section 7)."""
+    import torch
+    need = 4 if args[0] == "xy" else 2
+    if torch.cuda.device_count() < need:                      # counting devices does not initialise the GPU in this process
+        pytest.skip(f"needs {need} GPUs, this box has {torch.cuda.device_count()}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py")] + args, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 def test_rccl_transport_on_a_periodic_single_rank():
     """The RCCL mover itself, as far as one GPU allows: a communicator of one rank whose tile is its own western
     and eastern neighbour (a periodic channel), so every exchange point and the wide exchange send and receive real
