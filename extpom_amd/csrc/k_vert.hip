@@ -342,10 +342,19 @@ struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 // 2048x1536) -- wavefronts of a CU that drift apart by a few levels cycle through more pages than the CU's first-level
 // TLB holds, and then EVERY access misses (TCP_UTCL1_TRANSLATION_MISS 4.8e7 per launch = 2 of 3 wave accesses, the
 // translation FIFO stalled 27 % of the kernel; 1.7e6 with 8 paced rows -- profiles/round2_tlb_profq.txt).
+#ifndef PROFQ_KL
+#define PROFQ_KL 20
+#endif
 template <int FP, int FF, int ROWS>
 __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
+#ifndef POMGPU_EMU
+  // ee1, ee2 of the first PROFQ_KL levels wait for the walk up in LDS instead of the scratch arrays (a lane reads back what
+  // it wrote itself: no barrier): 2 x 20 x 8 bytes per column is what 160 KB per CU hold at 512 columns per CU
+  __shared__ double evec[2 * PROFQ_KL][ROWS][64];
+#endif
   COL2
   const int rho_rt = rho_rt_pace & 1, pace = rho_rt_pace & 2;
+  const int ty = (int)threadIdx.y, tx = (int)threadIdx.x;
   if (i > P.im || j > P.jm) return;
   const double a1 = 0.92, b1 = 16.6, a2 = 0.74, b2 = 10.1, c1 = 0.08, e1 = 1.8, e2 = 1.33, surfl = 2.e5;
   const int kb = P.kb, kbm1 = P.kbm1;
@@ -482,7 +491,14 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
     // the vectors' level k (level 1: the boundary values; level kb has none -- and uf, vf of level kb stay what they are)
     {
       const unsigned ov = (k <= kbm1) ? oc : BOFF_NONE;
-      bst(be1, ov, lv, e1p); bst(buf, ov, lv, g1p); bst(be2, ov, lv, e2p); bst(bvf, ov, lv, g2p);
+#ifndef POMGPU_EMU
+      const bool inl = k <= PROFQ_KL;                       // wave-uniform
+      if (inl) { evec[k - 1][ty][tx] = e1p; evec[PROFQ_KL + k - 1][ty][tx] = e2p; }
+      const unsigned oe_ = inl ? BOFF_NONE : ov;
+#else
+      const unsigned oe_ = ov;
+#endif
+      bst(be1, oe_, lv, e1p); bst(buf, ov, lv, g1p); bst(be2, oe_, lv, e2p); bst(bvf, ov, lv, g2p);
     }
     // ---- new mixing coefficients -- :1484-1503, cosmetics + mask :1510-1535
     double kq_n = 0., km_n = 0., kh_n = 0.;
@@ -532,7 +548,16 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
   const double hs = .5 * P.smoth;
   auto levb = [&](LevB &L, int k) {             // k = 1..kb
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
-    L.e1 = bld(be1, oc, lv); L.g1 = bld(buf, oc, lv); L.e2 = bld(be2, oc, lv); L.g2 = bld(bvf, oc, lv);
+#ifndef POMGPU_EMU
+    const bool inl = k <= PROFQ_KL;
+    const unsigned oe_ = inl ? BOFF_NONE : oc;              // outside the buffer: no traffic, the value comes from LDS
+#else
+    const unsigned oe_ = oc;
+#endif
+    L.e1 = bld(be1, oe_, lv); L.g1 = bld(buf, oc, lv); L.e2 = bld(be2, oe_, lv); L.g2 = bld(bvf, oc, lv);
+#ifndef POMGPU_EMU
+    if (inl) { L.e1 = evec[k - 1][ty][tx]; L.e2 = evec[PROFQ_KL + k - 1][ty][tx]; }
+#endif
     if (FF) { L.qb = bld(bq2b, oc, lv); L.qlb = bld(bq2lb, oc, lv); L.q = bld(bq2, oc, lv); L.ql = bld(bq2l, oc, lv); }
     else L.qb = L.qlb = L.q = L.ql = 0.;
   };

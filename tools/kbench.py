@@ -66,3 +66,5 @@ if kernels is None:
 print(f"{'min / median (ms)':22s}" + "".join(f"{t[0]:>18s}" for t in variants))
 for n in names:
     print(f"{n:22s}" + "".join(f"{min(t[3].get(n, [0])):9.3f}/{statistics.median(t[3].get(n, [0])):7.3f} " for t in variants))
+sys.stdout.flush()
+os._exit(0)      # contexts shared between builds (=@lib.so) must not be destroyed twice at interpreter exit
