@@ -345,6 +345,9 @@ struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 #ifndef PROFQ_KL
 #define PROFQ_KL 20
 #endif
+#ifndef PROFQ_BIG
+#define PROFQ_BIG 8                                         /* rows per workgroup on large grids */
+#endif
 template <int FP, int FF, int ROWS>
 __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
 #ifndef POMGPU_EMU
@@ -1250,7 +1253,7 @@ void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
   rho_rt = (rho_rt ? 1 : 0) | (getenv("POMGPU_PROFQ_NOPACE") ? 0 : 2);
 #define PQ(FP, FF)                                                                                                                       \
   do {                                                                                                                                   \
-    if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, 8>), dim3((c->P.iml + 63) / 64, (c->P.jml + 7) / 8, 1), dim3(64, 8, 1), c->P, rho_rt); \
+    if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, PROFQ_BIG>), dim3((c->P.iml + 63) / 64, (c->P.jml + PROFQ_BIG - 1) / PROFQ_BIG, 1), dim3(64, PROFQ_BIG, 1), c->P, rho_rt); \
     else LAUNCHN(c, "k_profq", (k_profq<FP, FF, 2>), dim3((c->P.iml + 63) / 64, (c->P.jml + 1) / 2, 1), dim3(64, 2, 1), c->P, rho_rt);       \
   } while (0)
   if (fuse_filter) { if (fuse_prod == 0) PQ(0, 1); else if (fuse_prod == 1) PQ(1, 1); else PQ(2, 1); }
