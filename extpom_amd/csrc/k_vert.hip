@@ -343,7 +343,7 @@ struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 // TLB holds, and then EVERY access misses (TCP_UTCL1_TRANSLATION_MISS 4.8e7 per launch = 2 of 3 wave accesses, the
 // translation FIFO stalled 27 % of the kernel; 1.7e6 with 8 paced rows -- profiles/round2_tlb_profq.txt).
 #ifndef PROFQ_KL
-#define PROFQ_KL 20
+#define PROFQ_KL 19                                         /* 20 = all 160 KB of a CU: see below */
 #endif
 #ifndef PROFQ_BIG
 #define PROFQ_BIG 8                                         /* rows per workgroup on large grids */
@@ -351,9 +351,14 @@ struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 template <int FP, int FF, int ROWS>
 __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
 #ifndef POMGPU_EMU
-  // ee1, ee2 of the first PROFQ_KL levels wait for the walk up in LDS instead of the scratch arrays (a lane reads back what
-  // it wrote itself: no barrier): 2 x 20 x 8 bytes per column is what 160 KB per CU hold at 512 columns per CU
-  __shared__ double evec[2 * PROFQ_KL][ROWS][64];
+  // 8-row workgroups (one per CU): 19 levels = 152 KB.  NOT 20 = the whole 160 KB: a library that merely CONTAINS a kernel with
+  // 163840 bytes of LDS made processes that share one GPU (tests, rehearsals: bench.py --gpus 4 on one card) run one after the
+  // other instead of side by side -- 47.9 against 21.4 ms per step, whether that kernel was launched or not; 155648 bytes do
+  // not (profiles/round2_profq_lds_vectors.txt).  2-row workgroups (small grids, tiles): 9 levels = 18 KB, four per CU.
+  constexpr int KL = ROWS >= 8 ? PROFQ_KL : (PROFQ_KL < 9 ? PROFQ_KL : 9);
+  // ee1, ee2 of the first KL levels wait for the walk up in LDS instead of the scratch arrays (a lane reads back what
+  // it wrote itself: no barrier): 2 x 20 x 8 bytes per column is all that 160 KB per CU could hold at 512 columns per CU
+  __shared__ double evec[2 * KL][ROWS][64];
 #endif
   COL2
   const int rho_rt = rho_rt_pace & 1, pace = rho_rt_pace & 2;
@@ -495,8 +500,8 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
     {
       const unsigned ov = (k <= kbm1) ? oc : BOFF_NONE;
 #ifndef POMGPU_EMU
-      const bool inl = k <= PROFQ_KL;                       // wave-uniform
-      if (inl) { evec[k - 1][ty][tx] = e1p; evec[PROFQ_KL + k - 1][ty][tx] = e2p; }
+      const bool inl = k <= KL;                             // wave-uniform
+      if (inl) { evec[k - 1][ty][tx] = e1p; evec[KL + k - 1][ty][tx] = e2p; }
       const unsigned oe_ = inl ? BOFF_NONE : ov;
 #else
       const unsigned oe_ = ov;
@@ -552,14 +557,14 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
   auto levb = [&](LevB &L, int k) {             // k = 1..kb
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
 #ifndef POMGPU_EMU
-    const bool inl = k <= PROFQ_KL;
+    const bool inl = k <= KL;
     const unsigned oe_ = inl ? BOFF_NONE : oc;              // outside the buffer: no traffic, the value comes from LDS
 #else
     const unsigned oe_ = oc;
 #endif
     L.e1 = bld(be1, oe_, lv); L.g1 = bld(buf, oc, lv); L.e2 = bld(be2, oe_, lv); L.g2 = bld(bvf, oc, lv);
 #ifndef POMGPU_EMU
-    if (inl) { L.e1 = evec[k - 1][ty][tx]; L.e2 = evec[PROFQ_KL + k - 1][ty][tx]; }
+    if (inl) { L.e1 = evec[k - 1][ty][tx]; L.e2 = evec[KL + k - 1][ty][tx]; }
 #endif
     if (FF) { L.qb = bld(bq2b, oc, lv); L.qlb = bld(bq2lb, oc, lv); L.q = bld(bq2, oc, lv); L.ql = bld(bq2l, oc, lv); }
     else L.qb = L.qlb = L.q = L.ql = 0.;
