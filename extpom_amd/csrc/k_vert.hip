@@ -13,6 +13,12 @@
 #define v_(i, j, k) F3(v, i, j, k)
 #define w_(i, j, k) F3(w, i, j, k)
 
+// Register-resident column kernels: rows per workgroup, same-context A/B at 2048x1536x50 (profiles/round2_reg_kernel_rows.txt):
+// profu / profv (one wave per SIMD) 1 row -7 / -3 % against 2, 4 rows +16 %; uv_filter, int_uvmean 4 rows -4.5 / -3 %; proft 1 row -0.7 %
+#define ROWS_PROFUV 1
+#define ROWS_PROFT 1
+#define ROWS_UVF 4
+#define ROWS_UVM 4
 #define COL2                               \
   const int i = TID_I, j = TID_J;          \
   if (i > P.iml || j > P.jml) return;
@@ -723,7 +729,7 @@ __global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsu
 // expression sequence as k_proft.  When SW = 0 the term dti2*(rad(k)-rad(k+1))/(dh*dz(k)) is +0
 // exactly (dti2 > 0, dh*dz > 0), written as "+ 0.".
 template <int KBT, int SW>
-__global__ void __launch_bounds__(128) k_proft_reg(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+__global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double r_[5] = {.58, .62, .67, .77, .78}, ad1_[5] = {.35, .60, 1.0, 1.5, 1.4}, ad2_[5] = {23., 20., 17., 14., 7.9};
@@ -996,7 +1002,7 @@ __global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
 // Phase A loads the whole column into the future ee/gg registers, phase B is the forward
 // elimination (solver.f:1712-1745 / :1810-1843), phase C the bottom value and back substitution.
 template <int KBT, int V>
-__global__ void __launch_bounds__(128) k_profuv_reg(KP P) {
+__global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg(KP P) {
   const int j = TID_J;
   if (j > P.jm) return;
   int i0, lane = 1;
@@ -1134,7 +1140,7 @@ __global__ void k_uv_filter(KP P) {
 // column once for the depth mean and again to correct it (4 reads + 2 writes for both components);
 // with the level loop unrolled for a template bound >= kb the column waits in registers: 1 read + 1 write.
 template <int KBT, int V>
-__global__ void __launch_bounds__(128) k_int_uvmean_reg(KP P) {
+__global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg(KP P) {
   COL2
   double *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.a3;
   const int kbm1 = P.kbm1;
@@ -1166,7 +1172,7 @@ __global__ void __launch_bounds__(128) k_int_uvmean_reg(KP P) {
 // second sweep needs no memory: 3 reads + 2 writes per component.  u and ub of the whole column are
 // requested up front into their final registers; uf streams through two small chunk buffers.
 template <int KBT, int V>
-__global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
+__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.a3;
@@ -1217,6 +1223,8 @@ __global__ void __launch_bounds__(128) k_uv_filter_reg(KP P) {
 
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 colblk() { return dim3(64, 2, 1); }
+static inline dim3 rowblk(int rows) { return dim3(64, rows, 1); }
+static inline dim3 rowgrid(const KP &P, int rows) { return dim3((P.iml + 63) / 64, (P.jml + rows - 1) / rows, 1); }
 static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml + 1) / 2, 1); }
 // baropg, vertvl: four paced rows per workgroup (same-context A/B against 2 unpaced rows: -2..-3 %; 8 rows: +3 % on baropg)
 #define COLV_G(P) dim3(((P).iml + 63) / 64, ((P).jml + 3) / 4, 1)
@@ -1229,8 +1237,8 @@ void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n) {
   LAUNCH(c, k_order_pack, dim3((len + 63) / 64, P.kb + 1, 1), dim3(64, 1, 1), c->P, send_e, send_n);
 }
 template <int KBT> static void launch_int_uvmean_reg_t(pomgpu_ctx *c) {
-  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 0>), colgrid(c->P), colblk(), c->P);
-  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 1>), colgrid(c->P), colblk(), c->P);
+  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 0>), rowgrid(c->P, ROWS_UVM), rowblk(ROWS_UVM), c->P);
+  LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 1>), rowgrid(c->P, ROWS_UVM), rowblk(ROWS_UVM), c->P);
 }
 void launch_int_uvmean(pomgpu_ctx *c) {
   const int kb = c->P.kb;
@@ -1272,8 +1280,8 @@ void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
 }
 template <int KBT>
 static void launch_proft_reg(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
-  if (nbc == 2 || nbc == 4) LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 1>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
-  else LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 0>), colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  if (nbc == 2 || nbc == 4) LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 1>), rowgrid(c->P, ROWS_PROFT), rowblk(ROWS_PROFT), c->P, f, wfsurf, fsurf, nbc);
+  else LAUNCHN(c, "k_proft_reg", (k_proft_reg<KBT, 0>), rowgrid(c->P, ROWS_PROFT), rowblk(ROWS_PROFT), c->P, f, wfsurf, fsurf, nbc);
 }
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   const int kb = c->P.kb;
@@ -1290,8 +1298,8 @@ void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_adv
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advv_profv, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
 template <int KBT> static void launch_profuv_reg_t(pomgpu_ctx *c) {
   const KP &P = c->P;
-  LAUNCHN(c, "k_profu_reg", (k_profuv_reg<KBT, 0>), dim3((P.iml + 61) / 62, (P.jml + 1) / 2, 1), colblk(), c->P);
-  LAUNCHN(c, "k_profv_reg", (k_profuv_reg<KBT, 1>), colgrid(P), colblk(), c->P);
+  LAUNCHN(c, "k_profu_reg", (k_profuv_reg<KBT, 0>), dim3((P.iml + 61) / 62, (P.jml + ROWS_PROFUV - 1) / ROWS_PROFUV, 1), rowblk(ROWS_PROFUV), c->P);
+  LAUNCHN(c, "k_profv_reg", (k_profuv_reg<KBT, 1>), rowgrid(P, ROWS_PROFUV), rowblk(ROWS_PROFUV), c->P);
 }
 int launch_profuv_reg(pomgpu_ctx *c) {
   const int kb = c->P.kb;
@@ -1306,8 +1314,8 @@ int launch_profuv_reg(pomgpu_ctx *c) {
   return 1;
 }
 template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c) {
-  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), colgrid(c->P), colblk(), c->P);
-  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), colgrid(c->P), colblk(), c->P);
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
 }
 static int launch_uv_filter_reg(pomgpu_ctx *c) {
   const int kb = c->P.kb;
