@@ -6,6 +6,7 @@
 // Fusion rule used throughout: all statements of the reference between two halo-exchange points
 // become ONE kernel; neighbour values of intermediates that the reference stored in scratch arrays
 // (fluxua, fluxva) are recomputed in registers where that needs no data from beyond the tile.
+#include <type_traits>
 #include "pomgpu_internal.hpp"
 
 // ua, va, d, el, elb are read through KP.x2 and written through KP.y2 in this file: the fused external
@@ -750,6 +751,208 @@ __device__ __forceinline__ void ext_step_body(const KP &P, int store_f, int rim_
 template <int FUSE_ADV>
 __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) { ext_step_body<FUSE_ADV>(P, store_f, rim_rows); }
 
+// ---- the same substep (advave fused), MARCHING DOWN THE ROWS: large tiles ----------------------------------------------
+// k_ext_step<1> is one wavefront per row segment of 62 cells: 58 loads, then ~650 fp64 instructions that all wait for them,
+// two wavefronts per SIMD (251 VGPRs).  The counters (2048x1536): a wavefront lives ~8.5 us and waits 57 % of it; the kernel
+// is 51 such lifetimes per SIMD / 2 -- bound by that latency, and every stencil row is fetched 1.75 times.  Here a wavefront
+// owns `rows` consecutive rows of its 62 columns and walks down them like the column kernels walk down the levels:
+//  * the operands of rows j-1, j, j+1 stay in registers; a row costs ONE new row of the eight stencil arrays (requested an
+//    iteration ahead) + the 18 pointwise operands of row j (requested at the top of the iteration, used in its second half),
+//    26 + 6 loads instead of 58 + 6;
+//  * what row j+1 recomputed from the same operands is carried instead: the new elevation of row j-1 (es), the fluxes
+//    fluxva(j), and advave's tps / fluxva(u) / fluxva(v) of the row above -- the SAME expressions on
+//    the SAME operands, so the bits do not change;
+//  * no load or store sits in a branch (vmcnt bookkeeping, as in the level loops): lanes / substeps with nothing to move aim
+//    outside the buffer; lane 0's two true western operands are one-lane loads (every other lane aims outside).
+// A segment starts one row early (a warm-up row whose stores are disabled) to fill the carried values.
+struct ExtRow { double d, ua, va, dx, dy, uab, vab, am, dW, dyW; };   // one row of the stencil operands; dW, dyW: column i-1
+#ifndef POMGPU_EMU
+// the western neighbour's value, true on lane 0 as well (w: the one-lane load).  The shift is made by ALL lanes before the
+// select: inside the arm of a ?: it would run with lane 0 switched off, and lane 1 would read a disabled lane
+__device__ __forceinline__ double west_true(double x, double w, int lane) {
+  const double t = wave_up1(x);
+  return lane == 0 ? w : t;
+}
+#endif
+__global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;   // (the host emulation runs lanes as blocks of width 1)
+  if (wg < rim_wgs) { ext_rim_cell(P, wg * 256 + (int)threadIdx.y * 64 + lane, store_f, 1); return; }
+  const int L = wg - rim_wgs, nbx = (P.iml + 61) / 62;
+  const int bx = L % nbx, seg = (L / nbx) * (int)blockDim.y + (int)threadIdx.y;
+  const int j0 = 3 + seg * rows;
+  if (j0 > P.jmm1) return;                                 // a whole wavefront
+  const int j1 = (j0 + rows - 1 < P.jmm1) ? j0 + rows - 1 : P.jmm1;
+  const int i0 = bx * 62 + lane;
+  const bool out = (lane >= 1 && lane <= 62 && i0 >= 3 && i0 <= P.imm1);
+#ifdef POMGPU_EMU
+  if (!out) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);    // halo / padding lanes shadow a valid column
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+  const unsigned vo = (unsigned)(i - 1) * 8u;
+#ifdef POMGPU_EMU
+  const unsigned voW = (unsigned)(iw - 1) * 8u;
+#define WTRUE(x, w) (w)
+#else
+  const unsigned voW = (lane == 0) ? (unsigned)(iw - 1) * 8u : BOFF_NONE;
+#define WTRUE(x, w) west_true((x), (w), lane)
+#endif
+#define RO(row) ((unsigned)WAVE_UNIFORM((row) - 1) * (unsigned)P.iml * 8u)
+#define XD(g) buf2_of(P.x2[g], P.n2)
+#define YD(g) buf2_of(P.y2[g], P.n2)
+// every blk2d array through ONE descriptor (the block is contiguous; < 4 GiB checked by the launcher): the array's offset
+// rides in the scalar offset -- a descriptor per array (4 SGPRs each, ~30 of them) spilled 220 SGPRs
+#define FLD(name, voff, ro_) bld2(b2d, (voff), (unsigned)(P2_##name * P.n2 * 8u) + (ro_))
+#define FST(name, voff, ro_, x) bst2(b2d, (voff), (unsigned)(P2_##name * P.n2 * 8u) + (ro_), (x))
+#define WS(x, expr) halo_w(x, [&] { return expr; })
+#define ES(x, expr) halo_e(x, [&] { return expr; })
+  const BufA b2d = buf2_of(P.b2, (size_t)POM_NBLK2D * P.n2);
+  auto load_row = [&](int row) {
+    ExtRow r;
+    const unsigned ro = RO(row);
+    r.d = bld2(XD(X2_d), vo, ro); r.ua = bld2(XD(X2_ua), vo, ro); r.va = bld2(XD(X2_va), vo, ro);
+    r.dx = FLD(dx, vo, ro); r.dy = FLD(dy, vo, ro);
+    r.uab = bld2(XD(X2_uab), vo, ro); r.vab = bld2(XD(X2_vab), vo, ro); r.am = FLD(aam2d, vo, ro);
+    r.dW = bld2(XD(X2_d), voW, ro); r.dyW = FLD(dy, voW, ro);
+    return r;
+  };
+  // uniform conditions of the substep (advance.f:295-347) as store / load offsets
+  const bool acc = (P.iext != P.isplit);
+  const unsigned o_etf_ld = (P.iext >= P.isplit - 1) ? vo : BOFF_NONE, o_acc_ld = acc ? vo : BOFF_NONE;
+  // rows jw-1, jw, jw+1 (jw = j0-1: the warm-up row)
+  const int jw = j0 - 1;
+  ExtRow rm = load_row(jw - 1), rc = load_row(jw), rp = load_row(jw + 1);
+  rm.dW = WTRUE(rm.d, rm.dW); rm.dyW = WTRUE(rm.dy, rm.dyW);
+  rc.dW = WTRUE(rc.d, rc.dW); rc.dyW = WTRUE(rc.dy, rc.dyW);
+  rp.dW = WTRUE(rp.d, rp.dW); rp.dyW = WTRUE(rp.dy, rp.dyW);
+  // pointwise operands of row jw-1 that the momentum equations read at j-1: filled by the warm-up row itself (rotation below)
+  double el_m1 = 0., elb_m1 = 0., ea_m1 = 0., h_m1 = 0., cor_m1 = 0.;
+  // carried: only fluxva(jw) must be right before the warm-up row; the others are produced by it
+  double fva_0 = .25 * (rc.d + rm.d) * (rc.dx + rm.dx) * rc.va;
+  double es = 0., tps0 = 0., fv0 = 0., gvM = 0.;
+  const bool fu_on = (i0 >= 2 && i0 <= P.imm1), w_on = (i0 >= 2 && i0 <= P.im);
+  // one row; LIVE = false: the warm-up row -- only what the carried values need (no momentum, no stores, 9 of the 22 pointwise loads)
+  auto row_step = [&](const int j, auto live_tag) {
+    constexpr bool LIVE = decltype(live_tag)::value;
+    const unsigned ro = RO(j);
+    // ---- requests: the pointwise operands of this row first (used below), then the stencil row of the next iteration
+    const double el_0 = bld2(XD(X2_el), vo, ro), elb_0 = bld2(XD(X2_elb), vo, ro);
+    const double art_0 = FLD(art, vo, ro), vfl_0 = FLD(vfluxf, vo, ro);
+    const unsigned mk_0 = P.m8[(size_t)WAVE_UNIFORM(j - 1) * (size_t)P.iml + (size_t)(i - 1)];
+    const double ea_0 = FLD(e_atmos, vo, ro), h_0 = FLD(h, vo, ro), cor_0 = FLD(cor, vo, ro);
+    double adx2d = 0., aru = 0., drx2d = 0., wusurf = 0., wubot = 0., ady2d = 0., arv = 0., dry2d = 0., wvsurf = 0., wvbot = 0.;
+    double etf_o = 0., egf_o = 0., utf_o = 0., vtf_o = 0.;
+    if (LIVE) {
+      adx2d = FLD(adx2d, vo, ro); aru = FLD(aru, vo, ro); drx2d = FLD(drx2d, vo, ro);
+      wusurf = FLD(wusurf, vo, ro); wubot = FLD(wubot, vo, ro);
+      ady2d = FLD(ady2d, vo, ro); arv = FLD(arv, vo, ro); dry2d = FLD(dry2d, vo, ro);
+      wvsurf = FLD(wvsurf, vo, ro); wvbot = FLD(wvbot, vo, ro);
+      etf_o = FLD(etf, o_etf_ld, ro); egf_o = FLD(egf, o_acc_ld, ro); utf_o = FLD(utf, o_acc_ld, ro); vtf_o = FLD(vtf, o_acc_ld, ro);
+    }
+    ExtRow rn = load_row(j + 2 <= P.jml ? j + 2 : P.jml);
+    const double fsm_0 = (double)(mk_0 & 1u), dum_0 = (double)((mk_0 >> 1) & 1u), dvm_0 = (double)((mk_0 >> 2) & 1u);
+    const unsigned o_st = out ? vo : BOFF_NONE;
+    // ---- neighbour-lane operands (rows m1 = j-1: rm, 0 = j: rc, p1 = j+1: rp)
+    const double dxW_0 = WS(rc.dx, dx_(iw, j)), dxW_p1 = WS(rp.dx, dx_(iw, j + 1));
+    const double corW_0 = WS(cor_0, F2(cor, iw, j)), vaW_0 = WS(rc.va, va_(iw, j)), vaW_p1 = WS(rp.va, va_(iw, j + 1));
+    const double elW_0 = WS(el_0, el_(iw, j)), elbW_0 = WS(elb_0, elb_(iw, j)), eaW_0 = WS(ea_0, F2(e_atmos, iw, j)), hW_0 = WS(h_0, F2(h, iw, j));
+    const double uaE_0 = ES(rc.ua, ua_(ie, j)), uaE_m1 = ES(rm.ua, ua_(ie, j - 1));
+    // ---- continuity (advance.f:211-231) at (i,j); (i,j-1) is the row above's, the west value the neighbour lane's
+    const double dysx_0 = rc.dy + rc.dyW, dxsy_0 = rc.dx + rm.dx, dxsy_p1 = rp.dx + rc.dx;
+    const double fua_0 = .25 * (rc.d + rc.dW) * dysx_0 * rc.ua;
+    const double fuaE_0 = ES(fua_0, flux_ua(P, ie, j));
+    const double fva_p1 = .25 * (rp.d + rc.d) * dxsy_p1 * rp.va;
+    const double ec = (elb_0 + P.dte2 * (-(fuaE_0 - fua_0 + fva_p1 - fva_0) / art_0 - vfl_0)) * fsm_0;
+    const double ew = WS(ec, elf_at(P, iw, j));
+    // ---- advave (solver.f:16-121) on register operands, as advave_cell; tps0, fv0, gvM are the row above's tpsP, fvP, gv0
+    double fu = 0., gu = 0., fvP = 0., gv0 = 0., tpsP = 0.;
+    {
+      const double dE_0 = ES(rc.d, d_(ie, j)), uabE_0 = ES(rc.uab, uab_(ie, j));
+      const double vabW_p1 = WS(rp.vab, vab_(iw, j + 1));
+      const double amW_0 = WS(rc.am, aam2d_(iw, j)), amW_p1 = WS(rp.am, aam2d_(iw, j + 1));
+      const double DY4_0 = rc.dy + rc.dyW + rm.dy + rm.dyW, DY4_p1 = rp.dy + rp.dyW + rc.dy + rc.dyW;
+      const double DX4_p1 = rp.dx + dxW_p1 + rc.dx + dxW_0;
+      if (LIVE && fu_on) {
+        double f = .125 * ((dE_0 + rc.d) * uaE_0 + (rc.d + rc.dW) * rc.ua) * (uaE_0 + rc.ua);
+        f = f - rc.d * 2. * rc.am * (uabE_0 - rc.uab) / rc.dx;
+        fu = f * rc.dy;
+      }
+      if (w_on) {
+        tpsP = .25 * (rp.d + rp.dW + rc.d + rc.dW) * (rp.am + rc.am + amW_p1 + amW_0) *
+               ((rp.uab - rc.uab) / DY4_p1 + (rp.vab - vabW_p1) / DX4_p1);
+        if (LIVE) {
+          const double g = .125 * ((rc.d + rc.dW) * rc.ua + (rm.d + rm.dW) * rm.ua) * (vaW_0 + rc.va);
+          gu = (g - tps0) * .25 * DY4_0;
+        }
+        const double fP = .125 * ((rp.d + rc.d) * rp.va + (rp.dW + rc.dW) * vaW_p1) * (rp.ua + rc.ua);
+        fvP = (fP - tpsP) * .25 * DX4_p1;
+        double gv = .125 * ((rp.d + rc.d) * rp.va + (rc.d + rm.d) * rc.va) * (rp.va + rc.va);
+        gv = gv - rc.d * 2. * rc.am * (rp.vab - rc.vab) / rc.dy;
+        gv0 = gv * rc.dx;
+      }
+    }
+    if (LIVE) {
+      const double fu_w = WS(fu, advave_fu(P, i - 1, j));
+      const double gu_e = ES(gu, (i + 1 <= P.im) ? advave_gu(P, i + 1, j, advave_tps(P, i + 1, j)) : 0.);
+      const double advua = fu - fu_w + fvP - fv0;             // :65-66
+      const double advva = gu_e - gu + gv0 - gvM;             // :116-117
+      // ---- momentum (:237-290), as uaf_interior / vaf_interior
+      double u = adx2d + advua - aru * .25 * (cor_0 * rc.d * (rp.va + rc.va) + corW_0 * rc.dW * (vaW_p1 + vaW_0)) +
+                 .25 * P.grav * dysx_0 * (rc.d + rc.dW) *
+                     ((1. - 2. * P.alpha) * (el_0 - elW_0) + P.alpha * (elb_0 - elbW_0 + ec - ew) + ea_0 - eaW_0) +
+                 drx2d + aru * (wusurf - wubot);
+      u = ((h_0 + elb_0 + hW_0 + elbW_0) * aru * rc.uab - 4. * P.dte * u) / ((h_0 + ec + hW_0 + ew) * aru);
+      double v = ady2d + advva + arv * .25 * (cor_0 * rc.d * (uaE_0 + rc.ua) + cor_m1 * rm.d * (uaE_m1 + rm.ua)) +
+                 .25 * P.grav * dxsy_0 * (rc.d + rm.d) *
+                     ((1. - 2. * P.alpha) * (el_0 - el_m1) + P.alpha * (elb_0 - elb_m1 + ec - es) + ea_0 - ea_m1) +
+                 dry2d + arv * (wvsurf - wvbot);
+      v = ((h_0 + elb_0 + h_m1 + elb_m1) * arv * rc.vab - 4. * P.dte * v) / ((h_0 + ec + h_m1 + es) * arv);
+      u = u * dum_0;
+      v = v * dvm_0;
+      // ---- stores: the new generation, etf weights, accumulation (:295-347), as ext_update_cell
+      {
+        const unsigned o_f = store_f ? o_st : BOFF_NONE;
+        FST(elf, o_f, ro, ec); FST(uaf, o_f, ro, u); FST(vaf, o_f, ro, v);
+        FST(advua, o_f, ro, advua); FST(advva, o_f, ro, advva);
+        double etf_n = 0.;
+        if (P.iext == P.isplit - 2) etf_n = .25 * P.smoth * ec;
+        else if (P.iext == P.isplit - 1) etf_n = etf_o + .5 * (1. - .5 * P.smoth) * ec;
+        else if (P.iext == P.isplit) etf_n = (etf_o + .5 * ec) * fsm_0;
+        FST(etf, (P.iext >= P.isplit - 2) ? o_st : BOFF_NONE, ro, etf_n);
+        bst2(YD(X2_uab), o_st, ro, rc.ua + .5 * P.smoth * (rc.uab - 2. * rc.ua + u));
+        bst2(YD(X2_vab), o_st, ro, rc.va + .5 * P.smoth * (rc.vab - 2. * rc.va + v));
+        bst2(YD(X2_elb), o_st, ro, el_0 + .5 * P.smoth * (elb_0 - 2. * el_0 + ec));
+        bst2(YD(X2_el), o_st, ro, ec);
+        const double dn = h_0 + ec;
+        bst2(YD(X2_d), o_st, ro, dn);
+        bst2(YD(X2_ua), o_st, ro, u);
+        bst2(YD(X2_va), o_st, ro, v);
+        const unsigned o_acc = acc ? o_st : BOFF_NONE;
+        FST(egf, o_acc, ro, egf_o + ec * P.ispi);
+        FST(utf, o_acc, ro, utf_o + u * (dn + (hW_0 + ew)) * P.isp2i);
+        FST(vtf, o_acc, ro, vtf_o + v * (dn + (h_m1 + es)) * P.isp2i);
+      }
+    }
+    // ---- one row down
+    fva_0 = fva_p1; es = ec;
+    tps0 = tpsP; fv0 = fvP; gvM = gv0;
+    el_m1 = el_0; elb_m1 = elb_0; ea_m1 = ea_0; h_m1 = h_0; cor_m1 = cor_0;
+    rm = rc; rc = rp;
+    rn.dW = WTRUE(rn.d, rn.dW); rn.dyW = WTRUE(rn.dy, rn.dyW);
+    rp = rn;
+  };
+  row_step(jw, std::false_type());
+  for (int j = j0; j <= j1; j++) row_step(j, std::true_type());
+#undef WTRUE
+#undef RO
+#undef XD
+#undef YD
+#undef FLD
+#undef FST
+#undef WS
+#undef ES
+}
+
 // ---- all the external substeps of an internal step in ONE launch (small tiles) ------------------------------------------
 // On a small tile a substep's kernel is a few wavefronts per CU on a chain of dependent loads: ~20 us each, 30 of them per
 // internal step, whatever the grid size (256x256x30: 0.68 of 1.34 ms per step) -- a launch boundary costs more than the
@@ -881,6 +1084,16 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, 0);
     LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
     return;
+  }
+  if (fuse_adv && !getenv("POMGPU_EXT_NOMARCH")) {            // large tiles: a wavefront marches down `rows` rows (k_ext_march)
+    int rows = 8;
+    if (getenv("POMGPU_EXT_ROWS")) rows = atoi(getenv("POMGPU_EXT_ROWS"));
+    const int nseg = (Q.jmm1 - 3 + 1 + rows - 1) / rows, nbx = (int)g.x;
+    if (rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
+      const int rim_wgs = (n + 255) / 256;
+      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + nbx * ((nseg + 3) / 4)), 1, 1), blk2(), Q, store_f, rim_wgs, rows);
+      return;
+    }
   }
   const int per_row = (int)g.x * 256, rim_rows = (n + per_row - 1) / per_row;
   g.y += rim_rows;

@@ -236,6 +236,27 @@ static inline BufA buf_of(const double *p, size_t) { BufA b; b.p = (double *)p; 
 static inline double bld(const BufA &b, unsigned voff, unsigned soff) { return voff >= 0xFFFFFFF0u ? 0. : b.p[((size_t)voff + soff) >> 3]; }
 static inline void bst(const BufA &b, unsigned voff, unsigned soff, double x) { if (voff < 0xFFFFFFF0u) b.p[((size_t)voff + soff) >> 3] = x; }
 #endif
+// 2-D arrays are fp64 in every build: buffer helpers that do not follow the storage type of the 3-D arrays
+#ifndef POMGPU_EMU
+__device__ __forceinline__ BufA buf2_of(const double *p, size_t doubles) {
+  BufA b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (unsigned)(doubles * 8), 0x00020000);
+  return b;
+}
+__device__ __forceinline__ double bld2(const BufA &b, unsigned voff, unsigned soff) {
+  const pomgpu_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void bst2(const BufA &b, unsigned voff, unsigned soff, double x) {
+  pomgpu_u32x2 v;
+  v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
+}
+#else
+static inline BufA buf2_of(const double *p, size_t) { BufA b; b.p = (double *)p; return b; }
+static inline double bld2(const BufA &b, unsigned voff, unsigned soff) { return voff >= 0xFFFFFFF0u ? 0. : b.p[((size_t)voff + soff) >> 3]; }
+static inline void bst2(const BufA &b, unsigned voff, unsigned soff, double x) { if (voff < 0xFFFFFFF0u) b.p[((size_t)voff + soff) >> 3] = x; }
+#endif
 // per-lane offset of a lane that must not store: outside every descriptor, the hardware drops the access (loads return 0;
 // tools/micro/buf_oob.hip).  A branch around a store or load inside a software-pipelined loop costs far more than the
 // wasted lanes: where the paths join the compiler no longer knows how many memory operations are outstanding and waits
