@@ -1086,10 +1086,11 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     return;
   }
   if (fuse_adv && !getenv("POMGPU_EXT_NOMARCH")) {            // large tiles: a wavefront marches down `rows` rows (k_ext_march)
-    int rows = 8;
+    int rows = 7;                                             // kbench at 2048x1536: 5-9 rows within 2 %, 13 +5 %, 26 and more +16 %
     if (getenv("POMGPU_EXT_ROWS")) rows = atoi(getenv("POMGPU_EXT_ROWS"));
     const int nseg = (Q.jmm1 - 3 + 1 + rows - 1) / rows, nbx = (int)g.x;
-    if (rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
+    const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
+    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
       const int rim_wgs = (n + 255) / 256;
       LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + nbx * ((nseg + 3) / 4)), 1, 1), blk2(), Q, store_f, rim_wgs, rows);
       return;

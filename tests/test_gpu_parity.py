@@ -275,7 +275,7 @@ def test_config2_seamount_256x256x30_matches_oracle():
 @pytest.mark.parametrize("switches", [("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
                                        "POMGPU_REALVERTVL_CELLS"), ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"),
                                       ("POMGPU_EXT_LOOP",), ("POMGPU_RHO_ROUNDTRIP", "POMGPU_TAU_ARRAYS", "POMGPU_IO_SYNC"),
-                                      ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP"), ("POMGPU_PROFQ_ROWS2", "POMGPU_PROFQ_NOPACE")])
+                                      ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH"), ("POMGPU_PROFQ_ROWS2", "POMGPU_PROFQ_NOPACE", "POMGPU_EXT_NOMARCH")])
 def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
     multi-tile runs, selected through the library's developer switches, on an even and an odd grid; second set: the

@@ -148,7 +148,7 @@ FALLBACK_ENV = ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "
                 "POMGPU_REALVERTVL_CELLS")
 
 
-@pytest.mark.parametrize("switches", [FALLBACK_ENV, ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"), ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP")])
+@pytest.mark.parametrize("switches", [FALLBACK_ENV, ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"), ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH")])
 def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
     multi-tile runs stay bit-identical too (selected here through the library's developer switches); second set:
