@@ -777,8 +777,15 @@ __device__ __forceinline__ double west_true(double x, double w, int lane) {
 __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;   // (the host emulation runs lanes as blocks of width 1)
   if (wg < rim_wgs) { ext_rim_cell(P, wg * 256 + (int)threadIdx.y * 64 + lane, store_f, 1); return; }
+  // Workgroups are dealt to the XCDs round-robin (linear id & 7; rim_wgs is a multiple of 8): XCD x owns a band of segment
+  // groups and walks it row by row, so that the wavefronts to the left and right of this one -- whose 64 columns overlap its
+  // own by two, and whose 512-byte row pieces share a 128-byte line with it (a piece starts every 496 bytes: five lines per
+  // load, not four) -- sit behind the same L2
   const int L = wg - rim_wgs, nbx = (P.iml + 61) / 62;
-  const int bx = L % nbx, seg = (L / nbx) * (int)blockDim.y + (int)threadIdx.y;
+  const int nseg_ = (P.jmm1 - 3 + 1 + rows - 1) / rows, ngrp = (nseg_ + (int)blockDim.y - 1) / (int)blockDim.y, gpx = (ngrp + 7) / 8;
+  const int m_ = L >> 3, grp = (L & 7) * gpx + m_ / nbx;
+  if (grp >= ngrp) return;
+  const int bx = m_ % nbx, seg = grp * (int)blockDim.y + (int)threadIdx.y;
   const int j0 = 3 + seg * rows;
   if (j0 > P.jmm1) return;                                 // a whole wavefront
   const int j1 = (j0 + rows - 1 < P.jmm1) ? j0 + rows - 1 : P.jmm1;
@@ -1091,8 +1098,8 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     const int nseg = (Q.jmm1 - 3 + 1 + rows - 1) / rows, nbx = (int)g.x;
     const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
     if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
-      const int rim_wgs = (n + 255) / 256;
-      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + nbx * ((nseg + 3) / 4)), 1, 1), blk2(), Q, store_f, rim_wgs, rows);
+      const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
+      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows);
       return;
     }
   }
