@@ -751,6 +751,22 @@ __device__ __forceinline__ void ext_step_body(const KP &P, int store_f, int rim_
 template <int FUSE_ADV>
 __global__ void __launch_bounds__(256) k_ext_step(KP P, int store_f, int rim_rows) { ext_step_body<FUSE_ADV>(P, store_f, rim_rows); }
 
+// art = dx*dy; aru, arv = .25*(dx+dx')*(dy+dy') (initialize.f:361-367): true of the arrays the host handed over?  *flag stays
+// non-zero if every cell agrees bit for bit.  The arrays are the caller's: the formulas are only USED after this check.
+__global__ void k_check_areas(KP P, int *flag) {
+  const int i = TID_I, j = TID_J;
+  if (i > P.im || j > P.jm) return;
+  bool ok = F2(art, i, j) == dx_(i, j) * dy_(i, j);
+  if (i >= 2 && j >= 2) {
+    ok = ok && F2(aru, i, j) == .25 * (dx_(i, j) + dx_(i - 1, j)) * (dy_(i, j) + dy_(i - 1, j));
+    ok = ok && F2(arv, i, j) == .25 * (dx_(i, j) + dx_(i, j - 1)) * (dy_(i, j) + dy_(i, j - 1));
+  }
+  if (!ok) *flag = 0;
+}
+void launch_check_areas(pomgpu_ctx *c) {
+  (void)hipMemsetAsync(c->d_areas, 1, sizeof(int), c->cur);   // 0x01010101: "canonical" until a cell disagrees
+  LAUNCH(c, k_check_areas, grid2(c->P), blk2(), c->P, c->d_areas);
+}
 // ---- the same substep (advave fused), MARCHING DOWN THE ROWS: large tiles ----------------------------------------------
 // k_ext_step<1> is one wavefront per row segment of 62 cells: 58 loads, then ~650 fp64 instructions that all wait for them,
 // two wavefronts per SIMD (251 VGPRs).  The counters (2048x1536): a wavefront lives ~8.5 us and waits 57 % of it; the kernel
@@ -774,7 +790,7 @@ __device__ __forceinline__ double west_true(double x, double w, int lane) {
   return lane == 0 ? w : t;
 }
 #endif
-__global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows) {
+__global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows, const int *areas, int use_areas) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;   // (the host emulation runs lanes as blocks of width 1)
   if (wg < rim_wgs) { ext_rim_cell(P, wg * 256 + (int)threadIdx.y * 64 + lane, store_f, 1); return; }
   // Workgroups are dealt to the XCDs round-robin (linear id & 7; rim_wgs is a multiple of 8): XCD x owns a band of segment
@@ -824,6 +840,9 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
     return r;
   };
   // uniform conditions of the substep (advance.f:295-347) as store / load offsets
+  // art, aru, arv from dx, dy where k_check_areas found the arrays to be exactly that (else: read them)
+  const bool canon = use_areas && WAVE_UNIFORM(*areas) != 0;
+  const unsigned o_area = canon ? BOFF_NONE : vo;
   const bool acc = (P.iext != P.isplit);
   const unsigned o_etf_ld = (P.iext >= P.isplit - 1) ? vo : BOFF_NONE, o_acc_ld = acc ? vo : BOFF_NONE;
   // rows jw-1, jw, jw+1 (jw = j0-1: the warm-up row)
@@ -844,15 +863,15 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
     const unsigned ro = RO(j);
     // ---- requests: the pointwise operands of this row first (used below), then the stencil row of the next iteration
     const double el_0 = bld2(XD(X2_el), vo, ro), elb_0 = bld2(XD(X2_elb), vo, ro);
-    const double art_0 = FLD(art, vo, ro), vfl_0 = FLD(vfluxf, vo, ro);
+    const double art_l = FLD(art, o_area, ro), vfl_0 = FLD(vfluxf, vo, ro);
     const unsigned mk_0 = P.m8[(size_t)WAVE_UNIFORM(j - 1) * (size_t)P.iml + (size_t)(i - 1)];
     const double ea_0 = FLD(e_atmos, vo, ro), h_0 = FLD(h, vo, ro), cor_0 = FLD(cor, vo, ro);
     double adx2d = 0., aru = 0., drx2d = 0., wusurf = 0., wubot = 0., ady2d = 0., arv = 0., dry2d = 0., wvsurf = 0., wvbot = 0.;
     double etf_o = 0., egf_o = 0., utf_o = 0., vtf_o = 0.;
     if (LIVE) {
-      adx2d = FLD(adx2d, vo, ro); aru = FLD(aru, vo, ro); drx2d = FLD(drx2d, vo, ro);
+      adx2d = FLD(adx2d, vo, ro); aru = FLD(aru, o_area, ro); drx2d = FLD(drx2d, vo, ro);
       wusurf = FLD(wusurf, vo, ro); wubot = FLD(wubot, vo, ro);
-      ady2d = FLD(ady2d, vo, ro); arv = FLD(arv, vo, ro); dry2d = FLD(dry2d, vo, ro);
+      ady2d = FLD(ady2d, vo, ro); arv = FLD(arv, o_area, ro); dry2d = FLD(dry2d, vo, ro);
       wvsurf = FLD(wvsurf, vo, ro); wvbot = FLD(wvbot, vo, ro);
       etf_o = FLD(etf, o_etf_ld, ro); egf_o = FLD(egf, o_acc_ld, ro); utf_o = FLD(utf, o_acc_ld, ro); vtf_o = FLD(vtf, o_acc_ld, ro);
     }
@@ -866,6 +885,8 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
     const double uaE_0 = ES(rc.ua, ua_(ie, j)), uaE_m1 = ES(rm.ua, ua_(ie, j - 1));
     // ---- continuity (advance.f:211-231) at (i,j); (i,j-1) is the row above's, the west value the neighbour lane's
     const double dysx_0 = rc.dy + rc.dyW, dxsy_0 = rc.dx + rm.dx, dxsy_p1 = rp.dx + rc.dx;
+    const double art_0 = canon ? rc.dx * rc.dy : art_l;                                      // initialize.f:361
+    if (canon) { aru = .25 * (rc.dx + dxW_0) * dysx_0; arv = .25 * dxsy_0 * (rc.dy + rm.dy); }   // :366-367
     const double fua_0 = .25 * (rc.d + rc.dW) * dysx_0 * rc.ua;
     const double fuaE_0 = ES(fua_0, flux_ua(P, ie, j));
     const double fva_p1 = .25 * (rp.d + rc.d) * dxsy_p1 * rp.va;
@@ -1099,7 +1120,7 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
     if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
       const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
-      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows);
+      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, getenv("POMGPU_EXT_AREAS_LOAD") ? 0 : 1);
       return;
     }
   }

@@ -305,6 +305,8 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   alloc(&c->d_vel, 4);
   alloc(&c->d_stats, 8);
   if (ok && hipMalloc((void **)&c->d_err, sizeof(int)) != hipSuccess) ok = false;
+  if (ok && hipMalloc((void **)&c->d_areas, sizeof(int)) != hipSuccess) ok = false;
+  if (ok && hipMemsetAsync(c->d_areas, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
   if (getenv("POMGPU_DEBUG_ALLOC"))
     fprintf(stderr, "pomgpu_create: b1 %p r1 %p b2 %p b3 %p bd %p s3[0] %p s3[4] %p s2[0] %p c2[0] %p\n", (void *)P.b1, (void *)P.r1, (void *)P.b2,
@@ -341,7 +343,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   (void)hipFree(P.m8);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
-  (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_stats); (void)hipFree(c->ext_bar);
+  (void)hipFree(c->d_vel); (void)hipFree(c->d_err); (void)hipFree(c->d_areas); (void)hipFree(c->d_stats); (void)hipFree(c->ext_bar);
   for (int k = 0; k < 3; k++) for (int sl = 0; sl < 4; sl++) { (void)hipFree(c->frc_dev[k][sl][0]); (void)hipFree(c->frc_dev[k][sl][1]); }
   for (int sl = 0; sl < 4; sl++) (void)hipFree(c->lat_dev[sl]);
   ProfState *ps = PS(c);
@@ -468,6 +470,7 @@ extern "C" int pomgpu_download(pomgpu_ctx *c, double *b1, double *b2, double *b3
 }
 // derived 2-D coefficient arrays follow the uploaded metrics / depths
 static void refresh_coefs(pomgpu_ctx *c) {
+  c->areas_checked = 0;                                       // dx, dy, art, aru, arv may have changed
   launch_coef_static(c);
   launch_coef_dt(c);
   launch_coef_eta(c);
@@ -836,6 +839,9 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
     if (!fuse_adv && c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235 (reads ua, va, d of the current generation)
     KP Q = P;
     for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
+    // once per internal step (and after any upload): are art, aru, arv what initialize.f:361-367 makes of dx, dy?  Then
+    // k_ext_march forms them in registers instead of reading three arrays per substep.  On the device, no host round trip.
+    if (fuse_adv && (P.iext == 1 || !c->areas_checked)) { launch_check_areas(c); c->areas_checked = 1; }
     launch_ext_step(c, Q, store_f || P.iext == P.isplit, fuse_adv);   // :211-347
     c->ext_parity ^= 1;
     ext_buffers(c);

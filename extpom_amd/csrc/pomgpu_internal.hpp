@@ -483,6 +483,8 @@ struct pomgpu_ctx {
   double rst_fold, rst_fnew;
   double *d_vel;             // device: vamax, then (imax,jmax) as two doubles' worth of ints
   int *d_err;                // device error flag
+  int *d_areas;              // device flag: art, aru, arv equal their defining formulas on dx, dy (k_check_areas); areas_checked: it is current
+  int areas_checked;
   double *d_stats;           // device: the seven sums of domain_stats
   double *frc_dev[3][4][2];  // forcing records on the device: [kind][slot = n % 4][field], (im,jm) each
   int frc_n[3][4];           // which record number a slot holds (0 = empty)
@@ -584,6 +586,7 @@ void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
 void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
+void launch_check_areas(pomgpu_ctx *c);
 int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last);   // 1 = launched (all substeps first..last), 0 = not applicable
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate

@@ -540,3 +540,27 @@ def test_fp32_storage_variant_tracks_the_fp64_path_within_its_stated_drift():
     with pytest.raises(PomGpuError):
         g32.write_file("output", "/tmp/should_not_exist.nc")
     g64.close(); g32.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("canonical", [True, False])
+def test_marching_external_substep_with_and_without_canonical_areas(monkeypatch, canonical):
+    """k_ext_march forced onto a small grid with a ragged last segment (its default use is the full-size test): art, aru, arv
+    formed from dx, dy where the arrays ARE initialize.f:361-367's formulas (k_check_areas decides on the device), read from
+    memory where the host's arrays differ in the last bit on a few cells -- all fields equal to the oracle's either way"""
+    OracleTile, oracle_finish_initial = _oracle()
+    monkeypatch.setenv("POMGPU_EXT_MARCH", "1")
+    monkeypatch.setenv("POMGPU_EXT_ROWS", "6")
+    a = make_case("seamount", 200, 93, 11, dte=6.0, isplit=10)
+    oracle_finish_initial(a)
+    if not canonical:
+        for name in ("aru", "art", "arv"):
+            f = a.field(name)
+            f[5:80:3, 7:190:5] = np.nextafter(f[5:80:3, 7:190:5], np.inf)
+    b = a.copy()
+    OracleTile(a).run(2)
+    g = _gpu(b)
+    g.run(2)
+    g.download()
+    g.close()
+    assert not diff(a, b), diff(a, b)

@@ -68,6 +68,29 @@ def test_even_leading_dimension_steps(case, im, jm):
         assert not diff(a, b), f"step {n}: {diff(a, b)}"
 
 
+@pytest.mark.parametrize("canonical", [True, False])
+def test_marching_external_substep_with_and_without_canonical_areas(monkeypatch, canonical):
+    """k_ext_march (forced onto a small grid, ragged last segment): art, aru, arv formed from dx, dy where the arrays ARE those
+    formulas (k_check_areas), read from memory where the host's arrays differ -- here aru and art perturbed in the last bit
+    on a few cells: the results must follow the arrays, as the oracle's do"""
+    monkeypatch.setenv("POMGPU_EXT_MARCH", "1")
+    monkeypatch.setenv("POMGPU_EXT_ROWS", "6")
+    a = make_case("seamount", 70, 45, 11, dte=6.0, isplit=10)
+    oracle_finish_initial(a)
+    if not canonical:
+        for name in ("aru", "art", "arv"):
+            f = a.field(name)
+            f[5:30:3, 7:60:5] = np.nextafter(f[5:30:3, 7:60:5], np.inf)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, 3):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
 def test_surface_and_lateral_forcing_across_record_changes():
     """wind / heat / surface (bounds_forcing.f:871-983) and lateral_bc (:593-868) on the device side, called by
     advance itself (advance.f:14-18) once records are supplied; dti = 360 s puts the record changes of the surface
