@@ -240,6 +240,12 @@ def launch_ranks(n):
     the GPU, and nothing is re-executed in place."""
     import socket
     import subprocess
+    if os.environ.get("POM_BENCH_REHEARSE") != "1":
+        import torch
+        have = torch.cuda.device_count()                       # counting devices does not initialise the GPU in this process
+        if have < n:
+            print(f"bench: --gpus {n} but {have} GPU(s) visible -- one rank per GPU, no measurement", file=sys.stderr)
+            return 3
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
