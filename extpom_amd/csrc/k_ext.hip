@@ -1114,11 +1114,17 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     return;
   }
   if (fuse_adv && !getenv("POMGPU_EXT_NOMARCH")) {            // large tiles: a wavefront marches down `rows` rows (k_ext_march)
-    int rows = 7;                                             // kbench at 2048x1536: 5-9 rows within 2 %, 13 +5 %, 26 and more +16 %
+    // rows per wavefront: enough wavefronts first (>= ~7400, i.e. 3.6 per wave slot of the chip), then taller segments (fewer
+    // halo rows): 7 at 2048x1536 (5-9 within 2 %), 2 at 1024x1024 (2.13 ms per step against 2.43 with 7 and 2.52 with the
+    // one-row kernel); below ~16500 wavefront-rows (the extended tile of a 4- or 8-tile split of that grid) the one-row kernel
+    // is faster (profiles/round2_ext_march.txt)
+    const long wave_rows = (long)g.x * (Q.jmm1 - 2);
+    int rows = (int)(wave_rows / 7400);
+    rows = rows < 2 ? 2 : (rows > 7 ? 7 : rows);
     if (getenv("POMGPU_EXT_ROWS")) rows = atoi(getenv("POMGPU_EXT_ROWS"));
-    const int nseg = (Q.jmm1 - 3 + 1 + rows - 1) / rows, nbx = (int)g.x;
+    const int nseg = rows > 0 ? (Q.jmm1 - 3 + 1 + rows - 1) / rows : 0, nbx = (int)g.x;
     const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
-    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && ((long)nseg * nbx >= 2048 || getenv("POMGPU_EXT_MARCH"))) {
+    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (wave_rows >= 16500 || getenv("POMGPU_EXT_MARCH"))) {
       const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
       LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, getenv("POMGPU_EXT_AREAS_LOAD") ? 0 : 1);
       return;
