@@ -775,12 +775,13 @@ void launch_check_areas(pomgpu_ctx *c) {
 //  * the operands of rows j-1, j, j+1 stay in registers; a row costs ONE new row of the eight stencil arrays (requested an
 //    iteration ahead) + the 18 pointwise operands of row j (requested at the top of the iteration, used in its second half),
 //    26 + 6 loads instead of 58 + 6;
-//  * what row j+1 recomputed from the same operands is carried instead: the new elevation of row j-1 (es), the fluxes
-//    fluxva(j), and advave's tps / fluxva(u) / fluxva(v) of the row above -- the SAME expressions on
-//    the SAME operands, so the bits do not change;
+//  * what row j+1 recomputed from the same operands is carried instead: the new elevation of row j-1 (es), fluxva(j), and
+//    advave's tps / fluxva (both halves) of the row above -- the SAME expressions on the SAME operands, so the bits do not
+//    change;
 //  * no load or store sits in a branch (vmcnt bookkeeping, as in the level loops): lanes / substeps with nothing to move aim
 //    outside the buffer; lane 0's two true western operands are one-lane loads (every other lane aims outside).
-// A segment starts one row early (a warm-up row whose stores are disabled) to fill the carried values.
+// A segment starts one row early: a warm-up row, peeled at compile time (row_step<false>: continuity and three advave terms,
+// no momentum, no stores), fills the carried values.  Workgroup order: XCD bands (below).  Cell areas: k_check_areas.
 struct ExtRow { double d, ua, va, dx, dy, uab, vab, am, dW, dyW; };   // one row of the stencil operands; dW, dyW: column i-1
 #ifndef POMGPU_EMU
 // the western neighbour's value, true on lane 0 as well (w: the one-lane load).  The shift is made by ALL lanes before the
