@@ -430,7 +430,7 @@ def main():
                     "algorithmic_bytes_per_launch": passes * (4 if f32 else 8) * tile_cells, "launches": nl,
                     "avg_launch_ms": round(tms / nl, 4)}
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
-        ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_copy2", "k_bcond1")
+        ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_check_areas", "k_copy2", "k_bcond1")
         msg_ms = prof.pop("msg_round", (0, 0.0))[1]           # the message rounds of the profiled step (N > 1): not a kernel
         msg_side_ms = prof.pop("msg_round_side", (0, 0.0))[1] # ... those on the library's second stream: beside kernels, not between them
         int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
