@@ -435,7 +435,7 @@ def test_config4_2048x1536x50_full_size():
     """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU: (i) ONE step, every field
     array_equal to the oracle (about a minute of CPU), (ii) the restart property: the device's second step equals a
     second step started from the ORACLE's first-step state uploaded into a fresh context, (iii) two contexts fed the
-    same state produce the same bits, (iv) land stays masked, nothing non-finite.  ~50 GB per host copy of the state."""
+    same state produce the same bits over 20 more steps, one on the large-grid kernel shapes and one on the general ones, (iv) land stays masked, nothing non-finite.  ~50 GB per host copy of the state."""
     import os
     import time
     OracleTile, oracle_finish_initial = _oracle()
@@ -467,15 +467,23 @@ def test_config4_2048x1536x50_full_size():
     beat("step 2 both ways")
     bad = diff(a, c)
     assert not bad, f"restart property: {bad}"
-    ga.run(1)
-    gc.run(1)
+    # 20 more steps: one context on the large-grid fast paths (the external substep marching down the rows, k_profq in 8 paced
+    # rows with its vectors in LDS, strip order), the other on the shapes small grids use -- the same bits
+    ga.run(20)
+    general = {"POMGPU_EXT_NOMARCH": "1", "POMGPU_PROFQ_ROWS2": "1", "POMGPU_PROFQ_NOPACE": "1", "POMGPU_COL_STRIP": "0"}
+    os.environ.update(general)
+    try:
+        gc.run(20)
+    finally:
+        for k in general:
+            os.environ.pop(k, None)
     ga.download()
     gc.download()
     ga.close()
     gc.close()
     bad = diff(a, c)
-    assert not bad, f"two contexts, same state, different bits: {bad}"
-    beat("step 3 compared")
+    assert not bad, f"two contexts, same state, fast against general kernels, different bits after 20 steps: {bad}"
+    beat("steps 3-22 compared")
     for f in PROGNOSTIC + ["q2", "km", "rho", "w"]:
         assert np.isfinite(a.field(f)).all(), f
     for f in ("t", "s", "el", "et"):
