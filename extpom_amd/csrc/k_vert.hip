@@ -14,11 +14,15 @@
 #define w_(i, j, k) F3(w, i, j, k)
 
 // Register-resident column kernels: rows per workgroup, same-context A/B at 2048x1536x50 (profiles/round2_reg_kernel_rows.txt):
-// profu / profv (one wave per SIMD) 1 row -7 / -3 % against 2, 4 rows +16 %; uv_filter, int_uvmean 4 rows -4.5 / -3 %; proft 1 row -0.7 %
+// profu / profv (one wave per SIMD) 1 row -7 / -3 % against 2, 4 rows +16 %; uv_filter 4 rows -4.5 %, 8 rows another -2 %; int_uvmean 4 rows -3 % (8: +1 %); proft 1 row -0.7 %
 #define ROWS_PROFUV 1
 #define ROWS_PROFT 1
-#define ROWS_UVF 4
+#ifndef ROWS_UVF
+#define ROWS_UVF 8
+#endif
+#ifndef ROWS_UVM
 #define ROWS_UVM 4
+#endif
 #define COL2                               \
   const int i = TID_I, j = TID_J;          \
   if (i > P.iml || j > P.jml) return;
