@@ -1264,9 +1264,10 @@ void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
   LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P, rho_rt);
 }
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
-  // 8 paced rows per workgroup (one workgroup per CU at 2 waves per SIMD) where that still leaves every CU several workgroups
+  // 8 paced rows per workgroup (one workgroup per CU at 2 waves per SIMD) where that still leaves every CU three workgroups
+  // (a 514x769 tile of an 8-tile split: 3.4 per CU, k_profq 1.27 -> 1.22 ms, the tile's step 7.15 -> 6.9)
   // (developer switches: POMGPU_PROFQ_ROWS8 / _ROWS2 force a shape, POMGPU_PROFQ_NOPACE drops the barrier)
-  const int rows8 = !getenv("POMGPU_PROFQ_ROWS2") && (getenv("POMGPU_PROFQ_ROWS8") || (long)((c->P.iml + 63) / 64) * ((c->P.jml + 7) / 8) >= 4 * 256);
+  const int rows8 = !getenv("POMGPU_PROFQ_ROWS2") && (getenv("POMGPU_PROFQ_ROWS8") || (long)((c->P.iml + 63) / 64) * ((c->P.jml + 7) / 8) >= 3 * 256);
   rho_rt = (rho_rt ? 1 : 0) | (getenv("POMGPU_PROFQ_NOPACE") ? 0 : 2);
 #define PQ(FP, FF)                                                                                                                       \
   do {                                                                                                                                   \
