@@ -349,7 +349,7 @@ def main():
         from extpom_amd import halo as H
         dev = torch.device("cuda", local)
         if rehearse:
-            g.set_transport(tile, H.StagedMover(g, tile, dev))
+            g.set_transport(tile, H.StagedMover(g, tile, dev), agree=H.dist_allmin())
             exchange = "library exchange, host-staged mover (rehearsal)"
         else:
             if H.connect_rccl(g, tile, rank, world):

@@ -767,6 +767,18 @@ static void side_join(pomgpu_ctx *c) {                        // everything the 
   if (c->early_started) { (void)hipStreamWaitEvent(c->stream, c->ev_early, 0); c->early_started = 0; }
   if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }
 }
+// the side stream and its three events, created on first use; 1 = they exist
+int pomgpu_side_stream(pomgpu_ctx *c) {
+  if (c->side) return 1;
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = NULL; return 0; }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(c->side);
+    c->side = NULL;
+    return 0;
+  }
+  return 1;
+}
 #define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
 static void wide_flush(pomgpu_ctx *c);
 #define NEED_HOT(c) NEED_RAW(c); ext_canonical(c); wide_flush(c)   /* the entry points pomgpu_advance strings together */
@@ -803,7 +815,15 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      
   }
   return POMGPU_OK;
 }
-extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) { return lateral_viscosity(c, 0); }
+static int wide_early_start(pomgpu_ctx *c);
+// The reference's own sequence (advance.f:14-21: surface_forcing, lateral_bc, lateral_viscosity, mode_interaction) gets the
+// early part of the wide exchange beside lateral_viscosity like pomgpu_advance does: the step's forcing is in place when the
+// host calls this (anything that touches the state in between joins the side stream first, and wide_begin then gathers all)
+extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {
+  NEED_HOT(c);
+  const int rc = wide_early_start(c);
+  return rc ? rc : lateral_viscosity(c, 0);
+}
 static int wide_begin(pomgpu_ctx *c);
 static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-202
   NEED_HOT(c);
@@ -1102,6 +1122,8 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
   pomgpu_transport &T = c->tp;
   if (!T.on) return fail(c, POMGPU_EINVAL, "wide external mode: set a transport first");
   const KP &P = c->P;
+  // the width follows the number of external substeps per internal step: the state (blkcon) must have been uploaded
+  if (c->con.isplit < 1) return fail(c, POMGPU_EINVAL, "wide external mode: isplit = %d -- upload the state (pomgpu_upload / pomgpu_set_con) first", c->con.isplit);
   int w = c->con.isplit + 4;
   if (getenv("POMGPU_WIDE_W")) w = atoi(getenv("POMGPU_WIDE_W"));   // developer switch: shows that fewer cells are not enough
   if (w < 1 || min_im < w + 3 || min_jm < w + 3 || P.im < w + 3 || P.jm < w + 3) {
@@ -1142,16 +1164,9 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
     wide_free(c);
     return rc;
   }
-  // the two-part gather on two streams (the default where the transport can serve a second stream)
-  if (!c->side && !getenv("POMGPU_NO_OVERLAP")) {
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = NULL;
-    else {
-      (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming);
-    }
-  }
-  if (c->side && pomgpu_tp_side_ok(c) && !getenv("POMGPU_NO_OVERLAP")) {
+  // the two-part gather on two streams: where EVERY rank can serve a second stream (pomgpu_tp_side_ok: the ranks' agreement,
+  // taken by pomgpu_rccl_init over the communicator or handed in by the host of a callback mover; never a rank's own choice)
+  if (pomgpu_tp_side_ok(c)) {
     size_t need2[8];
     const size_t per2 = (size_t)NEL(WIDE_HALO_EARLY) * (w + 1);
     need2[0] = need2[1] = per2 * P.jm + edge;
@@ -1200,6 +1215,8 @@ static int wide_begin(pomgpu_ctx *c) {
   pomgpu_wide &Wd = c->wide;
   pomgpu_ctx *x = Wd.x;
   int rc;
+  if (c->con.isplit + 4 > Wd.w && !getenv("POMGPU_WIDE_W"))     // the stale rim grows by one cell per substep (see above)
+    return fail(c, POMGPU_EINVAL, "wide external mode: isplit = %d now, the extended tile was made for isplit <= %d -- call pomgpu_set_wide_external again", c->con.isplit, Wd.w - 4);
   if (!Wd.static_done && (rc = wide_static(c))) return rc;
   if (c->early_started) {                                     // the rest of the gather here, then wait for the part that ran beside
     table_run(c, Wd.late_pack);
@@ -1326,7 +1343,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
   launch_int_tail(c);                                         // :525-531
   launch_coef_dt(c);                                          // dt changed: refresh the derived coefficients
   launch_realvertvl(c);                                       // :534
-  if (c->tp.on && c->exch && c->wide.split && !getenv("POMGPU_WR_MAIN")) {
+  if (c->tp.on && c->exch && c->wide.split && c->tp.wr_side) {     // wr_side: no rank asked for POMGPU_WR_MAIN (agreed with side_agreed)
     // solver.f:2055 on the side stream: nobody on the hot path reads wr's ghost cells (a diagnostic for the output
     // file), so the round runs beside check_velocity and the next step's lateral_viscosity; the next step's early gather
     // follows it on the same stream, and whoever looks at the state waits for it (side_join)
@@ -1337,9 +1354,12 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
     size_t cnt[8];
     for (int d = 0; d < 8; d++) cnt[d] = c->tp.nbr[d] >= 0 ? (size_t)P.kbm1 * len[d] : 0;
-    if (!launch_halo_pack8(c, arr, nz, 1, c->tp.send2) && !pomgpu_tp_move_side(c, cnt, cnt)) (void)launch_halo_unpack8(c, arr, nz, 1, (const double *const *)c->tp.recv2);
+    int rcw = launch_halo_pack8(c, arr, nz, 1, c->tp.send2) ? fail(c, POMGPU_EINVAL, "wr exchange: bad array list") : POMGPU_OK;
+    if (!rcw) rcw = pomgpu_tp_move_side(c, cnt, cnt);
+    if (!rcw) (void)launch_halo_unpack8(c, arr, nz, 1, (const double *const *)c->tp.recv2);
     side_end(c, c->ev_side);
     c->side_pending = 1;
+    if (rcw) return rcw;                                      // a failed round is the step's failure (error_status is set)
   } else {
     xch(c, 1, D3(c, wr), P.kbm1);                             // solver.f:2055
   }

@@ -424,6 +424,8 @@ struct pomgpu_transport {
   size_t cap[8];             // capacity of each staging buffer, doubles
   double *send2[8], *recv2[8];   // staging buffers of the side stream's rounds (they overlap rounds on the main stream)
   size_t cap2[8];
+  int side_agreed;           // EVERY rank of the decomposition can serve rounds on the side stream (collective decision, transport.hip)
+  int wr_side;               // ... and none of them asked for the wr exchange on the main stream (POMGPU_WR_MAIN)
   long rounds_side;          // message rounds served on the side stream
   long rounds;               // message rounds served so far
 };
@@ -661,6 +663,7 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
 void pomgpu_tp_free(pomgpu_ctx *c);
 int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need);                       // grow the staging buffers
 int pomgpu_tp_reserve2(pomgpu_ctx *c, const size_t *need);                      // ... those of the side stream
+int pomgpu_side_stream(pomgpu_ctx *c);                                          // create the side stream and its events (pomgpu_api.hip); 1 = there
 int pomgpu_tp_side_ok(pomgpu_ctx *c);                                           // can rounds run on the side stream (second communicator / callback mover)?
 int pomgpu_tp_move_side(pomgpu_ctx *c, const size_t *scount, const size_t *rcount);   // send2 / recv2, on c->side
 // k_reduce.hip

@@ -33,6 +33,7 @@ struct RcclApi {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   const char *(*GetErrorString)(ncclResult_t);
   ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *);   // optional (RCCL >= 2.18): the side stream's communicator
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);   // the ranks' agreement on side-stream rounds
 };
 static RcclApi g_rccl;
 struct RcclComm { ncclComm_t comm, comm2; int rank, nranks; };
@@ -57,6 +58,7 @@ static int rccl_load(const char *path) {
   SYM(Send, "ncclSend")
   SYM(Recv, "ncclRecv")
   SYM(GetErrorString, "ncclGetErrorString")
+  SYM(AllReduce, "ncclAllReduce")
 #undef SYM
   *(void **)(&a.CommSplit) = dlsym(h, "ncclCommSplit");       // absent in old libraries: no side-stream rounds then
   g_rccl = a;
@@ -82,6 +84,8 @@ void pomgpu_tp_free(pomgpu_ctx *c) {
     T.send2[d] = T.recv2[d] = NULL; T.cap2[d] = 0;
   }
   T.on = 0;
+  T.side_agreed = 0;
+  T.wr_side = 0;
 }
 
 // grow the staging buffers to at least need[d] doubles (directions without a neighbour stay empty)
@@ -114,11 +118,14 @@ int pomgpu_tp_reserve2(pomgpu_ctx *c, const size_t *need) {
   }
   return POMGPU_OK;
 }
-// Rounds on the side stream need a communicator of their own (one communicator serves one stream at a time); a callback
-// mover (tests) is synchronous and can serve any stream.
+// Rounds on the side stream need a communicator of their own (one communicator serves one stream at a time) and the
+// consent of EVERY rank: T.side_agreed is the minimum over the ranks of "I could" (pomgpu_tp_rccl reduces it over the
+// communicator; with a callback mover the host reduces pomgpu_transport_side_capable and reports through
+// pomgpu_transport_side_agree).  A rank deciding for itself would post its rounds on another communicator and in another
+// order than its neighbours: a deadlock.
 int pomgpu_tp_side_ok(pomgpu_ctx *c) {
   pomgpu_transport &T = c->tp;
-  if (!T.on || !c->side) return 0;
+  if (!T.on || !c->side || !T.side_agreed) return 0;
   if (T.fn) return 1;
 #ifndef POMGPU_EMU
   RcclComm *r = (RcclComm *)T.rccl;
@@ -126,6 +133,31 @@ int pomgpu_tp_side_ok(pomgpu_ctx *c) {
 #else
   return 0;
 #endif
+}
+// this rank's own answer (not yet an agreement): a second stream exists or can be made, nothing switches the overlap off
+static int side_capable_local(pomgpu_ctx *c) {
+  if (getenv("POMGPU_NO_OVERLAP")) return 0;
+  return pomgpu_side_stream(c);
+}
+extern "C" int pomgpu_transport_side_capable(pomgpu_ctx *c) {
+  if (!c || !c->tp.on) return 0;
+#ifndef POMGPU_EMU
+  if (!c->tp.fn) { RcclComm *r = (RcclComm *)c->tp.rccl; if (!r || !r->comm2) return 0; }
+#endif
+  return side_capable_local(c);
+}
+extern "C" int pomgpu_transport_side_agree(pomgpu_ctx *c, int agreed) {
+  if (!c) return POMGPU_EINVAL;
+  pomgpu_transport &T = c->tp;
+  if (!T.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: set a transport first");
+  if (c->wide.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: before pomgpu_set_wide_external");
+  if (!agreed) { T.side_agreed = 0; T.wr_side = 0; return POMGPU_OK; }
+  // "yes" can only come from the host's reduction over all ranks -- which included this rank's own answer
+  if (!pomgpu_transport_side_capable(c)) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: this rank reported that it cannot (the minimum over all ranks is 0)");
+  if (!T.fn) return POMGPU_OK;                                // RCCL: pomgpu_rccl_init has agreed already, nothing to raise
+  T.side_agreed = 1;
+  T.wr_side = getenv("POMGPU_WR_MAIN") ? 0 : 1;               // a process-wide developer switch: callback movers live in one process or one launcher
+  return POMGPU_OK;
 }
 // One message round on the SIDE stream: send2[d] -> neighbour d, recv2[d] <- neighbour d.  Every rank must issue its
 // side-stream rounds in the same order (they do: one early gather and one wr exchange per internal step).
@@ -248,7 +280,7 @@ int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8) {
   T.on = 1;
   T.rounds = 0;
   T.rounds_side = 0;
-  return pomgpu_tp_reserve(c, need);
+  return pomgpu_tp_reserve(c, need);   // side_agreed / wr_side: set by pomgpu_tp_rccl before this, 0 after pomgpu_tp_free otherwise
 }
 
 extern "C" long pomgpu_exchange_rounds(pomgpu_ctx *c) { return c ? c->tp.rounds : 0; }
@@ -269,10 +301,38 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
   }
   // the side stream's communicator: the same ranks, split off the first (collective, like the init above).  Without
   // ncclCommSplit the library keeps every round on the main stream.
+  const char *tf = getenv("POMGPU_TEST_SPLIT_FAIL_RANK");     // tests: this rank behaves as if its split had failed
+  const bool forced_fail = tf && atoi(tf) == rank;
   if (g_rccl.CommSplit && !getenv("POMGPU_NO_SIDE_COMM")) {
     const ncclResult_t e2 = g_rccl.CommSplit(r->comm, 0, rank, &r->comm2, NULL);
     if (e2 != ncclSuccess) { r->comm2 = NULL; fprintf(stderr, "pomgpu: ncclCommSplit: %s -- message rounds stay on one stream\n", g_rccl.GetErrorString(e2)); }
   }
+  // Side-stream rounds: all ranks or none.  Every rank contributes (can I: second communicator + second stream + no
+  // switch against it; may wr go there: POMGPU_WR_MAIN unset) and takes the minimum over the communicator.  Every rank
+  // reaches this all-reduce whatever its own answer is; a rank on which it fails leaves with an error (its partners'
+  // deadline -- bench.py, the host's own -- ends them: they cannot be told).
+  int mine[2] = {(r->comm2 != NULL && !forced_fail && side_capable_local(c)) ? 1 : 0, getenv("POMGPU_WR_MAIN") ? 0 : 1};
+  int agreed[2] = {0, 0};
+  {
+    int *dflag = NULL;
+    bool ok = hipMalloc((void **)&dflag, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpyAsync(dflag, mine, sizeof mine, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ncclResult_t ea = ncclSuccess;
+    if (ok) ea = g_rccl.AllReduce(dflag, dflag + 2, 2, ncclInt32, ncclMin, r->comm, c->stream);
+    ok = ok && ea == ncclSuccess && hipMemcpyAsync(agreed, dflag + 2, sizeof agreed, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    (void)hipFree(dflag);
+    if (!ok) {
+      if (r->comm2) (void)g_rccl.CommDestroy(r->comm2);
+      (void)g_rccl.CommDestroy(r->comm);
+      delete r;
+      return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: the ranks' agreement on side-stream rounds failed: %s", ea != ncclSuccess ? g_rccl.GetErrorString(ea) : "HIP");
+    }
+  }
+  if (!agreed[0] && r->comm2) { (void)g_rccl.CommDestroy(r->comm2); r->comm2 = NULL; }
+  if (!agreed[0] && mine[0] && rank == 0) fprintf(stderr, "pomgpu: a rank cannot serve side-stream rounds -- every rank keeps its message rounds on one stream\n");
+  c->tp.side_agreed = agreed[0];
+  c->tp.wr_side = agreed[0] && agreed[1];
   c->tp.rccl = r;
   c->tp.fn = NULL;
   c->tp.user = NULL;

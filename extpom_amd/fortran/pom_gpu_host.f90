@@ -30,13 +30,34 @@ end subroutine
 ! broadcast with MPI_Bcast over pom_comm) and the eight neighbour ranks.  From then on every exchange point of the hot
 ! path is served inside the library (pack, one grouped ncclSend/ncclRecv round, unpack, on its stream), and the 2-D
 ! external mode runs on a wide-halo copy of the tile (one exchange per internal step) when the tiles are wide enough.
+! Call it after pomgpu_upload_state: the extended tile is sized by isplit (the library refuses with isplit = 0).
 subroutine pomgpu_host_connect(id128)
   use pomgpu_iface
   implicit none
   include 'pom.h'
   character(kind=c_char) :: id128(128)
   integer(c_int) :: nb(8), rc
-  integer :: px, py, npx, npy, min_im, min_jm
+  integer :: nranks, min_im, min_jm
+  call pomgpu_host_neighbours(nb, nranks, min_im, min_jm)
+  rc = pomgpu_rccl_init(pom_ctx, id128, int(my_task, c_int), int(nranks, c_int), nb, c_null_ptr)
+  if (rc /= 0) then
+    error_status = 1
+    write(6,'(/''Error: pomgpu_rccl_init failed'')')
+    return
+  end if
+  rc = pomgpu_set_wide_external(pom_ctx, 1_c_int, int(min_im, c_int), int(min_jm, c_int))   ! EINVAL = tiles too narrow: per-point exchanges stay
+end subroutine
+
+! The eight neighbour ranks of this tile in the C ABI's order W E S N SW SE NW NE, the number of tiles, and the extents of
+! the smallest tile -- from what distribute_mpi left in blkpar / blksiz (parallel_mpi.f:54-119): the tiles are numbered row
+! by row, nproc_x of them per row, the east- / north-most ones are the trimmed ones (:83-87, :98-102).
+subroutine pomgpu_host_neighbours(nb, nranks, min_im, min_jm)
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  integer(c_int), intent(out) :: nb(8)
+  integer, intent(out) :: nranks, min_im, min_jm
+  integer :: px, py, npx, npy
   npx = (im_global - 2 + im_local - 3) / (im_local - 2)        ! tiles in x, y (parallel_mpi.f:54-65)
   npy = (jm_global - 2 + jm_local - 3) / (jm_local - 2)
   px = mod(my_task, npx); py = my_task / npx
@@ -46,16 +67,23 @@ subroutine pomgpu_host_connect(id128)
   if (px < npx - 1 .and. py > 0) nb(6) = my_task + 1 - npx
   if (px > 0 .and. py < npy - 1) nb(7) = my_task - 1 + npx
   if (px < npx - 1 .and. py < npy - 1) nb(8) = my_task + 1 + npx
-  rc = pomgpu_rccl_init(pom_ctx, id128, int(my_task, c_int), int(npx * npy, c_int), nb, c_null_ptr)
-  if (rc /= 0) then
-    error_status = 1
-    write(6,'(/''Error: pomgpu_rccl_init failed'')')
-    return
-  end if
-  ! the east-/north-most tiles are the trimmed ones (parallel_mpi.f:83-87, :98-102)
+  nranks = npx * npy
   min_im = min(im_local, im_global - (npx - 1) * (im_local - 2))
   min_jm = min(jm_local, jm_global - (npy - 1) * (jm_local - 2))
-  rc = pomgpu_set_wide_external(pom_ctx, 1_c_int, int(min_im, c_int), int(min_jm, c_int))   ! EINVAL = tiles too narrow: per-point exchanges stay
+end subroutine
+
+! End of the run (the reference: finalize_mpi, pom.f:36): the output / restart file still being written behind the model's
+! back is joined -- its status is the run's -- and the device state is released.
+subroutine pomgpu_host_finalize
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  if (pomgpu_io_wait(pom_ctx) /= 0) then
+    error_status = 1
+    write(6,'(/''Error: an output / restart file could not be written'')')
+  end if
+  call pomgpu_destroy(pom_ctx)
+  pom_ctx = c_null_ptr
 end subroutine
 
 subroutine pomgpu_upload_state

@@ -62,4 +62,12 @@ subroutine pomgpu_write_file(fname, restart)
     end if
     call pomgpu_barrier_mpi                        ! mpi_barrier(pom_comm) on several ranks
   end do
+  ! The library returns once the file is laid out and a snapshot of its arrays is taken; a host thread writes it while the
+  ! model goes on.  A RESTART file must be whole when this routine returns (the reference's writer is synchronous and
+  ! collective, io_pnetcdf.F:1661-2083: a run that dies in the next step must find it), so it is joined here and its
+  ! status becomes the run's; an output file is joined by the next write or by pomgpu_host_finalize.
+  if (restart /= 0) then
+    if (pomgpu_io_wait(pom_ctx) /= 0) error_status = 1
+    call pomgpu_barrier_mpi
+  end if
 end subroutine

@@ -1,0 +1,232 @@
+! pom_gpu_mpi_main.f90 -- the Fortran host on several MPI ranks, with file forcing and the output writers: a driver in the
+! shape of the reference's `program pom` (pom/pom.f:5-39) that exercises, in one executable, every wrapper an integrator
+! links -- pom_gpu_host.f90 (hot path), pom_gpu_mpi.f90 (ranks), pom_gpu_forcing.f90 (wind / heat / surface / lateral_bc
+! with the reference's own record scheduling) and pom_gpu_io.f90 (write_output_pnetcdf / write_restart_pnetcdf).
+!
+!   mpiexec -n N pom_gpu_mpi_main <in-prefix> <out-prefix>        (pom.nml in the working directory)
+!
+! Rank r reads <in-prefix>.<r> -- what initialize would have left in its COMMON blocks (the reference reads grid, initial
+! and forcing fields through PnetCDF, which this image lacks) plus the forcing records its readers would deliver -- and
+! writes the blocks after each listed step to <out-prefix>.<r>.<step> for the test to hash.  initialize_mpi's part
+! (communicator, rank) is three MPI calls; distribute_mpi's result (im, jm, the four neighbours, the tile's first global
+! indices) comes with the file, where extpom_amd.decomp -- held to the reference's own blkpar by tests/golden -- put it.
+module pom_gpu_records                           ! what the reference's PnetCDF readers would deliver, record by record
+  implicit none
+  integer :: nfrc = 0, nlat = 0
+  double precision, allocatable :: frc(:,:,:,:,:)      ! (im, jm, field 1:2, record, kind 1:3 = wind, heat, surface)
+  double precision, allocatable :: lat(:,:)            ! (20 arrays back to back, record)
+end module
+
+program pom_gpu_mpi_main
+  use pomgpu_iface
+  use pom_gpu_records
+  implicit none
+  include 'mpif.h'
+  include 'pom.h'
+  namelist/pom_nml/ title,wrk_pth,netcdf_file,mode,nadv,nitera,sw,npg,dte,isplit,time_start,nread_rst, &
+                    read_rst_file,cont_bry,write_rst,write_rst_file,days,prtd1,prtd2,swtch,ntp,nbct,nbcs
+  integer :: hdr(16), check(8), nsteps, nrec, n, k, rc, n2, n3, nbd, i0, j0, ncheck, wfiles, ierr, nranks, device, latlen
+  double precision :: vtot, atot, mtot, stot, tavg, savg, eavg, ekin
+  double precision, allocatable, target :: tr(:,:,:,:), sr(:,:,:,:)
+  character(len=256) :: pin, pout, fname
+  character(len=16) :: env
+  logical :: forced
+
+  call mpi_init(ierr)                            ! initialize_mpi, parallel_mpi.f:124-151
+  pom_comm = mpi_comm_world
+  call mpi_comm_rank(pom_comm, my_task, ierr)
+  call mpi_comm_size(pom_comm, nranks, ierr)
+  master_task = 0
+  error_status = 0
+  call get_command_argument(1, pin)
+  call get_command_argument(2, pout)
+  n2 = im_local*jm_local
+  n3 = n2*kb
+  write(fname, '(a,''.'',i0)') trim(pin), my_task
+  open(71, file=trim(fname), form='unformatted', access='stream', status='old')
+  read(71) hdr, check
+  im = hdr(1); jm = hdr(2); n_west = hdr(3); n_east = hdr(4); n_south = hdr(5); n_north = hdr(6)
+  nsteps = hdr(7); nrec = hdr(8); nbd = hdr(9); i0 = hdr(10); j0 = hdr(11); nfrc = hdr(12); nlat = hdr(13)
+  ncheck = hdr(14); wfiles = hdr(15)
+  imm1=im-1; imm2=im-2; jmm1=jm-1; jmm2=jm-2; kbm1=kb-1; kbm2=kb-2
+  do n = 1, im_local                             ! distribute_mpi, parallel_mpi.f:70-76, :89-95
+    i_global(n) = n + i0 - 1
+  end do
+  do n = 1, jm_local
+    j_global(n) = n + j0 - 1
+  end do
+  call blk_read(71, dz, 4*kb)
+  call blk_read(71, aam2d, 73*n2)
+  call blk_read(71, aam, 40*n3)
+  call blk_read(71, ele, nbd)
+  call blk_read(71, alpha, 47)
+  allocate(tr(im,jm,kb,max(nrec,1)), sr(im,jm,kb,max(nrec,1)))
+  do n = 1, nrec
+    read(71) tr(:,:,:,n), sr(:,:,:,n)
+  end do
+  forced = nfrc > 0
+  if (forced) then
+    allocate(frc(im,jm,2,nfrc,3))
+    do k = 1, 3
+      do n = 1, nfrc
+        read(71) frc(:,:,1,n,k), frc(:,:,2,n,k)
+      end do
+    end do
+    latlen = 8*jm_local*kb + 8*im_local*kb + 2*jm_local + 2*im_local
+    allocate(lat(latlen, max(nlat,1)))
+    do n = 1, nlat
+      read(71) lat(:,n)
+    end do
+  end if
+  close(71)
+  lramp = .false.
+  open(73, file='pom.nml', status='old')         ! read_input, initialize.f:71-74,173-198
+  read(73, nml=pom_nml)
+  close(73)
+  dti=dte*float(isplit); dte2=dte*2; dti2=dti*2
+  ispi=1.d0/float(isplit); isp2i=1.d0/(2.d0*float(isplit))
+
+  device = 0                                     ! one GPU per rank in production; POM_GPU_DEVICE for ranks that share one
+  call get_environment_variable('POM_GPU_DEVICE', env, status=rc)
+  if (rc == 0) read(env, *) device
+  call pomgpu_host_init(device)
+  call pomgpu_upload_state                       ! before the ranks are connected: the wide-halo mode sizes its extended tile by isplit
+  if (nranks > 1) call pomgpu_host_connect_mpi
+  do n = 1, nrec
+    rc = pomgpu_set_restore_record(pom_ctx, int(n, c_int), c_loc(tr(1,1,1,n)), c_loc(sr(1,1,1,n)))
+  end do
+  k = 1
+  do n = 1, nsteps                               ! pom.f:17-19
+    iint = iint + 1
+    call advance_hot(forced)
+    if (k <= ncheck) then
+      if (check(k) == n) then
+        call pomgpu_download_state
+        write(fname, '(a,''.'',i0,''.'',i0)') trim(pout), my_task, n
+        open(72, file=trim(fname), form='unformatted', access='stream', status='replace')
+        call blk_write(72, aam2d, 73*n2)
+        call blk_write(72, aam, 40*n3)
+        call blk_write(72, ele, nbd)
+        call blk_write(72, alpha, 47)
+        close(72)
+        k = k + 1
+      end if
+    end if
+  end do
+  if (wfiles /= 0) then                          ! advance.f:35-49 at the end of the run: one output file, one restart file
+    call write_output_pnetcdf
+    call write_restart_pnetcdf
+  end if
+  call domain_stats(vtot, atot, mtot, stot, tavg, savg, eavg, ekin)
+  if (my_task == 0) then
+    write(6,'(a,8es25.16e3)') 'domain_stats:', vtot, atot, mtot, stot, tavg, savg, eavg, ekin
+    write(6,'(a,i4,a,i7,a,i7)') 'message rounds per step on rank 0: ', int(pomgpu_exchange_rounds(pom_ctx))/max(nsteps,1), &
+                                 '  total ', int(pomgpu_exchange_rounds(pom_ctx)), '  on the second stream ', int(pomgpu_exchange_rounds_side(pom_ctx))
+  end if
+  call pomgpu_host_finalize
+  call mpi_allreduce(mpi_in_place, error_status, 1, mpi_integer, mpi_max, pom_comm, ierr)
+  if (my_task == 0) write(6,'(a,i6,a,i3,a,i3)') 'pom_gpu_mpi_main: steps ', nsteps, '  ranks ', nranks, '  error_status ', error_status
+  call mpi_finalize(ierr)
+  if (error_status /= 0) stop 1
+end program
+
+! advance.f:6-59 without print_section: get_time, surface_forcing + lateral_bc when records came with the state (the
+! reference calls them unconditionally: its forcing is always file-driven), the four modes, check_velocity
+subroutine advance_hot(forced)
+  implicit none
+  include 'pom.h'
+  logical forced
+  time=dti*float(iint)/86400.d0+time0            ! get_time, advance.f:62-75
+  if(iint.ge.iswtch) iprint=nint(prtd2*24.d0*3600.d0/dti)
+  if(lramp) then
+    ramp=time/period
+    if(ramp.gt.1.d0) ramp=1.d0
+  else
+    ramp=1.d0
+  endif
+  if (forced) then
+    call wind                                    ! surface_forcing, advance.f:77-93
+    call heat
+    call surface
+    call lateral_bc                              ! advance.f:18
+  end if
+  call lateral_viscosity
+  call mode_interaction
+  do iext=1,isplit
+    call mode_external
+  end do
+  call mode_internal
+  call check_velocity
+end subroutine
+
+! ---- the reference's readers (io_pnetcdf.F:2912, :3110, :3170, :3393), served from the records that came with the state ----
+subroutine read_wind_pnetcdf(n, wu, wv)
+  use pom_gpu_records
+  implicit none
+  include 'pom.h'
+  integer n
+  double precision wu(im,jm), wv(im,jm)
+  call serve_record(1, n, wu, wv)
+end subroutine
+subroutine read_heat_pnetcdf(n, shf, swr)
+  use pom_gpu_records
+  implicit none
+  include 'pom.h'
+  integer n
+  double precision shf(im,jm), swr(im,jm)
+  call serve_record(2, n, shf, swr)
+end subroutine
+subroutine read_surface_pnetcdf(n, sst, sss)
+  use pom_gpu_records
+  implicit none
+  include 'pom.h'
+  integer n
+  double precision sst(im,jm), sss(im,jm)
+  call serve_record(3, n, sst, sss)
+end subroutine
+subroutine serve_record(kind, n, a, b)
+  use pom_gpu_records
+  implicit none
+  include 'pom.h'
+  integer kind, n
+  double precision a(im,jm), b(im,jm)
+  if (n < 1 .or. n > nfrc) then
+    write(6,'(a,i2,a,i4,a)') 'pom_gpu_mpi_main: forcing record ', kind, ' /', n, ' did not come with the state'
+    error_status = 1
+    stop 2
+  end if
+  a = frc(:,:,1,n,kind)
+  b = frc(:,:,2,n,kind)
+end subroutine
+subroutine read_boundary_conditions_pnetcdf(n, nz, tw, sw_, uw, vw, te, se, ue, ve, tn, sn, vn, un, ts, ss, vs, us, ew, ee, en, es)
+  use pom_gpu_records
+  implicit none
+  include 'pom.h'
+  integer n, nz, o
+  double precision tw(jm_local,kb), sw_(jm_local,kb), uw(jm_local,kb), vw(jm_local,kb)
+  double precision te(jm_local,kb), se(jm_local,kb), ue(jm_local,kb), ve(jm_local,kb)
+  double precision tn(im_local,kb), sn(im_local,kb), vn(im_local,kb), un(im_local,kb)
+  double precision ts(im_local,kb), ss(im_local,kb), vs(im_local,kb), us(im_local,kb)
+  double precision ew(jm_local), ee(jm_local), en(im_local), es(im_local)
+  if (n < 1 .or. n > nlat) then
+    write(6,'(a,i4,a)') 'pom_gpu_mpi_main: lateral record ', n, ' did not come with the state'
+    error_status = 1
+    stop 2
+  end if
+  o = 0
+  call take2(tw, jm_local); call take2(sw_, jm_local); call take2(uw, jm_local); call take2(vw, jm_local)
+  call take2(te, jm_local); call take2(se, jm_local); call take2(ue, jm_local); call take2(ve, jm_local)
+  call take2(tn, im_local); call take2(sn, im_local); call take2(vn, im_local); call take2(un, im_local)
+  call take2(ts, im_local); call take2(ss, im_local); call take2(vs, im_local); call take2(us, im_local)
+  ew = lat(o+1:o+jm_local, n); o = o + jm_local
+  ee = lat(o+1:o+jm_local, n); o = o + jm_local
+  en = lat(o+1:o+im_local, n); o = o + im_local
+  es = lat(o+1:o+im_local, n); o = o + im_local
+contains
+  subroutine take2(x, len)
+    integer len
+    double precision x(len,kb)
+    x = reshape(lat(o+1:o+len*kb, n), (/len, kb/))
+    o = o + len*kb
+  end subroutine
+end subroutine

@@ -49,6 +49,13 @@ module pomgpu_iface
     integer(c_int) function pomgpu_set_wide_external(ctx, on, min_im, min_jm) bind(C, name='pomgpu_set_wide_external')
       import; type(c_ptr), value :: ctx; integer(c_int), value :: on, min_im, min_jm
     end function
+    ! hosts without RCCL between the ranks: the MPI mover of libpomgpu_mpi.so (extpom_amd/csrc/mpi_mover.c); fcomm = pom_comm
+    integer(c_int) function pomgpu_mpi_mover_install(ctx, fcomm, neighbours8) bind(C, name='pomgpu_mpi_mover_install')
+      import; type(c_ptr), value :: ctx; integer(c_int), value :: fcomm; integer(c_int) :: neighbours8(8)
+    end function
+    integer(c_long) function pomgpu_exchange_rounds_side(ctx) bind(C, name='pomgpu_exchange_rounds_side')
+      import; type(c_ptr), value :: ctx
+    end function
     integer(c_long) function pomgpu_exchange_rounds(ctx) bind(C, name='pomgpu_exchange_rounds')
       import; type(c_ptr), value :: ctx
     end function

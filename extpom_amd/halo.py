@@ -297,6 +297,17 @@ class StagedMover:
         torch.cuda.current_stream().synchronize()
 
 
+def dist_allmin(group=None):
+    """the host's reduction behind pomgpu_transport_side_agree for callback movers whose ranks are torch.distributed
+    processes: the minimum of every rank's own answer (one all-gather; any backend)"""
+    def agree(mine: int) -> int:
+        world = dist.get_world_size(group)
+        box = [None] * world
+        dist.all_gather_object(box, int(mine), group=group)
+        return min(box)
+    return agree
+
+
 def rccl_library_path():
     """the librccl torch has already mapped (one copy per process), else the system one"""
     import os

@@ -117,13 +117,26 @@ class PomGpu:
         """ranks in the C ABI's direction order W E S N SW SE NW NE"""
         return [tile.n_west, tile.n_east, tile.n_south, tile.n_north, tile.n_sw, tile.n_se, tile.n_nw, tile.n_ne]
 
-    def set_transport(self, tile, fn):
-        """callback mover (tests): fn(send, scount, recv, rcount), each a list of eight (device address, doubles)"""
+    def set_transport(self, tile, fn, agree=None):
+        """callback mover (tests): fn(send, scount, recv, rcount), each a list of eight (device address, doubles).
+        agree: the host's reduction over ALL ranks -- agree(mine: int) -> min over the ranks -- through which the ranks
+        settle whether message rounds may run on the library's second stream (all of them or none, pomgpu.h); without
+        it every round stays on the main stream."""
         def cb(user, send, scount, recv, rcount):
             fn([send[d] for d in range(8)], [scount[d] for d in range(8)], [recv[d] for d in range(8)], [rcount[d] for d in range(8)])
         self._tp_cb = _lib.TRANSPORT_FN(cb)
         nb = (ctypes.c_int * 8)(*self.neighbours8(tile))
         self._chk(self.L.pomgpu_set_transport(self.h, nb, self._tp_cb, None), "set_transport")
+        if agree is not None:
+            self.side_agree(agree)
+
+    def side_capable(self) -> int:
+        """this rank's own answer: could it serve message rounds on a second stream?"""
+        return int(self.L.pomgpu_transport_side_capable(self.h))
+
+    def side_agree(self, agree):
+        """collective: agree(mine) must return the minimum of `mine` over all ranks of the decomposition"""
+        self._chk(self.L.pomgpu_transport_side_agree(self.h, int(agree(self.side_capable()))), "transport_side_agree")
 
     def rccl_init(self, tile, id128: bytes, rank: int, nranks: int, librccl: str | None = None):
         """production mover: grouped ncclSend / ncclRecv on the library's stream"""

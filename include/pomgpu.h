@@ -161,6 +161,16 @@ int pomgpu_rccl_available(const char *librccl_path);   /* POMGPU_OK if librccl o
 int pomgpu_rccl_unique_id(void *id128, const char *librccl_path);
 int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, const int *neighbours8,
                      const char *librccl_path);
+/* Message rounds on the library's SECOND stream (the early part of the wide exchange, wr) are a decision every rank of
+ * the decomposition must take alike: a rank that kept them on the first stream while its neighbours moved them would post
+ * its rounds in another order on another communicator, and the job would hang.  pomgpu_rccl_init agrees on it itself
+ * (one ncclAllReduce(min) over the ranks' own answers: second communicator split off, second stream created,
+ * POMGPU_NO_OVERLAP / POMGPU_NO_SIDE_COMM / POMGPU_WR_MAIN not set -- all ranks or none).  With a callback mover the
+ * library cannot reach the other ranks: side rounds stay OFF until the host has reduced pomgpu_transport_side_capable()
+ * (1 / 0, this rank) to its minimum over ALL ranks and handed the result to pomgpu_transport_side_agree() on every rank,
+ * after pomgpu_set_transport and before pomgpu_set_wide_external.  agreed = 0 is accepted with any transport. */
+int pomgpu_transport_side_capable(pomgpu_ctx *ctx);
+int pomgpu_transport_side_agree(pomgpu_ctx *ctx, int agreed);
 /* message rounds served by the transport since it was set (measurement) */
 long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
 /* ... of them on the library's second stream (the early part of the wide exchange, wr): beside kernels, not between them */

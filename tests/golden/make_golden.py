@@ -2,7 +2,7 @@
 (oracle/_ref/libpomref_65x49x21.so, built from the unmodified sources by oracle/build_ref.sh) on
 the inputs of extpom_amd.cases.  Run from the repo root in a container that has /root/reference:
 
-    oracle/build_ref.sh 65 49 21 && oracle/build_ref.sh 256 192 50 && python tests/golden/make_golden.py [kb50 | forced]
+    oracle/build_ref.sh 65 49 21 && oracle/build_ref.sh 256 192 50 && python tests/golden/make_golden.py [kb50 | kb50long NAME | forced]
 
 The fixture holds, per configuration and checkpoint step, the SHA-256 of every restart-list field
 (the prognostic state, reference io_pnetcdf.F:1724-1886) exactly as the reference left it in its
@@ -55,6 +55,14 @@ CONFIGS_KB50 = {
 }
 
 
+# north_star's bar -- 1000 internal steps -- at the benchmark's level count: checkpoints 100 / 500 / 1000 of the reference
+# itself at 256x192x50 (about ten minutes of one core per configuration; `kb50long NAME` writes kb50_1000steps_NAME.json)
+CONFIGS_KB50_LONG = {
+    "basin50_default": ("basin", dict(dte=6.0, isplit=30), [100, 500, 1000]),
+    "seamount50_default": ("seamount", dict(dte=6.0, isplit=30), [100, 500, 1000]),
+}
+
+
 # One configuration stepped by the reference's OWN `advance` (advance.f:6-59) instead of the harness's restatement of its
 # sequence: surface_forcing and lateral_bc run as the reference calls them (their PnetCDF readers are the input hooks of
 # oracle/ref_traps.c, fed the records of extpom_amd.cases), print_section / write_output / write_restart stay silent
@@ -91,6 +99,9 @@ def generate_forced():
 def main():
     if "forced" in sys.argv[1:]:
         return generate_forced()
+    if "kb50long" in sys.argv[1:]:
+        name = sys.argv[sys.argv.index("kb50long") + 1]
+        return generate(256, 192, 50, {name: CONFIGS_KB50_LONG[name]}, {}, "kb50_1000steps_" + name)
     if "kb50" not in sys.argv[1:]:
         generate(65, 49, 21, CONFIGS, PLANES, "seamount_65x49x21")
     generate(256, 192, 50, CONFIGS_KB50, {}, "kb50_256x192x50")

@@ -41,7 +41,7 @@ def run(mover, wide):
                 if tile_nb[d] >= 0 and rcount[d]:
                     w(recv[d], rcount[d]).copy_(w(send[OPP[d]], scount[OPP[d]]))
         tile_nb = PomGpu.neighbours8(tile)
-        g.set_transport(tile, fn)
+        g.set_transport(tile, fn, agree=lambda mine: mine)        # one rank: its own answer is the minimum
     else:
         lib = rccl_library_path()
         g.rccl_init(tile, g.rccl_unique_id(lib), 0, 1, lib)
@@ -60,19 +60,25 @@ def main():
     ref, n_ref, err, _ = run("copy", False)
     assert err == 0 and n_ref > 100, (err, n_ref)
     assert np.isfinite(ref["u"]).all() and np.abs(ref["u"]).max() > 0
-    for mover, wide, overlap in (("rccl", False, True), ("copy", True, True), ("rccl", True, True), ("rccl", True, False)):
+    for mover, wide, overlap, split_fails in (("rccl", False, True, False), ("copy", True, True, False), ("rccl", True, True, False), ("rccl", True, False, False),
+                                              ("rccl", True, True, True)):
         # overlap: the early part of the wide exchange and the wr round on the library's second stream, over the second
-        # (split) communicator -- two rounds per internal step beside the kernels; POMGPU_NO_OVERLAP keeps one stream
+        # (split) communicator -- two rounds per internal step beside the kernels; POMGPU_NO_OVERLAP keeps one stream.
+        # split_fails: the rank behaves as if ncclCommSplit had failed -- the ranks' agreement (ncclAllReduce(min) inside
+        # pomgpu_rccl_init) then keeps every round on the main stream
         if overlap:
             os.environ.pop("POMGPU_NO_OVERLAP", None)
         else:
             os.environ["POMGPU_NO_OVERLAP"] = "1"
+        if split_fails:
+            os.environ["POMGPU_TEST_SPLIT_FAIL_RANK"] = "0"
         got, n, err, ns = run(mover, wide)
         os.environ.pop("POMGPU_NO_OVERLAP", None)
+        os.environ.pop("POMGPU_TEST_SPLIT_FAIL_RANK", None)
         bad = [f for f in ref if not np.array_equal(ref[f], got[f])]
         assert err == 0 and not bad, (mover, wide, err, bad[:10])
-        assert ns == (2 * STEPS if wide and overlap else 0), (mover, wide, overlap, ns)
-        print(f"{mover} wide={wide} overlap={overlap}: {n} message rounds on the kernels' stream + {ns} on the side stream "
+        assert ns == (2 * STEPS if wide and overlap and not split_fails else 0), (mover, wide, overlap, split_fails, ns)
+        print(f"{mover} wide={wide} overlap={overlap} split_fails={split_fails}: {n} message rounds on the kernels' stream + {ns} on the side stream "
               f"(per-point, copy mover: {n_ref}), fields identical")
     print("RCCL-SELF-OK")
 

@@ -51,7 +51,8 @@ def worker(rank, world, split, port, out, nml):
         if mode == "rccl":
             assert connect_rccl(g, tile, rank, world), "the RCCL transport could not connect the ranks"
         else:
-            g.set_transport(tile, StagedMover(g, tile, torch.device("cuda", 0)))
+            from extpom_amd.halo import dist_allmin
+            g.set_transport(tile, StagedMover(g, tile, torch.device("cuda", 0)), agree=dist_allmin())
         if mode in ("wide", "rccl"):
             tiles = [decomp.make_tile(r, IM, JM, iml, jml, n_proc=world) for r in range(world)]
             assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))

@@ -189,6 +189,12 @@ def test_output_and_restart_files_without_pnetcdf(tmp_path):
     g.download()
     g.close()
     kb = 21
+    # the WHOLE header of both files -- format version, global attributes, dimensions, every variable in definition order with
+    # its type, dimensions and every attribute text -- against tests/golden/cdf_schema.json, which make_cdf_schema.py reads out
+    # of the reference's own source (io_pnetcdf.F:6-40, :57-410, :1661-2083), not out of this repository
+    from cdf_check import check_header
+    for kind, name in (("output", "out.nc"), ("restart", "rst.nc")):
+        check_header(tmp_path / name, kind, "seamount test", "2000-01-01 00:00:00 +00:00", kb, 65, 49)
     with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
         assert f.version_byte == 2 and f.title == b"seamount test" and f.description == b"output file"
         assert {k: v for k, v in f.dimensions.items()} == dict(time=1, z=kb, zz=kb - 1, y=49, x=65)
@@ -316,7 +322,9 @@ def test_restart_and_determinism_properties_1024x1024x40():
     """config 3's grid on one GPU, size-independent properties: (i) two runs give identical bits,
     (ii) run(2n) == run(n) + download/upload + run(n) (the restart property), (iii) land stays
     masked, nothing non-finite, (iv) closed basin conserves volume: the area integral of et does
-    not drift, (v) one step equals the oracle's."""
+    not drift, (v) steps 1 AND 2 equal the oracle's on every field: at iint = 1 with time0 = 0 mode_internal skips its 3-D
+    body (advance.f:362), so step 2 is the first one in which advq / profq / advt2 / proft / advu / advv / profu / profv and
+    the filters run, on the default (fast) kernel shapes of this grid."""
     OracleTile, oracle_finish_initial = _oracle()
     a = make_case("basin", 1024, 1024, 40, dte=6.0, isplit=30)
     oracle_finish_initial(a)
@@ -342,15 +350,17 @@ def test_restart_and_determinism_properties_1024x1024x40():
         assert not np.any((x if x.ndim == 2 else x[:39]) * (1.0 - a.fsm)), f
     area = float((a.art * a.fsm).sum())
     assert abs(float((a.et * a.art * a.fsm).sum()) - vol0) / area < 1e-12
-    OracleTile(c).run(1)
-    d = c.copy()
-    d.blk2d[...] = 0
     e = make_case("basin", 1024, 1024, 40, dte=6.0, isplit=30)
     oracle_finish_initial(e)
     ge = _gpu(e)
-    ge.run(1)
-    ge.download()
-    assert not diff(c, e), diff(c, e)
+    oc = OracleTile(c)
+    for step in (1, 2):
+        oc.run(1)
+        ge.run(1)
+        ge.download()
+        assert not diff(c, e), f"step {step} differs from the oracle: {diff(c, e)}"
+    assert c.iint == 2 and e.iint == 2                # step 2: the 3-D body of mode_internal has run on both sides
+    ge.close()
 
 
 # ---- the instantiations bench.py runs: kb = 50 and 2048-wide rows ---------------------------------------------------
@@ -373,6 +383,36 @@ def test_gpu_reproduces_reference_digests_kb50(golden_kb50, name):
         done = step
         g.download()
         bad = [f for f in golden_kb50["fields"] if _digest(st.field(f)) != cfg["steps"][str(step)][f]]
+        assert not bad, f"{name}: step {step}: {bad} differ from the reference"
+    g.close()
+    assert st.error_status == 0
+
+
+@pytest.mark.parametrize("name", ["basin50_default", "seamount50_default"])
+def test_1000_internal_steps_kb50_hash_to_the_reference(name):
+    """north_star's bar -- all prognostic fields after 1000 internal steps -- at the benchmark's level count, pinned to the
+    REFERENCE ITSELF: digests of every restart-list field after 100 / 500 / 1000 steps of oracle/_ref/libpomref_256x192x50.so
+    (tests/golden/kb50_1000steps_<name>.json, make_golden.py kb50long; ten minutes of one core each in the build container).
+    north_star asks for 1e-10 relative; equal digests mean the difference is exactly zero."""
+    import json
+    import os
+    OracleTile, oracle_finish_initial = _oracle()
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", f"kb50_1000steps_{name}.json")))
+    cfg = gold["configs"][name]
+    im, jm, kb = gold["grid"]
+    assert kb == 50 and sorted(int(s) for s in cfg["steps"]) == [100, 500, 1000]
+    st = make_case(cfg["case"], im, jm, kb, **cfg["nml"])
+    oracle_finish_initial(st)
+    bad = [f for f in gold["fields"] if _digest(st.field(f)) != cfg["init"][f]]
+    assert not bad, f"{name}: initial state: {bad}"
+    g = _gpu(st)
+    done = 0
+    for step in (100, 500, 1000):
+        g.run(step - done)
+        done = step
+        g.download()
+        bad = [f for f in gold["fields"] if _digest(st.field(f)) != cfg["steps"][str(step)][f]]
         assert not bad, f"{name}: step {step}: {bad} differ from the reference"
     g.close()
     assert st.error_status == 0
@@ -432,10 +472,13 @@ def test_100_internal_steps_256x192x50_within_1e_10():
 
 
 def test_config4_2048x1536x50_full_size():
-    """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU: (i) ONE step, every field
-    array_equal to the oracle (about a minute of CPU), (ii) the restart property: the device's second step equals a
-    second step started from the ORACLE's first-step state uploaded into a fresh context, (iii) two contexts fed the
-    same state produce the same bits over 20 more steps, one on the large-grid kernel shapes and one on the general ones, (iv) land stays masked, nothing non-finite.  ~50 GB per host copy of the state."""
+    """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU, default (fast) kernel shapes:
+    (i) steps 1 AND 2, every field array_equal to the oracle.  Step 1 (iint = 1, time0 = 0) skips mode_internal's 3-D body
+    (advance.f:362); step 2 is the first in which k_profq<1,1,8>, k_advt2_col<2>, k_advq_col<2>, k_advct_col, k_advuv_col in
+    strip order, k_ts_update and the <50> register kernels run AT THE BENCHMARKED LAUNCH GEOMETRY -- it is compared with the
+    oracle directly (about two minutes of one CPU core for the two oracle steps); (ii) two contexts fed the same state produce the same bits over 20 more steps, one on
+    the large-grid kernel shapes and one on the general ones; (iii) land stays masked, nothing non-finite.
+    ~50 GB per host copy of the state."""
     import os
     import time
     OracleTile, oracle_finish_initial = _oracle()
@@ -451,22 +494,19 @@ def test_config4_2048x1536x50_full_size():
     beat("case built")
     c = a.copy()
     ga = _gpu(a)
-    ga.run(1)
-    ga.download()
-    beat("device step 1 downloaded")
-    OracleTile(c).run(1)
-    beat("oracle step 1 done")
-    bad = diff(a, c)
-    assert not bad, f"step 1 differs from the oracle: {bad}"
-    beat("step 1 compared")
-    ga.run(1)
-    ga.download()
-    gc = _gpu(c)                                     # the oracle's state after one step, uploaded
-    gc.run(1)
-    gc.download()
-    beat("step 2 both ways")
-    bad = diff(a, c)
-    assert not bad, f"restart property: {bad}"
+    oc = OracleTile(c)
+    for step in (1, 2):
+        ga.run(1)
+        ga.download()
+        beat(f"device step {step} downloaded")
+        oc.run(1)
+        beat(f"oracle step {step} done")
+        bad = diff(a, c)
+        assert not bad, f"step {step} differs from the oracle: {bad}"
+        beat(f"step {step} compared")
+    assert a.iint == 2 and c.iint == 2               # the 3-D body ran on both sides (advance.f:362)
+    del oc
+    gc = _gpu(c)                                     # the oracle's state after two steps, uploaded
     # 20 more steps: one context on the large-grid fast paths (the external substep marching down the rows, k_profq in 8 paced
     # rows with its vectors in LDS, strip order), the other on the shapes small grids use -- the same bits
     ga.run(20)

@@ -127,6 +127,10 @@ def test_output_and_restart_files_read_back(tmp_path):
     g.write_file("output", tmp_path / "out.nc", title="island", time_start="2000-01-01 00:00:00 +00:00")
     g.write_file("restart", tmp_path / "rst.nc", title="island", time_start="2000-01-01 00:00:00 +00:00")
     g.download()
+    # the WHOLE header of both files against what the reference's own source defines (tests/golden/cdf_schema.json)
+    from cdf_check import check_header
+    for kind, name in (("output", "out.nc"), ("restart", "rst.nc")):
+        check_header(tmp_path / name, kind, "island", "2000-01-01 00:00:00 +00:00", 21, 65, 49)
     with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
         assert f.version_byte == 2 and f.description == b"output file"
         assert dict(f.dimensions) == dict(time=1, z=21, zz=20, y=49, x=65)

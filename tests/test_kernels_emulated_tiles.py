@@ -37,6 +37,14 @@ class Board:
         self.box = {}
         self.barrier = threading.Barrier(world)
 
+    def allmin(self, me, value):
+        """the host's reduction behind pomgpu_transport_side_agree: the minimum of `value` over all ranks"""
+        self.box[("min", me)] = int(value)
+        self.barrier.wait()
+        m = min(v for k, v in self.box.items() if k[0] == "min")
+        self.barrier.wait()
+        return m
+
 
 def view(ptr, nz, tile):
     n = nz * tile.jm_local * tile.im_local
@@ -125,7 +133,7 @@ OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
 
 
 def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None,
-              by_routine=False, records=False, dte=6.0):
+              by_routine=False, records=False, dte=6.0, side_fail_rank=None, side_rounds=None):
     world = nx * ny
     IMg, JMg = grid or (IM, JM)
     iml, jml = decomp.local_size(IMg, JMg, nx, ny)
@@ -147,7 +155,9 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
                     exchange(board, tile, [view(p, nz, tile) for p, nz in zip(ptrs, nzs)])
 
             if library_exchange:                     # the library packs, moves and unpacks by itself
-                g.set_transport(tile, lambda *a: transport(board, tile, *a))
+                # side-stream rounds: the ranks' own answers reduced to their minimum (side_fail_rank: that rank says no)
+                g.set_transport(tile, lambda *a: transport(board, tile, *a),
+                                agree=lambda mine: board.allmin(r, 0 if r == side_fail_rank else mine))
                 if wide:
                     assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
             else:
@@ -190,6 +200,8 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
                 g.run(steps or STEPS)
             g.download()
             out[r] = (tile, st, g.exchange_rounds() if library_exchange else count[0])
+            if side_rounds is not None and library_exchange:
+                side_rounds[r] = g.exchange_rounds_side()
         except Exception as e:                      # a dead rank must not leave the others at the barrier
             errs.append(e)
             board.barrier.abort()
@@ -264,6 +276,24 @@ def test_wide_halo_external_mode(nx, ny, case, nml):
         for n in ("ua", "va", "el", "elb", "d", "uab", "vab", "etf", "egf", "utf", "vtf", "adx2d", "ady2d", "advua", "advva", "elf", "uaf", "vaf"):
             t = wide[r][0]
             assert np.array_equal(wide[r][1].field(n)[:t.jm, :t.im], narrow[r][1].field(n)[:t.jm, :t.im]), (r, n)
+
+
+def test_side_stream_rounds_are_a_collective_decision():
+    """Rounds on the library's second stream (the early part of the wide exchange, wr) run on all ranks or on none: one rank of
+    2x2 that reports it cannot serve them (a failed ncclCommSplit / hipStreamCreate in production) keeps EVERY rank on the
+    main stream -- no rank posts a round its neighbours do not expect --, the results stay bit-identical, and the step
+    has the same total number of rounds.  With every rank able, two rounds per step move to the second stream."""
+    counts = {}
+    for fail in (None, 2):
+        side = {}
+        out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, side_fail_rank=fail, side_rounds=side)
+        compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10, ghosts=False)
+        counts[fail] = ({r: v[2] for r, v in out.items()}, side)
+    (main_all, side_all), (main_one, side_one) = counts[None], counts[2]
+    assert set(side_one.values()) == {0}, side_one                     # nobody went to the second stream
+    assert set(side_all.values()) == {2 * STEPS}, side_all             # early gather + wr, every step, every rank
+    for r in main_all:       # per step: 8 rounds between kernels + 2 beside them, or 9 between kernels (wr back, the gather one round instead of early + late)
+        assert main_one[r] == main_all[r] + STEPS, (main_one, main_all, side_all)
 
 
 def test_wide_halo_too_narrow_shows_up(monkeypatch):

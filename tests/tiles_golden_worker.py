@@ -54,7 +54,8 @@ def worker(rank, world, port, out, name, mode):
             keep = DeviceHalo(g, tile, dev, staged=True)      # noqa: F841
             g.set_order_exchange(Halo(tile, staged=True).device_order_hook(dev))
         else:
-            g.set_transport(tile, StagedMover(g, tile, dev))
+            from extpom_amd.halo import dist_allmin
+            g.set_transport(tile, StagedMover(g, tile, dev), agree=dist_allmin())
             if mode == "wide":
                 tiles = [decomp.make_tile(r, IM, JM, IML, JML, n_proc=world) for r in range(world)]
                 assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
