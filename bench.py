@@ -321,6 +321,7 @@ def main():
         sys.exit(2)
     from extpom_amd import lib as _L
     g = gpu_initialise(st, local, stream, _L.LIBPATH_F32 if f32 else None)
+    build_id = g.L.pomgpu_build_id().decode()
     exchange = "none"
     # N > 1: a rank that is lost, or a message round whose partner never posts, would leave the others waiting inside
     # RCCL for ever.  Every phase -- connecting, the first steps (RCCL sets its channels up lazily), the timed steps --
@@ -420,21 +421,42 @@ def main():
         roof = None
         if nl and passes:
             ach = passes * (4.0 if f32 else 8.0) * tile_cells / (tms / nl * 1e-3) / 1e9
-            traffic = None
+            # HBM-side bytes per launch from the PMC counters (profiles/traffic.json, tools/make_traffic_json.py): quoted only for
+            # the library build the counters were taken from -- after a kernel change the stored number says nothing
+            traffic, traffic_note = None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf) and not f32:
-                rec = json.load(open(tf)).get(f"{args.workload}/{world}/{dom}")
-                traffic = rec["bytes_per_launch"] if rec else None
+                tj = json.load(open(tf))
+                rec = tj.get(f"{args.workload}/{world}/{dom}")
+                if rec and tj.get("_build_id") == build_id:
+                    traffic = rec["bytes_per_launch"]
+                elif rec:
+                    traffic_note = f"profiles/traffic.json holds counters of build {tj.get('_build_id')}, this library is {build_id}: not quoted"
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_ceiling": round(ach / HBM_COPY_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": passes * (4 if f32 else 8) * tile_cells, "launches": nl,
                     "avg_launch_ms": round(tms / nl, 4)}
+            if traffic_note:
+                roof["traffic_note"] = traffic_note
         # internal (3-D) mode alone, from the all-kernels profiled step: everything but the 2-D kernels
         ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_check_areas", "k_copy2", "k_bcond1")
         msg_ms = prof.pop("msg_round", (0, 0.0))[1]           # the message rounds of the profiled step (N > 1): not a kernel
         msg_side_ms = prof.pop("msg_round_side", (0, 0.0))[1] # ... those on the library's second stream: beside kernels, not between them
-        int_ms = sum(v[1] for k, v in prof.items() if not k.startswith(ext))
-        ext_ms = sum(v[1] for k, v in prof.items() if k.startswith(ext))
+        prof.pop("phase_step", None); prof.pop("phase_external", None)
+        int_ms_one = sum(v[1] for k, v in prof.items() if not k.startswith(ext))    # the profiled step: sum of kernel durations
+        ext_ms_one = sum(v[1] for k, v in prof.items() if k.startswith(ext))
+        # the TIMED region: every step bracketed as a whole and around its external substeps (events on the kernels' stream):
+        # K-step means, measured while only the dominant kernel carries events of its own
+        nst, step_dev_ms = timed.get("phase_step", (0, 0.0))
+        nex, ext_dev_ms = timed.get("phase_external", (0, 0.0))
+        if nst == args.steps and nex == args.steps:
+            ext_ms = ext_dev_ms / nex
+            int_ms = step_dev_ms / nst - ext_ms
+            int_note = (f"mean over the {args.steps} timed steps on rank 0: device time of the step (events around pomgpu_advance on the kernels' stream) minus "
+                        "the device time of its isplit external substeps; advave / the 2-D tail of mode_interaction (once per step) count as internal here")
+        else:
+            int_ms, ext_ms = int_ms_one, ext_ms_one
+            int_note = "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"
         BPV = 4.0 if f32 else 8.0                              # bytes per stored 3-D value
         step_gbs = P_STEP * BPV * cells / (dt / args.steps) / 1e9
         share = sorted(((k, v[1]) for k, v in prof.items()), key=lambda kv: -kv[1])
@@ -456,8 +478,10 @@ def main():
                               "algorithmic_GBps": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9, 1) if int_ms else None,
                               "frac_of_peak": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if int_ms else None,
                               "frac_of_measured_copy_ceiling": round(P_STEP * BPV * tile_cells / (int_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if int_ms else None,
-                              "note": "sum of 3-D kernel durations of one profiled step on rank 0 (its tile only)"},
-            "external_mode": {"device_ms_per_step": round(ext_ms, 3)},
+                              "note": int_note, "profiled_step_kernel_sum_ms": round(int_ms_one, 3)},
+            "external_mode": {"device_ms_per_step": round(ext_ms, 3), "profiled_step_kernel_sum_ms": round(ext_ms_one, 3)},
+            "device_ms_per_step": round(step_dev_ms / nst, 3) if nst else None,
+            "library_build_id": build_id,
             # all kernels of one profiled step on rank 0 (without the RCCL transfers): at N > 1, ms_per_step minus this is what
             # the message rounds and the waiting for neighbours cost
             "kernel_ms_sum_rank0": round(sum(v[1] for v in prof.values()), 3),

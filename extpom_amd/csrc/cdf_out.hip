@@ -170,6 +170,9 @@ static int write_file(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m
     return fail(c, POMGPU_EINVAL, "write: the tile (%d..%d, %d..%d) does not fit the global grid %d x %d", m->i0, m->i0 + P.im - 1, m->j0,
                 m->j0 + P.jm - 1, m->im_global, m->jm_global);
   { const int rcw = pomgpu_io_wait(c); if (rcw) return rcw; }  // one file in flight at a time
+  // the snapshot below reads the mirrors directly: whatever the library keeps lazily is brought up to date first, whether or not
+  // the caller supplied the statistics (pomgpu_domain_stats would have done it as a side effect)
+  { const int rcm = pomgpu_materialize(c); if (rcm) return rcm; }
   const std::string h = header(S);
   const int fd = open(path, m->create ? (O_WRONLY | O_CREAT | O_TRUNC) : O_WRONLY, 0644);
   if (fd < 0) return fail(c, POMGPU_EINVAL, "write: cannot open %s", path);

@@ -572,17 +572,9 @@ __device__ __forceinline__ void uvaf_cell_nb(const KP &P, int i, int j, double e
   uo = u;
   vo = v;
 }
-// the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells.
+// One cell of a substep by the general formulas (any cell: rim cells with bcond(1) / bcond(2), interior cells alike), from memory.
 // fuse_adv: advua, advva are formed here (advave is part of this substep's kernel) instead of read
-__device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, int fuse_adv) {
-  const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
-  int i, j;
-  if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
-  else {
-    const int q = t - 3 * im;
-    if (ncol <= 0 || q >= 3 * ncol) return;
-    const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
-  }
+__device__ __forceinline__ void ext_cell_general(const KP &P, int i, int j, int store_f, int fuse_adv) {
   double ec, ew, es, u, v, adu, adv;
   if (fuse_adv) {                                           // the fused kernel's rim: branch-free forms, loads in flight together
     ec = elf_at_nb(P, i, j); ew = elf_at_nb(P, i - 1, j); es = elf_at_nb(P, i, j - 1);
@@ -600,6 +592,35 @@ __device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, in
     if (fuse_adv) { F2(advua, i, j) = adu; F2(advva, i, j) = adv; }
   }
   ext_update_cell(P, i, j, true, ec, u, v, ew, es);
+}
+// the three outermost lines on every side, with bcond(1) and bcond(2); t numbers their cells.
+__device__ __forceinline__ void ext_rim_cell(const KP &P, int t, int store_f, int fuse_adv) {
+  const int im = P.im, jm = P.jm, ncol = jm - 3;          // rows 1, 2, jm in full; columns 1, 2, im for j = 3..jmm1
+  int i, j;
+  if (t < 3 * im) { const int r = t / im; i = t - r * im + 1; j = r == 0 ? 1 : (r == 1 ? 2 : jm); }
+  else {
+    const int q = t - 3 * im;
+    if (ncol <= 0 || q >= 3 * ncol) return;
+    const int r = q / ncol; j = 3 + (q - r * ncol); i = r == 0 ? 1 : (r == 1 ? 2 : im);
+  }
+  ext_cell_general(P, i, j, store_f, fuse_adv);
+}
+// A ring of cells: lines 1..nlo and the last nhi ones on every side (rows in full, columns for the rows between); t numbers its
+// cells.  With (nlo, nhi) = (2, 1) it is the rim; k_ext_march2 leaves (4, 2) to it.  advave is formed in place.
+__device__ __forceinline__ int ext_ring_count(const KP &P, int nlo, int nhi) {
+  const int nl = nlo + nhi, mid = P.jm - nl;
+  return nl * P.im + (mid > 0 ? nl * mid : 0);
+}
+__device__ __forceinline__ void ext_ring_cell(const KP &P, int t, int store_f, int nlo, int nhi) {
+  const int im = P.im, jm = P.jm, nl = nlo + nhi, mid = jm - nl;
+  int i, j;
+  if (t < nl * im) { const int r = t / im; i = t - r * im + 1; j = r < nlo ? r + 1 : jm - nl + r + 1; }
+  else {
+    const int q = t - nl * im;
+    if (mid <= 0 || q >= nl * mid) return;
+    const int r = q / mid; j = nlo + 1 + (q - r * mid); i = r < nlo ? r + 1 : im - nl + r + 1;
+  }
+  ext_cell_general(P, i, j, store_f, 1);
 }
 // ---------------------------------------------------------------------------------------------
 // mode_external, single tile: ONE kernel per substep.  With nothing to exchange between the
@@ -982,6 +1003,334 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
 #undef ES
 }
 
+// ---- TWO substeps per pass over memory (large tiles) --------------------------------------------------------------------
+// k_ext_march moves 1.1-1.2 GB per substep at ~5.6 TB/s: it sits on the practical HBM ceiling, only fewer bytes help.  Of
+// the ~36 array passes of a substep 16 are operands that do not change during the external loop (metrics, depth, Coriolis,
+// the vertical integrals, surface / bottom stress ...), 7 are the generation it reads and 7 the generation it writes -- which
+// the next substep reads again.  Here a wavefront that marches down its rows carries a SECOND generation one row behind the
+// first: substep n is evaluated for row t from the operands in memory (generation X) exactly as k_ext_march does it, its
+// results (generation Y: ua, va, d, el, elb, uab, vab of row t) stay in registers, and substep n+1 is evaluated for row t-1
+// from the Y rows t-2, t-1, t and the same static operands; only its results (generation Z) and the accumulators with BOTH
+// contributions are stored.  Per pair of substeps the statics and X are read once and Y never touches memory: ~38 passes
+// instead of ~72.  The arithmetic of a row is ONE function (ext_row_math) used by both generations: the same expressions on
+// the same operands in the same order as k_ext_step / k_ext_march, so the bits do not change.
+//  * Columns: substep n+1 at column i reads Y at i-2 .. i+1.  Of a wavefront's 64 lanes the first substep is right on lanes
+//    1..62 (d and the elevation on 0..62, thanks to lane 0's two true western operands), the second on lanes 2..61: a
+//    wavefront owns 60 columns.
+//  * Rows: a segment of `rows` rows of substep n+1 (j0..j1) needs Y rows j0-2 .. j1+1, i.e. substep n on rows+3 rows and a
+//    warm-up row: taller segments than k_ext_march's (the redundant part is (rows + 4.5) / rows per pair).
+//  * Ring: the lines 1..4 and the last two on every side are not marched (substep n+1 at line 3 would need Y of the rim lines
+//    1, 2 with their boundary conditions).  ext_ring_cell evaluates BOTH substeps there by the general cell formulas: substep
+//    n (X -> a third buffer set T) as the first workgroups of this kernel's own launch, substep n+1 (T -> Z) as a small launch
+//    after it (k_ext_ring), for which this kernel stores the Y cells of the two lines next to the ring into T.  The marched
+//    cells need nothing from the ring: Y of lines 3, 4 are plain interior cells of substep n, evaluated here from X.
+//  * One wave per SIMD (~400 registers): 4 wavefronts per CU with ~50 loads in flight each keep the memory pipes busy; the
+//    kernel is then bound about evenly by the issue of its ~1300 instructions per row pair and by its traffic.
+#ifndef POMGPU_EMU
+struct XRow { double d, ua, va, uab, vab, dW; };            // one row of the time-dependent stencil operands; dW: d of column i-1
+struct SRow { double dx, dy, am, dyW; };                    // one row of the static stencil operands; dyW: dy of column i-1
+struct PRow { double el, elb; };                            // the two time-dependent operands read at (i, i-1) x (j, j-1) only
+struct SPt {                                                // static pointwise operands of one row
+  double vfl, ea, h, cor, adx2d, aru, drx2d, wusurf, wubot, ady2d, arv, dry2d, wvsurf, wvbot, art;
+  unsigned mk;
+};
+struct SPm { double ea, h, cor; };                          // ... what the row below still needs of them
+struct ECarry { double fva_0, es, tps0, fv0, gvM, el_m1, elb_m1; };   // what row j hands to row j+1 (one set per generation)
+struct EOut { double ec, ew, hW, esm, u, v, advua, advva, uab_n, vab_n, elb_n, dn; };
+// One row of one substep on register operands: rows m = j-1 (rm, sm), 0 = j (rc, sc), p = j+1 (rp, sp); qm: e_atmos, h, cor
+// of row j-1.  LIVE = false: the warm-up row of a segment -- continuity and the three advave terms row j+1 takes over, no
+// momentum.  Every lane must call it (neighbour-lane shifts); as row_step of k_ext_march, operand for operand.
+template <bool LIVE>
+__device__ __forceinline__ void ext_row_math(const KP &P, const bool canon, const bool fu_on, const bool w_on, const XRow &rm, const XRow &rc,
+                                             const XRow &rp, const SRow &sm, const SRow &sc, const SRow &sp, const PRow &pc, const SPt &q,
+                                             const SPm &qm, ECarry &cy, EOut &o) {
+  const double fsm_0 = (double)(q.mk & 1u), dum_0 = (double)((q.mk >> 1) & 1u), dvm_0 = (double)((q.mk >> 2) & 1u);
+  const double el_0 = pc.el, elb_0 = pc.elb;
+  // ---- neighbour-lane operands
+  const double dxW_0 = wave_up1(sc.dx), dxW_p1 = wave_up1(sp.dx);
+  const double corW_0 = wave_up1(q.cor), vaW_0 = wave_up1(rc.va), vaW_p1 = wave_up1(rp.va);
+  const double elW_0 = wave_up1(el_0), elbW_0 = wave_up1(elb_0), eaW_0 = wave_up1(q.ea), hW_0 = wave_up1(q.h);
+  const double uaE_0 = wave_dn1(rc.ua), uaE_m1 = wave_dn1(rm.ua);
+  // ---- continuity (advance.f:211-231) at (i,j); (i,j-1) is the row above's, the west value the neighbour lane's
+  const double dysx_0 = sc.dy + sc.dyW, dxsy_0 = sc.dx + sm.dx, dxsy_p1 = sp.dx + sc.dx;
+  const double art_0 = canon ? sc.dx * sc.dy : q.art;                                        // initialize.f:361
+  double aru = q.aru, arv = q.arv;
+  if (canon) { aru = .25 * (sc.dx + dxW_0) * dysx_0; arv = .25 * dxsy_0 * (sc.dy + sm.dy); }   // :366-367
+  const double fua_0 = .25 * (rc.d + rc.dW) * dysx_0 * rc.ua;
+  const double fuaE_0 = wave_dn1(fua_0);
+  const double fva_p1 = .25 * (rp.d + rc.d) * dxsy_p1 * rp.va;
+  const double ec = (elb_0 + P.dte2 * (-(fuaE_0 - fua_0 + fva_p1 - cy.fva_0) / art_0 - q.vfl)) * fsm_0;
+  const double ew = wave_up1(ec);
+  // ---- advave (solver.f:16-121) on register operands; tps0, fv0, gvM are the row above's tpsP, fvP, gv0
+  double fu = 0., gu = 0., fvP = 0., gv0 = 0., tpsP = 0.;
+  {
+    const double dE_0 = wave_dn1(rc.d), uabE_0 = wave_dn1(rc.uab);
+    const double vabW_p1 = wave_up1(rp.vab);
+    const double amW_0 = wave_up1(sc.am), amW_p1 = wave_up1(sp.am);
+    const double DY4_0 = sc.dy + sc.dyW + sm.dy + sm.dyW, DY4_p1 = sp.dy + sp.dyW + sc.dy + sc.dyW;
+    const double DX4_p1 = sp.dx + dxW_p1 + sc.dx + dxW_0;
+    if (LIVE && fu_on) {
+      double f = .125 * ((dE_0 + rc.d) * uaE_0 + (rc.d + rc.dW) * rc.ua) * (uaE_0 + rc.ua);
+      f = f - rc.d * 2. * sc.am * (uabE_0 - rc.uab) / sc.dx;
+      fu = f * sc.dy;
+    }
+    if (w_on) {
+      tpsP = .25 * (rp.d + rp.dW + rc.d + rc.dW) * (sp.am + sc.am + amW_p1 + amW_0) *
+             ((rp.uab - rc.uab) / DY4_p1 + (rp.vab - vabW_p1) / DX4_p1);
+      if (LIVE) {
+        const double g = .125 * ((rc.d + rc.dW) * rc.ua + (rm.d + rm.dW) * rm.ua) * (vaW_0 + rc.va);
+        gu = (g - cy.tps0) * .25 * DY4_0;
+      }
+      const double fP = .125 * ((rp.d + rc.d) * rp.va + (rp.dW + rc.dW) * vaW_p1) * (rp.ua + rc.ua);
+      fvP = (fP - tpsP) * .25 * DX4_p1;
+      double gv = .125 * ((rp.d + rc.d) * rp.va + (rc.d + rm.d) * rc.va) * (rp.va + rc.va);
+      gv = gv - rc.d * 2. * sc.am * (rp.vab - rc.vab) / sc.dy;
+      gv0 = gv * sc.dx;
+    }
+  }
+  o.ec = ec; o.ew = ew; o.hW = hW_0; o.esm = cy.es;
+  if (LIVE) {
+    const double fu_w = wave_up1(fu);
+    const double gu_e = wave_dn1(gu);
+    const double advua = fu - fu_w + fvP - cy.fv0;            // :65-66
+    const double advva = gu_e - gu + gv0 - cy.gvM;            // :116-117
+    // ---- momentum (advance.f:237-290)
+    double u = q.adx2d + advua - aru * .25 * (q.cor * rc.d * (rp.va + rc.va) + corW_0 * rc.dW * (vaW_p1 + vaW_0)) +
+               .25 * P.grav * dysx_0 * (rc.d + rc.dW) *
+                   ((1. - 2. * P.alpha) * (el_0 - elW_0) + P.alpha * (elb_0 - elbW_0 + ec - ew) + q.ea - eaW_0) +
+               q.drx2d + aru * (q.wusurf - q.wubot);
+    u = ((q.h + elb_0 + hW_0 + elbW_0) * aru * rc.uab - 4. * P.dte * u) / ((q.h + ec + hW_0 + ew) * aru);
+    double v = q.ady2d + advva + arv * .25 * (q.cor * rc.d * (uaE_0 + rc.ua) + qm.cor * rm.d * (uaE_m1 + rm.ua)) +
+               .25 * P.grav * dxsy_0 * (rc.d + rm.d) *
+                   ((1. - 2. * P.alpha) * (el_0 - cy.el_m1) + P.alpha * (elb_0 - cy.elb_m1 + ec - cy.es) + q.ea - qm.ea) +
+               q.dry2d + arv * (q.wvsurf - q.wvbot);
+    v = ((q.h + elb_0 + qm.h + cy.elb_m1) * arv * rc.vab - 4. * P.dte * v) / ((q.h + ec + qm.h + cy.es) * arv);
+    u = u * dum_0;
+    v = v * dvm_0;
+    o.u = u; o.v = v; o.advua = advua; o.advva = advva;
+    // ---- the next generation of this cell: Asselin filter and time rotation (:321-330)
+    o.uab_n = rc.ua + .5 * P.smoth * (rc.uab - 2. * rc.ua + u);
+    o.vab_n = rc.va + .5 * P.smoth * (rc.vab - 2. * rc.va + v);
+    o.elb_n = el_0 + .5 * P.smoth * (elb_0 - 2. * el_0 + ec);
+    o.dn = q.h + ec;
+  }
+  // ---- one row down
+  cy.fva_0 = fva_p1; cy.es = ec;
+  cy.tps0 = tpsP; cy.fv0 = fvP; cy.gvM = gv0;
+  cy.el_m1 = el_0; cy.elb_m1 = elb_0;
+}
+struct Gen7 { double *p[POMGPU_NGEN]; };
+// One generation of ua, va, d, el, elb, uab, vab behind ONE buffer descriptor: array g starts off[g] bytes into `base` (the blk2d block
+// with the arrays' slot offsets, or a buffer set of its own).  A descriptor per array (4 SGPRs each, 21 of them for three generations)
+// spilled ~180 SGPRs in k_ext_march2 -- ~200 v_readlane / v_writelane / s_mov per row.
+struct GenD { const double *base; unsigned bytes; unsigned off[POMGPU_NGEN]; };
+// etf of one substep (advance.f:295-318): e = the value before, ec the substep's new elevation
+__device__ __forceinline__ double etf_rule(const KP &P, int iext, double e, double ec, double fsm) {
+  if (iext == P.isplit - 2) return .25 * P.smoth * ec;
+  if (iext == P.isplit - 1) return e + .5 * (1. - .5 * P.smoth) * ec;
+  if (iext == P.isplit) return (e + .5 * ec) * fsm;
+  return e;
+}
+struct YRow { XRow x; PRow p; };
+struct EAcc { double egf, utf, vtf, etf; };
+// The cells this kernel leaves to k_ext_ring (both substeps): lines 1..RING_LO and the last RING_HI ones on every side.  Substep
+// n+1 at line 5 reads Y of lines 3, 4 -- plain interior cells of substep n, evaluated here from X (rows 1, 2 of X are in memory) --
+// so this kernel needs nothing from the ring: its launch carries the ring's substep n as its first workgroups.
+#define RING_LO 4
+#define RING_HI 2
+// P.iext = n (the first substep of the pair), P.x2 = generation X, P.y2 = generation Z; T: generation Y next to the ring, for
+// the ring's second substep
+__global__ void __launch_bounds__(256) k_ext_march2(KP P, Gen7 T, GenD GX, GenD GZ, GenD GT, int store_f2, int ring_wgs, int rows, const int *areas, int use_areas) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;
+  if (wg < ring_wgs) {                                       // the ring's FIRST substep (X -> T), beside the marching workgroups
+    KP R = P;
+#pragma unroll
+    for (int g = 0; g < POMGPU_NGEN; g++) R.y2[g] = T.p[g];
+    ext_ring_cell(R, wg * 256 + (int)threadIdx.y * 64 + lane, 0, RING_LO, RING_HI);
+    return;
+  }
+  const int L = wg - ring_wgs;
+  // A workgroup = four ADJACENT wavefronts of one segment (not four segments of one column block as in k_ext_march): the segments
+  // are tall here (one round of workgroups: ~55 rows at 2048x1536), and four wavefronts a megabyte apart in each of ~30 arrays
+  // cycle through more 2-MiB pages than a CU's first-level TLB holds (k_profq's lesson, profiles/round2_tlb_profq.txt) -- side by
+  // side they read the same rows of the same pages.  Workgroups in segment-major order: consecutive ones (dealt to the eight XCDs
+  // in turn) are neighbours along the row.
+  const int jlo = RING_LO + 1, jhi = P.jm - RING_HI, ilo = RING_LO + 1, ihi = P.im - RING_HI;      // the cells of substep n+1 marched here
+  const int nbx = (ihi - 2) / 60 + 1, ncg = (nbx + (int)blockDim.y - 1) / (int)blockDim.y;
+  const int nseg_ = (jhi - jlo + 1 + rows - 1) / rows;
+  const int seg = L / ncg, bx = (L % ncg) * (int)blockDim.y + (int)threadIdx.y;
+  if (seg >= nseg_ || bx >= nbx) return;                      // a whole wavefront
+  const int j0 = jlo + seg * rows;
+  const int j1 = (j0 + rows - 1 < jhi) ? j0 + rows - 1 : jhi;
+  const int i0 = bx * 60 + lane;
+  const bool own = (lane >= 2 && lane <= 61);               // the 60 columns of this wavefront
+  const bool out2 = own && i0 >= ilo && i0 <= ihi;
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);    // halo / padding lanes shadow a valid column
+  const int iw = i > 1 ? i - 1 : 1;
+  const unsigned vo = (unsigned)(i - 1) * 8u;
+  const unsigned voW = (lane == 0) ? (unsigned)(iw - 1) * 8u : BOFF_NONE;
+  const unsigned o_st = out2 ? vo : BOFF_NONE;
+  // generation Y goes to T where the ring's second substep will read it: two lines next to the ring
+  const bool bandcol = (i0 > RING_LO && i0 <= RING_LO + 2) || (i0 >= P.im - RING_HI - 1 && i0 <= P.im - RING_HI);
+#define RO(row) ((unsigned)WAVE_UNIFORM((row) - 1) * (unsigned)P.iml * 8u)
+#define XLD(g, voff, ro_) bld2(bX, (voff), GX.off[g] + (ro_))
+#define ZST(g, voff, ro_, x) bst2(bZ, (voff), GZ.off[g] + (ro_), (x))
+#define TST(g, voff, ro_, x) bst2(bT, (voff), GT.off[g] + (ro_), (x))
+#define FLD(name, voff, ro_) bld2(b2d, (voff), (unsigned)(P2_##name * P.n2 * 8u) + (ro_))
+#define FST(name, voff, ro_, x) bst2(b2d, (voff), (unsigned)(P2_##name * P.n2 * 8u) + (ro_), (x))
+  const BufA b2d = buf2_of(P.b2, (size_t)POM_NBLK2D * P.n2);
+  BufA bX, bZ, bT;
+  bX.r = __builtin_amdgcn_make_buffer_rsrc((void *)GX.base, 0, GX.bytes, 0x00020000);
+  bZ.r = __builtin_amdgcn_make_buffer_rsrc((void *)GZ.base, 0, GZ.bytes, 0x00020000);
+  bT.r = __builtin_amdgcn_make_buffer_rsrc((void *)GT.base, 0, GT.bytes, 0x00020000);
+  const bool canon = use_areas && WAVE_UNIFORM(*areas) != 0;
+  const unsigned o_area = canon ? BOFF_NONE : vo;
+  const int n1 = P.iext, n2 = P.iext + 1;                   // the two substeps; the first one always accumulates (n1 < isplit)
+  const bool acc2 = (n2 != P.isplit);
+  const bool etf_ld = (n2 >= P.isplit - 1), etf_st = (n2 >= P.isplit - 2);
+  const bool fu_on = (i0 >= 2 && i0 <= P.imm1), w_on = (i0 >= 2 && i0 <= P.im);
+  const int jcl = P.jml;
+  auto clampr = [&](int r) { return r < 1 ? 1 : (r > jcl ? jcl : r); };
+  auto load_x = [&](int row, XRow &r, SRow &s_) {
+    const unsigned ro = RO(clampr(row));
+    r.d = XLD(X2_d, vo, ro); r.ua = XLD(X2_ua, vo, ro); r.va = XLD(X2_va, vo, ro);
+    s_.dx = FLD(dx, vo, ro); s_.dy = FLD(dy, vo, ro);
+    r.uab = XLD(X2_uab, vo, ro); r.vab = XLD(X2_vab, vo, ro); s_.am = FLD(aam2d, vo, ro);
+    r.dW = XLD(X2_d, voW, ro); s_.dyW = FLD(dy, voW, ro);
+  };
+  auto fix_w = [&](XRow &r, SRow &s_) { r.dW = west_true(r.d, r.dW, lane); s_.dyW = west_true(s_.dy, s_.dyW, lane); };
+  // the pointwise operands of one row of the first substep, and the accumulators of that row (accrow: a row this segment stores)
+  auto load_pt = [&](int row, PRow &pr, SPt &q, EAcc &a, bool live, bool accrow) {
+    const unsigned ro = RO(clampr(row));
+    pr.el = XLD(X2_el, vo, ro); pr.elb = XLD(X2_elb, vo, ro);
+    q.art = FLD(art, o_area, ro); q.vfl = FLD(vfluxf, vo, ro);
+    q.mk = P.m8[(size_t)WAVE_UNIFORM(clampr(row) - 1) * (size_t)P.iml + (size_t)(i - 1)];
+    q.ea = FLD(e_atmos, vo, ro); q.h = FLD(h, vo, ro); q.cor = FLD(cor, vo, ro);
+    const unsigned vl = live ? vo : BOFF_NONE, vla = live ? o_area : BOFF_NONE;   // (wave-uniform) the warm-up row needs no momentum operands
+    q.adx2d = FLD(adx2d, vl, ro); q.aru = FLD(aru, vla, ro); q.drx2d = FLD(drx2d, vl, ro);
+    q.wusurf = FLD(wusurf, vl, ro); q.wubot = FLD(wubot, vl, ro);
+    q.ady2d = FLD(ady2d, vl, ro); q.arv = FLD(arv, vla, ro); q.dry2d = FLD(dry2d, vl, ro);
+    q.wvsurf = FLD(wvsurf, vl, ro); q.wvbot = FLD(wvbot, vl, ro);
+    const unsigned va = accrow ? vo : BOFF_NONE;              // (wave-uniform)
+    a.egf = FLD(egf, va, ro); a.utf = FLD(utf, va, ro); a.vtf = FLD(vtf, va, ro);
+    a.etf = FLD(etf, (accrow && etf_ld) ? vo : BOFF_NONE, ro);
+  };
+  // generation Y of row `row` from the first substep's results; the lines next to the ring also go to T
+  auto make_y = [&](int row, const EOut &o, YRow &y) {
+    y.x.d = o.dn; y.x.ua = o.u; y.x.va = o.v; y.x.uab = o.uab_n; y.x.vab = o.vab_n;
+    y.p.el = o.ec; y.p.elb = o.elb_n;
+    y.x.dW = wave_up1(y.x.d);
+    const bool bandrow = (row > RING_LO && row <= RING_LO + 2) || (row >= P.jm - RING_HI - 1 && row <= P.jm - RING_HI);   // wave-uniform
+    const bool st = own && i0 > RING_LO && i0 <= P.im - RING_HI && row > RING_LO && row <= P.jm - RING_HI && (bandrow || bandcol);
+    const unsigned vs = st ? vo : BOFF_NONE;
+    const unsigned ro = RO(clampr(row));
+    TST(X2_d, vs, ro, y.x.d); TST(X2_ua, vs, ro, y.x.ua); TST(X2_va, vs, ro, y.x.va);
+    TST(X2_uab, vs, ro, y.x.uab); TST(X2_vab, vs, ro, y.x.vab);
+    TST(X2_el, vs, ro, y.p.el); TST(X2_elb, vs, ro, y.p.elb);
+  };
+  // ---- first substep: rows tw-1, tw, tw+1 of X and the warm-up row tw = j0-3 (>= 2)
+  const int tw = j0 - 3;
+  XRow xm, xc, xp, xn;
+  SRow sq, sm, sc, sp, sn;                                   // sq: the static row above the first substep's three (the second one's j-1)
+  load_x(tw - 1, xm, sm); load_x(tw, xc, sc); load_x(tw + 1, xp, sp);
+  fix_w(xm, sm); fix_w(xc, sc); fix_w(xp, sp);
+  sq = sm;
+  ECarry c1, c2;
+  c1.fva_0 = .25 * (xc.d + xm.d) * (sc.dx + sm.dx) * xc.va;
+  c1.es = c1.tps0 = c1.fv0 = c1.gvM = c1.el_m1 = c1.elb_m1 = 0.;
+  c2 = c1;
+  SPt q1, q1n, q1m;                                          // statics of the first substep's row, of the next one (in flight), of the row above (= the second substep's row)
+  SPm qmm, qm2;                                              // e_atmos, h, cor of the row above the first substep's / above the second substep's
+  PRow p1, p1n;
+  EAcc a1, a1n, b1;                                          // accumulators of the first substep's row as loaded / of the next row (in flight); b1: of the second substep's row after the first substep
+  EOut o1, o2;
+  YRow ym, yc, yp;
+  ym = YRow(); yc = YRow(); yp = YRow();
+  b1.egf = b1.utf = b1.vtf = b1.etf = 0.;
+  {
+    load_pt(tw, p1, q1, a1, false, false);
+    load_x(tw + 2, xn, sn);
+    load_pt(tw + 1, p1n, q1n, a1n, true, false);              // the first live row's operands: one row ahead from here on
+    qmm.ea = qmm.h = qmm.cor = 0.;
+    ext_row_math<false>(P, canon, fu_on, w_on, xm, xc, xp, sm, sc, sp, p1, q1, qmm, c1, o1);
+    q1m = q1;
+    qmm.ea = q1.ea; qmm.h = q1.h; qmm.cor = q1.cor;
+    qm2 = qmm;
+    sq = sm; xm = xc; xc = xp; sm = sc; sc = sp; fix_w(xn, sn); xp = xn; sp = sn;
+    p1 = p1n; q1 = q1n; a1 = a1n;
+  }
+  // One live row of the first substep (row t).  Before: xm/xc/xp = X rows t-1, t, t+1; sq/sm/sc/sp = static rows t-2 .. t+1; p1, q1, a1 =
+  // the pointwise operands and accumulators of row t (requested one iteration ago); q1m = statics of row t-1, qmm = e_atmos, h, cor of row t-1.
+  // After rotate(): everything one row further down; q1m = statics of row t, qm2 = e_atmos, h, cor of row t-1, b1 = row t's accumulators.
+  EAcc an;
+  auto first = [&](const int t, const bool next_accrow) {
+    load_pt(t + 1, p1n, q1n, a1n, true, next_accrow);         // in flight during this iteration
+    load_x(t + 2, xn, sn);
+    ext_row_math<true>(P, canon, fu_on, w_on, xm, xc, xp, sm, sc, sp, p1, q1, qmm, c1, o1);
+    an.egf = a1.egf + o1.ec * P.ispi;
+    an.utf = a1.utf + o1.u * (o1.dn + (o1.hW + o1.ew)) * P.isp2i;
+    an.vtf = a1.vtf + o1.v * (o1.dn + (qmm.h + o1.esm)) * P.isp2i;
+    an.etf = etf_rule(P, n1, a1.etf, o1.ec, (double)(q1.mk & 1u));
+    make_y(t, o1, yp);
+  };
+  auto rotate = [&]() {
+    sq = sm; sm = sc; sc = sp; xm = xc; xc = xp;
+    fix_w(xn, sn); xp = xn; sp = sn;
+    qm2 = qmm;
+    qmm.ea = q1.ea; qmm.h = q1.h; qmm.cor = q1.cor;
+    q1m = q1;
+    p1 = p1n; q1 = q1n; a1 = a1n;
+    ym = yc; yc = yp;
+    b1 = an;
+  };
+  // ---- Y rows j0-2, j0-1: two live rows of the first substep
+  first(j0 - 2, false); rotate();
+  first(j0 - 1, true); rotate();
+  // ---- row j0 of the first substep, then the warm-up row j0-1 of the second: Y rows j0-2, j0-1, j0; statics sq, sm, sc = rows j0-2 .. j0
+  {
+    first(j0, j0 + 1 <= j1);
+    c2.fva_0 = .25 * (yc.x.d + ym.x.d) * (sm.dx + sq.dx) * yc.x.va;
+    SPm z3; z3.ea = z3.h = z3.cor = 0.;
+    ext_row_math<false>(P, canon, fu_on, w_on, ym.x, yc.x, yp.x, sq, sm, sc, yc.p, q1m, z3, c2, o2);
+    rotate();
+  }
+  // ---- the rows: first substep at t, second at t-1
+  for (int t = j0 + 1; t <= j1 + 1; t++) {
+    first(t, t + 1 <= j1);
+    // second substep, row q = t-1: Y rows t-2, t-1, t; static rows sq, sm, sc; statics q1m (row q), qm2 (row q-1)
+    ext_row_math<true>(P, canon, fu_on, w_on, ym.x, yc.x, yp.x, sq, sm, sc, yc.p, q1m, qm2, c2, o2);
+    {
+      const unsigned ro = RO(t - 1);
+      const unsigned o_f = store_f2 ? o_st : BOFF_NONE;
+      FST(elf, o_f, ro, o2.ec); FST(uaf, o_f, ro, o2.u); FST(vaf, o_f, ro, o2.v);
+      FST(advua, o_f, ro, o2.advua); FST(advva, o_f, ro, o2.advva);
+      FST(etf, etf_st ? o_st : BOFF_NONE, ro, etf_rule(P, n2, b1.etf, o2.ec, (double)(q1m.mk & 1u)));
+      ZST(X2_uab, o_st, ro, o2.uab_n);
+      ZST(X2_vab, o_st, ro, o2.vab_n);
+      ZST(X2_elb, o_st, ro, o2.elb_n);
+      ZST(X2_el, o_st, ro, o2.ec);
+      ZST(X2_d, o_st, ro, o2.dn);
+      ZST(X2_ua, o_st, ro, o2.u);
+      ZST(X2_va, o_st, ro, o2.v);
+      FST(egf, o_st, ro, acc2 ? b1.egf + o2.ec * P.ispi : b1.egf);
+      FST(utf, o_st, ro, acc2 ? b1.utf + o2.u * (o2.dn + (o2.hW + o2.ew)) * P.isp2i : b1.utf);
+      FST(vtf, o_st, ro, acc2 ? b1.vtf + o2.v * (o2.dn + (qm2.h + o2.esm)) * P.isp2i : b1.vtf);
+    }
+    rotate();
+  }
+#undef RO
+#undef XLD
+#undef ZST
+#undef TST
+#undef FLD
+#undef FST
+}
+#endif
+// the ring of one substep (the cells k_ext_march2 leaves out), advave formed in place: P.x2 = the generation read, P.y2 = the generation written
+__global__ void __launch_bounds__(64) k_ext_ring(KP P, int store_f, int nlo, int nhi) {
+  ext_ring_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f, nlo, nhi);
+}
+
 // ---- all the external substeps of an internal step in ONE launch (small tiles) ------------------------------------------
 // On a small tile a substep's kernel is a few wavefronts per CU on a chain of dependent loads: ~20 us each, 30 of them per
 // internal step, whatever the grid size (256x256x30: 0.68 of 1.34 ms per step) -- a launch boundary costs more than the
@@ -1136,6 +1485,70 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
   if (fuse_adv) LAUNCHN(c, "k_ext_step_adv", k_ext_step<1>, g, blk2(), Q, store_f, rim_rows);
   else LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, rim_rows);
 }
+// Two substeps (Q.iext, Q.iext + 1) in one pass over memory (k_ext_march2, the ring's first substep beside it) + the ring's second substep (k_ext_ring).  Q: c->P with x2 = the
+// generation read, y2 = the generation written (the other buffer set); T: a third set for the rim's / the band's intermediate
+// generation.  Returns 1 when launched, 0 when the tile is not one for this path (the caller takes the substeps one by one).
+int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) {
+#ifdef POMGPU_EMU
+  (void)c; (void)Q; (void)T; (void)store_f2;
+  return 0;                                                   // neighbour lanes are not emulated (tests/emu): the GPU tests cover this path
+#else
+  if (getenv("POMGPU_EXT_NOPAIR")) return 0;
+  const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);         // blk2d through one 32-bit buffer descriptor
+  if (!fits || Q.im < 16 || Q.jm < 16) return 0;
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t pr;
+    ncu = (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  // rows per segment: a workgroup (four segments, one wave per SIMD) fills a CU; the pass costs about
+  // ceil(workgroups / CUs) x (rows + 4.5) row evaluations -- the shortest such product
+  const int nbx = (Q.im - RING_HI - 2) / 60 + 1, nrow = Q.jm - RING_HI - RING_LO;
+  int rows = 0;
+  double best = 1e30;
+  const int ncg = (nbx + 3) / 4;
+  for (int r = 6; r <= 96; r++) {
+    const int nseg = (nrow + r - 1) / r;
+    const long nwg = (long)ncg * nseg;
+    const double cost = (double)((nwg + ncu - 1) / ncu) * (r + 4.5);
+    if (cost < best) { best = cost; rows = r; }
+  }
+  if (getenv("POMGPU_EXT_ROWS2")) rows = atoi(getenv("POMGPU_EXT_ROWS2"));
+  if (rows < 2) return 0;
+  // small tiles keep the one-substep kernels unless asked (tests): below ~two workgroups per CU the marching kernels lose to
+  // the one-row kernel (profiles/round2_ext_march.txt)
+  const long wave_rows = (long)grid2_halo(Q).x * (Q.jmm1 - 2);
+  if (wave_rows < 16500 && !getenv("POMGPU_EXT_PAIR")) return 0;
+  const int nseg = (nrow + rows - 1) / rows;
+  const int nl = RING_LO + RING_HI, n = nl * Q.im + nl * (Q.jm - nl);          // cells of the ring
+  const int ring_wgs = ((n + 255) / 256 + 7) / 8 * 8;
+  Gen7 Tg;
+  for (int g = 0; g < POMGPU_NGEN; g++) Tg.p[g] = T[g];
+  // each generation behind one descriptor: the blk2d block (arrays at their slots) or a buffer set of its own (one allocation)
+  auto gen_of = [&](double *const *a, GenD &G) {
+    const bool in_b2 = a[0] >= Q.b2 && a[0] < Q.b2 + (size_t)POM_NBLK2D * Q.n2;
+    G.base = in_b2 ? Q.b2 : a[0];
+    G.bytes = (unsigned)((in_b2 ? (size_t)POM_NBLK2D : (size_t)POMGPU_NGEN) * Q.n2 * 8);
+    for (int g = 0; g < POMGPU_NGEN; g++) {
+      const ptrdiff_t d = a[g] - G.base;
+      if (d < 0 || (size_t)d * 8 + Q.n2 * 8 > (size_t)G.bytes) return false;            // not one block: not this path
+      G.off[g] = (unsigned)((size_t)d * 8);
+    }
+    return true;
+  };
+  GenD GX, GZ, GT;
+  if (!gen_of(Q.x2, GX) || !gen_of(Q.y2, GZ) || !gen_of(T, GT)) return 0;
+  // launch 1: the ring's first substep (X -> T) as the first workgroups, the marching workgroups beside them (X -> Z, band of Y -> T)
+  LAUNCHN(c, "k_ext_pair", k_ext_march2, dim3((unsigned)(ring_wgs + nseg * ncg), 1, 1), blk2(), Q, Tg, GX, GZ, GT, store_f2, ring_wgs, rows, (const int *)c->d_areas,
+          getenv("POMGPU_EXT_AREAS_LOAD") ? 0 : 1);
+  // launch 2: the ring's second substep (T -> Z)
+  KP R2 = Q;
+  for (int g = 0; g < POMGPU_NGEN; g++) R2.x2[g] = T[g];
+  R2.iext = Q.iext + 1;
+  LAUNCHN(c, "k_ext_ring", k_ext_ring, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), R2, store_f2, RING_LO, RING_HI);
+  return 1;
+#endif
+}
 // every substep first..last in one launch, or 0 when the tile is too large for all its workgroups to be resident (the
 // caller then launches the substeps one by one).  Q: as for launch_ext_step (y2 = the other buffer set).
 int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last) {
@@ -1148,7 +1561,7 @@ int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last) {
   // lines for the L2 write-back of the release and 325 lanes poll one counter; 65x49 (28 workgroups): 0.35 against 0.39 ms,
   // nothing on the step.  A launch boundary on this chip (~1.5-2 us + the ~20 us the substep's dependent loads take anyway)
   // is cheaper than this barrier; an XCD-hierarchical one (MI355X_MICROARCH.md: ~6 us + the publish) would be the next try.
-  if (!getenv("POMGPU_EXT_LOOP") || last <= first) return 0;
+  if (!getenv("POMGPU_EXT_LOOP") || last <= first || c->ext_loop_off) return 0;
   static int occ = -1, ncu = 0;
   if (occ < 0) {
     hipDeviceProp_t pr;
@@ -1168,7 +1581,8 @@ int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last) {
     (void)hipMemsetAsync(c->ext_bar, 0, 2 * sizeof(unsigned), c->cur);
     c->ext_bar_base = 0;
   }
-  LAUNCHN(c, "k_ext_loop", k_ext_loop<1>, g, blk2(), Q, rim_rows, first, last, c->ext_bar, c->ext_bar_base, c->d_err);
+  // the error flag is the TILE's (the extended tile of the wide-halo mode reports through its parent: nobody pulls its own)
+  LAUNCHN(c, "k_ext_loop", k_ext_loop<1>, g, blk2(), Q, rim_rows, first, last, c->ext_bar, c->ext_bar_base, (c->parent ? c->parent : c)->d_err);
   c->ext_bar_base += (unsigned)(blocks * (last - first));
   return 1;
 #endif

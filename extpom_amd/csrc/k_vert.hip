@@ -3,6 +3,7 @@
 // segment, so the k-loops stream whole planes coalesced.  The Thomas recurrences (profq, proft,
 // profu, profv) keep their ee/gg work vectors in per-thread private arrays instead of the five to
 // eleven full 3-D temporaries the reference streams through memory (solver.f:1224-1230,1552-1554).
+#include <type_traits>
 #include "pomgpu_internal.hpp"
 
 #define dt_(i, j) F2(dt, i, j)
@@ -437,6 +438,7 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
   double ccm = 0., rhom = 0.;                   // sound speed and density of level k-1
   double kqm = 0., kqc = F3(kq, i, j, 1);       // OLD kq at k-1, k (k+1 arrives with the level: kq1)
   double ucm = 0., uem = 0., vcm = 0., vnm = 0.;   // u(i), u(i+1), v(j), v(j+1) of level k-1
+#ifdef PROFQ_OLDWALK
   auto lev = [&](LevQ &L, int k) {              // k = 1..kb; every operand, every lane
     const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
     L.t = bld(bt, oc, lv); L.s = bld(bs_, oc, lv); L.rho = bld(brho, oc, lv); L.rm = bld(BUF3(A3(rmean)), o_rm, lv);
@@ -561,6 +563,168 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
       if (k + 1 <= kb) step(k + 1, rb, ra);
     }
   }
+#else
+  // The walk down, PEELED BY PHASE.  The level loop above (kept under PROFQ_OLDWALK for A/B runs) asked "which level is this?" a
+  // dozen times per level -- k == 1, k == 2, 2 <= k <= kbm1, k == kbm1, k <= KL, z(k) > -0.5 ... -- all wave-uniform, i.e. a
+  // dozen scalar branches that cut every level into small basic blocks.  This kernel is bound by the latency of its dependent
+  // fp64 chains (13 divisions and 3 square roots per level at two waves per SIMD: a wave issues an instruction every ~17
+  // cycles, profiles/round3_profq_phases.txt), and the scheduler can only overlap chains that sit in ONE block.  Here the
+  // phase is a compile-time tag: level 1, level 2, the levels whose elimination vectors go to LDS (3..KL), those that go to
+  // memory (KL+1..kbm2), level kbm1, level kb -- inside a phase no question about the level is left, per-lane conditions are
+  // selects, and the two loops' bodies are two levels in one block each.  Same operations on the same operands in the same order.
+  enum { PH_1, PH_2, PH_LDS, PH_MEM, PH_KBM1, PH_KB };
+  auto lev = [&](LevQ &L, int k) {              // k = 1..kb; every operand, every lane
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    L.t = bld(bt, oc, lv); L.s = bld(bs_, oc, lv); L.rho = bld(brho, oc, lv); L.rm = bld(BUF3(A3(rmean)), o_rm, lv);
+    L.q2b = bld(bq2b, oc, lv); L.q2lb = bld(bq2lb, oc, lv); L.q2 = bld(bq2, oc, lv);
+    L.km = bld(bkm, oc, lv); L.kh = bld(bkh, oc, lv);
+    L.uf = bld(buf, oc, lv); L.vf = bld(bvf, oc, lv);
+    if (FP) { L.uc = bld(bu, oc, lv); L.ue = bld(bu, oe, lv); L.vc = bld(bv, oc, lv); L.vn = bld(bv, on, lv); }
+    else L.uc = L.ue = L.vc = L.vn = 0.;
+    L.kq1 = bld(bkq, oc, (unsigned)WAVE_UNIFORM(k < kb ? k : kb - 1) * lvb);     // OLD kq of level k+1 (overwritten two iterations from now)
+    L.prod = (FP != 1) ? bld(bpr, o_pr, lv) : 0.;
+  };
+  auto step = [&](auto ph, const int k, const LevQ &cur, LevQ &nxt) {
+    constexpr int PH = decltype(ph)::value;
+    constexpr bool mid = (PH != PH_1 && PH != PH_KB);       // 2 <= k <= kbm1
+    if (PH != PH_KB) lev(nxt, k + 1);                       // in flight during this iteration
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    const double kqp = cur.kq1;
+    // ---- level-local quantities
+    double cck = 0., rhok = 0.;
+    if (PH != PH_KB) { cck = profq_cc_v(P, cur.t, cur.s, hij, k); rhok = rho_rt ? (cur.rho - cur.rm) + cur.rm : cur.rho; }
+    double q2b = cur.q2b;
+    double l, gh = 0.;
+    double uck = 0., uek = 0., vck = 0., vnk = 0., bg = 0.;
+    if (PH != PH_KB) { uck = pin ? cur.uc : 0.; uek = pin ? cur.ue : 0.; vck = pin ? cur.vc : 0.; vnk = pin ? cur.vn : 0.; }
+    double q2lb = 0.;
+    if (mid) {
+      q2b = fabs(q2b);                                                                      // :1325-1326
+      q2lb = fabs(cur.q2lb);
+      bg = P.grav * (rhom - rhok) / (F1(dzz, k - 1) * hij) + sq(P.grav) * 2. / (sq(ccm) + sq(cck));   // :1327-1330
+      l = fabs(q2lb / q2b);                                                                 // :1338-1344
+      const double lmx = fmax(l, P.kappa * l0);
+      l = (F1(z, k) > -0.5) ? lmx : l;
+      gh = fmin(sq(l) * bg / q2b, .028);
+      bst(bq2b, o_abs, lv, q2b);
+      bst(bq2lb, o_abs, lv, q2lb);
+    } else {
+      l = (PH == PH_1) ? P.kappa * l0 : 0.;                                                 // :1351-1354
+    }
+    bst(bl, oc, lv, l);
+    const double dtef1 = sqrt(fabs(q2b)) * 1. / (b1 * l + P.small_);                        // :1388-1389
+    double dtef2 = dtef1;
+    if (mid) dtef2 = dtef1 * (1. + e2 * sq(divi((1. / fabs(F1(z, k) - z1) + 1. / fabs(F1(z, k) - zkb)) * l, dhk)));   // :1429-1432
+    bst(bdt, oc, lv, dtef2);
+    // ---- both forward eliminations -- :1394-1404, :1436-1446
+    if (mid) {
+      const double a = -P.dti2 * (kqp + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k) * dh * dh);      // :1261-1264
+      const double c = -P.dti2 * (kqm + kqc + umol2) * .5 / (F1(dzz, k - 1) * F1(dz, k - 1) * dh * dh);
+      double pr;
+      if (FP == 0) {
+        pr = cur.prod;
+      } else {                                                                              // :1359-1373, as k_profq_prod; every lane
+        const double sef = 1., shiw = 0.;                                                   // evaluates it, the lanes off the interior
+        const double km = cur.km;                                                           // select their own value afterwards
+        pr = km * .25 * sef * (sq(uck - ucm + uek - uem) + sq(vck - vcm + vnk - vnm)) / sq(F1(dzz, k - 1) * dh) - shiw * km * bg;
+        pr = pr + cur.kh * bg;
+        pr = pin ? pr : (FP == 2 ? cur.prod : 0.);
+      }
+      const double g = 1. / (a + c * (1. - e1p) - (2. * P.dti2 * dtef1 + 1.));
+      e1p = a * g;
+      g1p = (-2. * P.dti2 * pr + c * g1p - cur.uf) * g;
+      if (PH == PH_2) {
+        e2p = 0.;
+        g2p = -P.kappa * F1(z, 2) * dh * cur.q2;
+      } else {
+        const double rhs = (PH == PH_KBM1) ? vbot : cur.vf;
+        const double g2 = 1. / (a + c * (1. - e2p) - (P.dti2 * dtef2 + 1.));
+        e2p = a * g2;
+        g2p = (P.dti2 * (-pr * l * e1) + c * g2p - rhs) * g2;
+      }
+    }
+    // the vectors' level k (level 1: the boundary values; level kb has none -- and uf, vf of level kb stay what they are)
+    if (PH != PH_KB) {
+#ifndef POMGPU_EMU
+      if (PH == PH_1 || PH == PH_2 || PH == PH_LDS) {       // k <= KL (KL >= 9)
+        evec[k - 1][ty][tx] = e1p; evec[KL + k - 1][ty][tx] = e2p;
+      } else if (PH == PH_MEM) {
+        bst(be1, oc, lv, e1p); bst(be2, oc, lv, e2p);
+      } else {                                              // level kbm1: either side of KL
+        const bool inl = k <= KL;                           // wave-uniform
+        if (inl) { evec[k - 1][ty][tx] = e1p; evec[KL + k - 1][ty][tx] = e2p; }
+        const unsigned oe_ = inl ? BOFF_NONE : oc;
+        bst(be1, oe_, lv, e1p); bst(be2, oe_, lv, e2p);
+      }
+#else
+      bst(be1, oc, lv, e1p); bst(be2, oc, lv, e2p);
+#endif
+      bst(buf, oc, lv, g1p); bst(bvf, oc, lv, g2p);
+    }
+    // ---- new mixing coefficients -- :1484-1503, cosmetics + mask :1510-1535
+    double kq_n = 0., km_n = 0., kh_n = 0.;
+    {
+      const double sh = coef1 / (1. - coef2 * gh);
+      double sm = coef3 + sh * coef4 * gh;
+      sm = sm / (1. - coef5 * gh);
+      const double pl = l * sqrt(fabs(cur.q2));
+      kq_n = (pl * .41 * sh + kqc) * .5;
+      km_n = (pl * sm + cur.km) * .5;
+      kh_n = (pl * sh + cur.kh) * .5;
+      // own cell: in place (old kq lives on in kqm / kqc / kq1)
+      bst(bkq, o_k, lv, kq_n * fsm_c);
+      bst(bkm, o_k, lv, km_n * fsm_c);
+      bst(bkh, o_k, lv, kh_n * fsm_c);
+    }
+    // Physical-edge cells that copy this column are written to the staging arrays s3[1..3] (their own threads still
+    // read the old kq) and moved by k_profq_rim.  Stores only, in the few columns next to such an edge.
+    if ((ti | tj) && !repl) {
+#define PUT(ii, jj, m)                               \
+  {                                                  \
+    G3(P.s3[1], ii, jj, k) = km_n * m;               \
+    G3(P.s3[2], ii, jj, k) = kh_n * m;               \
+    G3(P.s3[3], ii, jj, k) = kq_n * m;               \
+  }
+      if (ti) PUT(ti, j, m_ti)
+      if (tj) PUT(i, tj, m_tj)
+      if (ti && tj) PUT(ti, tj, m_tij)
+#undef PUT
+    }
+    ccm = cck; rhom = rhok;
+    ucm = uck; uem = uek; vcm = vck; vnm = vnk;
+    kqm = kqc; kqc = kqp;
+  };
+  {
+    using std::integral_constant;
+    LevQ ra, rb;
+    lev(ra, 1);
+    if (pace) PACE_BARRIER();
+    step(integral_constant<int, PH_1>(), 1, ra, rb);
+    step(integral_constant<int, PH_2>(), 2, rb, ra);          // kb >= 4 (pomgpu_create): level 2 is never level kbm1
+    int k = 3;
+    const int kbm2 = kb - 2;
+#ifndef POMGPU_EMU
+    const int kA = KL < kbm2 ? KL : kbm2;                   // the levels whose ee1, ee2 wait in LDS
+#else
+    const int kA = 2;
+#endif
+    for (; k + 1 <= kA; k += 2) {
+      if (pace) PACE_BARRIER();
+      step(integral_constant<int, PH_LDS>(), k, ra, rb);
+      step(integral_constant<int, PH_LDS>(), k + 1, rb, ra);
+    }
+    if (k <= kA) { step(integral_constant<int, PH_LDS>(), k, ra, rb); ra = rb; k++; }         // an odd level: back to the first register set
+    for (; k + 1 <= kbm2; k += 2) {
+      if (pace) PACE_BARRIER();
+      step(integral_constant<int, PH_MEM>(), k, ra, rb);
+      step(integral_constant<int, PH_MEM>(), k + 1, rb, ra);
+    }
+    if (k <= kbm2) { step(integral_constant<int, PH_MEM>(), k, ra, rb); ra = rb; k++; }
+    if (pace) PACE_BARRIER();
+    step(integral_constant<int, PH_KBM1>(), kbm1, ra, rb);
+    step(integral_constant<int, PH_KB>(), kb, rb, ra);
+  }
+#endif
   // ---- back substitution -- :1406-1413, :1448-1455, abs :1467-1468; with the fused filter one level of k_q_filter rides
   // on every level: bcond(6)'s mask, Asselin filter, rotation; q2b, q2lb as the walk down leaves them (|.| at 2..kbm1)
   const double hs = .5 * P.smoth;

@@ -79,6 +79,25 @@ void pomgpu_prof_post(pomgpu_ctx *c, int slot) {
   p.slot = slot;
   (void)hipEventRecord(p.b, st);
 }
+// Phases: brackets that contain other brackets (a whole step, its external substeps).  Not subject to the kernel filter, so
+// that a timed region which brackets one kernel only still yields K-step means of the step and of its external mode.
+static int prof_phase_open(pomgpu_ctx *c) {
+  if (!c->prof_on) return -1;
+  pomgpu_prof_pre(c);
+  return (int)PS(c)->pending.size() - 1;
+}
+static void prof_phase_close(pomgpu_ctx *c, int idx, const char *name) {
+  if (idx < 0 || !c->prof_on) return;
+  ProfState *ps = PS(c);
+  int slot = -1;
+  for (int k = 0; k < c->nprof; k++) if (strcmp(c->prof[k].name, name) == 0) slot = k;
+  if (slot < 0 && c->nprof < (int)(sizeof c->prof / sizeof c->prof[0])) {
+    slot = c->nprof++;
+    c->prof[slot].name = name; c->prof[slot].launches = 0; c->prof[slot].ms = 0.;
+  }
+  ps->pending[idx].slot = slot;
+  (void)hipEventRecord(ps->pending[idx].b, c->stream);
+}
 static void prof_drain(pomgpu_ctx *c) {
   ProfState *ps = PS(c);
   (void)hipStreamSynchronize(c->stream);
@@ -142,6 +161,12 @@ static void sync_scalars(pomgpu_ctx *c) {
 }
 
 // ---- life cycle -------------------------------------------------------------------------------
+// a digest of the library's sources, put in by the build (__graft_entry__.build_hip): measurements kept in profiles/ carry it, and
+// bench.py only quotes a stored counter value (roofline.traffic) for the build it was taken from
+#ifndef POMGPU_BUILD_ID
+#define POMGPU_BUILD_ID "unknown"
+#endif
+extern "C" const char *pomgpu_build_id(void) { return POMGPU_BUILD_ID; }
 #ifdef POMGPU_STORE_F32
 extern "C" const char *pomgpu_version(void) { return "extpom_amd pomgpu 0.2 (gfx950) fp32-storage variant"; }
 #define F32_REFUSE(c, what) return fail(c, POMGPU_EINVAL, what ": not in the fp32-storage variant (3-D arrays are not doubles there)")
@@ -294,7 +319,8 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   for (int n = 0; n < POMGPU_NSCR3 && !only2d; n++) alloc(&P.s3[n], P.n3);
   for (int n = 0; n < POMGPU_NSCR2; n++) alloc(&P.s2[n], P.n2);
   for (int n = 0; n < POMGPU_NCOEF2; n++) alloc(&P.c2[n], P.n2);
-  for (int n = 0; n < POMGPU_NGEN; n++) alloc(&c->alt2[n], P.n2);
+  alloc(&c->alt2[0], (size_t)POMGPU_NGEN * P.n2);              // ONE block: a kernel reaches the whole set through one buffer descriptor (k_ext_march2)
+  for (int n = 1; n < POMGPU_NGEN && ok; n++) c->alt2[n] = c->alt2[0] + (size_t)n * P.n2;
   { double *m = NULL; alloc(&m, (P.n2 + 7) / 8 + 1); P.m8 = (unsigned char *)m; }
   for (int n = 0; n < 2; n++) {
     const size_t len = (size_t)(P.kb + 1) * (n == 0 ? P.jml : P.iml);
@@ -330,7 +356,9 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);
-  (void)pomgpu_io_wait(c);
+  if (pomgpu_io_wait(c) != POMGPU_OK)                          // nobody is left to hand the status to: say it (error_status dies with the context)
+    fprintf(stderr, "pomgpu_destroy: the output / restart file still being written could not be completed -- call pomgpu_io_wait (or pomgpu_sync) "
+                    "before pomgpu_destroy to get its status\n");
   wide_free(c);
   pomgpu_tp_free(c);
   KP &P = c->P;
@@ -339,7 +367,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
   for (int n = 0; n < POMGPU_NCOEF2; n++) (void)hipFree(P.c2[n]);
-  for (int n = 0; n < POMGPU_NGEN; n++) (void)hipFree(c->alt2[n]);
+  (void)hipFree(c->alt2[0]); (void)hipFree(c->alt3[0]);         // one block each
   (void)hipFree(P.m8);
   for (int n = 0; n < 2; n++) { (void)hipFree(c->ord_send[n]); (void)hipFree(c->ord_recv[n]); }
   for (int n = 0; n <= POMGPU_MAXREC; n++) { (void)hipFree(c->rec_t[n]); (void)hipFree(c->rec_s[n]); }
@@ -368,7 +396,19 @@ static int pull_err(pomgpu_ctx *c) {
   int e = 0;
   HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (e) c->con.error_status = 1;
+  if (e) {
+    c->con.error_status = 1;
+    // k_ext_loop (opt-in) raises the same flag when a spin at its grid barrier times out.  Its abort word is sticky and its
+    // arrival counter is out of step then: clear both and keep this context off that path (a shared or oversubscribed GPU
+    // does not guarantee that all workgroups are resident, which the barrier needs)
+    pomgpu_ctx *two[2] = {c, c->wide.x};
+    for (pomgpu_ctx *t : two)
+      if (t && t->ext_bar) {
+        (void)hipMemsetAsync(t->ext_bar, 0, 2 * sizeof(unsigned), c->stream);
+        t->ext_bar_base = 0;
+        t->ext_loop_off = 1;
+      }
+  }
   return POMGPU_OK;
 }
 extern "C" int pomgpu_sync(pomgpu_ctx *c) {
@@ -784,6 +824,13 @@ static void wide_flush(pomgpu_ctx *c);
 #define NEED_HOT(c) NEED_RAW(c); ext_canonical(c); wide_flush(c)   /* the entry points pomgpu_advance strings together */
 #define NEED(c) NEED_HOT(c); side_join(c); restore_materialize(c)
 
+// every lazily kept array brought up to date in the COMMON-block mirrors (the second generation of the external mode's arrays,
+// the extended tile's 2-D state, work on the side stream, rho's deferred round trip, the restore fields): what anything that
+// reads the mirrors directly -- the file writers' snapshot -- must call first
+int pomgpu_materialize(pomgpu_ctx *c) {
+  NEED(c);
+  return POMGPU_OK;
+}
 extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
   NEED_HOT(c);
   pom_blkcon &k = c->con;
@@ -876,6 +923,33 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   launch_ext_update(c);                                       // :295-347
   if (P.iext != P.isplit) xch(c, 2, D2(c, utf), 1, D2(c, vtf), 1);   // :348-349
   return POMGPU_OK;
+}
+// Substeps iext and iext + 1 in one pass over memory (k_ext_march2, k_ext.hip): one tile -- or the extended tile of the wide-halo
+// mode -- large enough for the marching kernels, inside pomgpu_advance only (the public pomgpu_mode_external leaves elf, uaf, vaf
+// of EVERY substep in memory for its caller).  1 = both substeps done (c->con.iext = iext + 1), 0 = not applicable.
+static int ext_pair(pomgpu_ctx *c, int iext) {
+  pomgpu_ctx *t = c;
+  if (c->wide.on) { if (!c->wide.pending) return 0; t = c->wide.x; }
+  else if (c->exch) return 0;
+  const int isplit = c->con.isplit;
+  KP &P = t->P;
+  if (iext + 1 > isplit || getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE")) return 0;
+  if (!t->alt3[0]) {
+    if (hipMalloc((void **)&t->alt3[0], (size_t)POMGPU_NGEN * P.n2 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); t->alt3[0] = NULL; return 0; }
+    for (int n = 1; n < POMGPU_NGEN; n++) t->alt3[n] = t->alt3[0] + (size_t)n * P.n2;
+    (void)hipMemsetAsync(t->alt3[0], 0, (size_t)POMGPU_NGEN * P.n2 * sizeof(double), c->stream);
+  }
+  t->con.iext = iext; t->con.isplit = isplit;
+  P.iext = iext;
+  if (iext == 1 || !t->areas_checked) { launch_check_areas(t); t->areas_checked = 1; }
+  KP Q = P;
+  for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = t->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : t->alt2[n];
+  if (!launch_ext_pair(t, Q, t->alt3, iext + 1 == isplit)) return 0;
+  t->ext_parity ^= 1;                                         // two substeps, one change of buffer sets
+  ext_buffers(t);
+  c->con.iext = iext + 1; t->con.iext = iext + 1; P.iext = iext + 1; c->P.iext = iext + 1;
+  if (c->wide.on && iext + 1 == isplit) wide_flush(c);        // the tile's arrays, ghost cells included, are current again
+  return 1;
 }
 // every external substep of the step in one launch (k_ext_loop): one tile -- or the extended tile of the wide-halo mode --
 // whose workgroups are all resident at once; 0 = not applicable, the caller loops over mode_external
@@ -1514,20 +1588,25 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
   const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
   const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
+  const int ph_step = prof_phase_open(c);                     // "phase_step": this whole step on the kernels' stream
   if ((rc = wide_early_start(c))) return rc;                  // most of the wide exchange, beside lateral_viscosity
   // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)
   const pom_blkcon &k0 = c->con;
   const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !getenv("POMGPU_RHO_ROUNDTRIP");   // rho's readers before dens: k_profq, k_profq_prod(_lines)
   if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
+  const int ph_ext = prof_phase_open(c);                      // "phase_external": the isplit substeps of mode_external (advance.f:27-29)
   if (!ext_loop_all(c))
   for (int iext = 1; iext <= c->con.isplit; iext++) {
+    if (ext_pair(c, iext)) { iext++; continue; }              // two substeps per pass over memory (large tiles)
     c->con.iext = iext;
     if ((rc = mode_external(c, 0))) return rc;                // ... to the last substep
   }
+  prof_phase_close(c, ph_ext, "phase_external");
   c->con.iext = c->con.isplit + 1;
   if ((rc = pomgpu_mode_internal(c))) return rc;
   launch_check_velocity(c);   // result stays on the device; error flag is merged at the next get_con
+  prof_phase_close(c, ph_step, "phase_step");
   return POMGPU_OK;
 }
 extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19

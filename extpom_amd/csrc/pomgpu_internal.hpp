@@ -342,12 +342,18 @@ template <int NS> __device__ __forceinline__ const double *rowshare_pick(const d
 struct InvD { double b, y; };
 __device__ __forceinline__ InvD inv_of(double b) { InvD d; d.b = b; d.y = 1.0 / b; return d; }
 #ifndef POMGPU_EMU
+// A zero numerator keeps its sign: masked flux numerators such as -am * ... * msk are -0.0 on land, a/b is then -0.0 (b > 0),
+// but the corrections give (+0) + (-0) = +0 -- the product a*y has the quotient's sign, one select hands it through (array_equal
+// cannot see the sign of a zero, a digest of the bytes can).  Not covered: non-zero numerators below 2^-969 in magnitude,
+// whose residual a - b*q would be subnormal and no longer exact (the last bit may differ from a/b there) -- the numerators
+// here are products of metrics, depths and O(1e-12 ... 1e3) field differences, eight hundred binary orders of magnitude away.
 __device__ __forceinline__ double divi(double a, const InvD &d) {
-  double q = a * d.y;
-  double r = __builtin_fma(-d.b, q, a);
-  q = __builtin_fma(r, d.y, q);
+  const double q0 = a * d.y;
+  double r = __builtin_fma(-d.b, q0, a);
+  double q = __builtin_fma(r, d.y, q0);
   r = __builtin_fma(-d.b, q, a);
-  return __builtin_fma(r, d.y, q);
+  q = __builtin_fma(r, d.y, q);
+  return a == 0. ? q0 : q;
 }
 #else
 static inline double divi(double a, const InvD &d) { return a / d.b; }
@@ -472,6 +478,7 @@ struct pomgpu_ctx {
   void *order_user;
   double *ord_send[2], *ord_recv[2];   // [0] east/west: (kb+1) x jml, [1] north/south: (kb+1) x iml
   double *alt2[POMGPU_NGEN]; // second buffer set of ua, va, d, el, elb, uab, vab (fused external step)
+  double *alt3[POMGPU_NGEN]; // third set: the intermediate generation on the rim and next to it when two substeps share a pass (k_ext_march2); allocated on first use
   int ext_parity;            // 1 while the current generation of those five lives in alt2
   // taurstrb / taurstrf (index 0 / 1): known to hold one value everywhere restore_interior looks, because the library wrote
   // it itself ("taurstrf = 1./trst", bounds_forcing.f:1043,1065; the shift :1054-1056 hands f's value to b).  k_ts_update then
@@ -504,6 +511,7 @@ struct pomgpu_ctx {
   int flags;                 // POMGPU_CTX_2D: no 3-D arrays (the extended tile of the wide-halo external mode)
   unsigned *ext_bar;         // device: arrival counter + abort word of k_ext_loop's grid barrier (k_ext.hip)
   unsigned ext_bar_base;     // the counter's value when the next k_ext_loop starts (every workgroup arrives once per barrier)
+  int ext_loop_off;          // a k_ext_loop launch of this context gave up at its barrier: the substeps run as launches of their own from then on
   void *io_job;              // the output / restart file being written behind the model's back (cdf_out.hip), NULL = none
   int launch_err;            // first hipError_t a kernel launch returned (0 = none); reported by the next sync / get_con
   char err[512];
@@ -590,6 +598,7 @@ void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
 void launch_check_areas(pomgpu_ctx *c);
 int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last);   // 1 = launched (all substeps first..last), 0 = not applicable
+int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2);   // 1 = substeps Q.iext, Q.iext + 1 launched, 0 = not applicable
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate
 void launch_frc_load(pomgpu_ctx *c, const double *ra, const double *rb, double *xf, double *yf);
@@ -663,6 +672,7 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
 void pomgpu_tp_free(pomgpu_ctx *c);
 int pomgpu_tp_reserve(pomgpu_ctx *c, const size_t *need);                       // grow the staging buffers
 int pomgpu_tp_reserve2(pomgpu_ctx *c, const size_t *need);                      // ... those of the side stream
+int pomgpu_materialize(pomgpu_ctx *c);                                          // every lazily kept array up to date in the mirrors (pomgpu_api.hip)
 int pomgpu_side_stream(pomgpu_ctx *c);                                          // create the side stream and its events (pomgpu_api.hip); 1 = there
 int pomgpu_tp_side_ok(pomgpu_ctx *c);                                           // can rounds run on the side stream (second communicator / callback mover)?
 int pomgpu_tp_move_side(pomgpu_ctx *c, const size_t *scount, const size_t *rcount);   // send2 / recv2, on c->side

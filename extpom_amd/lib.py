@@ -100,6 +100,7 @@ _SIGS = {
     "pomgpu_prof_get": (_I, [_P, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_long),
                              ctypes.POINTER(ctypes.c_double)]),
     "pomgpu_version": (ctypes.c_char_p, []),
+    "pomgpu_build_id": (ctypes.c_char_p, []),
 }
 # argument-less hot-path entry points, same names as the reference subroutines
 NOARG = ["get_time", "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "advance", "advave",

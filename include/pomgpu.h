@@ -263,13 +263,18 @@ int pomgpu_restore_interior(pomgpu_ctx *ctx);    /* bounds_forcing.f:1023-1121 *
  * returns, for kernel number `k` (0 <= k < pomgpu_prof_count()), its name, launch count and
  * total milliseconds. */
 int pomgpu_prof_begin(pomgpu_ctx *ctx);
-/* restrict the bracketing to one kernel (its name, e.g. "k_profq"); NULL or "" = every kernel */
+/* Two phases are always bracketed as well, whatever the filter: "phase_step" (one pomgpu_advance, on the kernels' stream) and
+ * "phase_external" (its isplit mode_external substeps); internal mode = the difference.
+ * restrict the bracketing to one kernel (its name, e.g. "k_profq"); NULL or "" = every kernel */
 int pomgpu_prof_filter(pomgpu_ctx *ctx, const char *kernel_name);
 int pomgpu_prof_end(pomgpu_ctx *ctx);
 int pomgpu_prof_count(pomgpu_ctx *ctx);
 int pomgpu_prof_get(pomgpu_ctx *ctx, int k, const char **name, long *launches, double *total_ms);
 
 const char *pomgpu_version(void);
+/* a digest of the sources this library was built from (measurement bookkeeping: profiles/traffic.json names the build its
+ * counters were taken from) */
+const char *pomgpu_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -28,8 +28,13 @@ def _oracle():
     return OracleTile, oracle_finish_initial
 
 
+def same_bits(x, y):
+    """bit for bit: unlike array_equal this sees the sign of a zero (and takes equal NaN patterns for equal)"""
+    return x.shape == y.shape and np.array_equal(np.ascontiguousarray(x).view(np.uint64), np.ascontiguousarray(y).view(np.uint64))
+
+
 def diff(a, b):
-    return [n for n in BLK2D + BLK3D if n not in SCRATCH and not np.array_equal(a.field(n), b.field(n))]
+    return [n for n in BLK2D + BLK3D if n not in SCRATCH and not same_bits(a.field(n), b.field(n))]
 
 
 def reldiff(a, b, fields):
@@ -227,6 +232,54 @@ def test_output_and_restart_files_without_pnetcdf(tmp_path):
         assert f.variables["q2l"].long_name == b"q2 x l" and f.variables["advua"].long_name == b"sum of 2nd, 3rd and 4th terms in eq (18)"
         for n in RESTART_2D + RESTART_3D:
             assert np.array_equal(f.variables[n][:], a.field(n)), n
+
+
+def test_files_written_with_the_callers_statistics_see_the_current_state(tmp_path):
+    """as tests/test_kernels_emulated.py: the writer's snapshot after an odd number of fused external substeps, with the caller's
+    own statistics (no pomgpu_domain_stats call inside), through the asynchronous path"""
+    from scipy.io import netcdf_file
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=7)
+    oracle_finish_initial(a)
+    g = _gpu(a)
+    g.run(3)
+    g.write_file("output", tmp_path / "out.nc", title="t", time_start="s", stats=(1., 2., 3., 4., 5., 6., 7., 8.))
+    g.write_file("restart", tmp_path / "rst.nc", title="t", time_start="s", stats=(1., 2., 3., 4., 5., 6., 7., 8.))
+    g.io_wait()
+    g.download()
+    g.close()
+    with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
+        assert float(f.variables["vtot"][0]) == 1.0 and float(f.variables["ekin"][0]) == 8.0
+        for n in ("uab", "vab", "elb"):
+            assert np.array_equal(f.variables[n][0], a.field(n)), n
+    with netcdf_file(str(tmp_path / "rst.nc"), "r", mmap=False) as f:
+        for n in ("ua", "va", "el", "elb", "uab", "vab", "rho"):
+            assert np.array_equal(f.variables[n][:], a.field(n)), n
+
+
+def test_a_failed_file_write_surfaces_as_a_status():
+    """the writers return once the file is laid out; the arrays are written behind the model's back by a host thread.  An I/O
+    error there (here: /dev/full, every pwrite fails with ENOSPC) must not be lost: pomgpu_io_wait / pomgpu_sync / the next
+    write return it and error_status is 1, as after the reference's handle_error_pnetcdf (io_pnetcdf.F:43-54)"""
+    from extpom_amd.lib import PomGpuError
+    OracleTile, oracle_finish_initial = _oracle()
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    g = _gpu(a)
+    g.run(1)
+    g.write_file("restart", "/dev/full", title="t", time_start="s", create=False)     # laid out by "another rank": only the patch is written
+    with pytest.raises(PomGpuError):
+        g.io_wait()
+    g.get_con()
+    assert a.error_status == 1
+    a.error_status = 0
+    g.set_con(error_status=0)
+    g.write_file("output", "/dev/full", title="t", time_start="s", create=False)
+    with pytest.raises(PomGpuError):
+        g.sync()                                              # sync joins the writer too
+    with pytest.raises(PomGpuError):
+        g.write_file("output", "/dev/full", title="t", time_start="s", create=True)   # the header itself cannot be written: at once
+    g.close()
 
 
 def test_domain_stats_on_device():
@@ -507,10 +560,11 @@ def test_config4_2048x1536x50_full_size():
     assert a.iint == 2 and c.iint == 2               # the 3-D body ran on both sides (advance.f:362)
     del oc
     gc = _gpu(c)                                     # the oracle's state after two steps, uploaded
-    # 20 more steps: one context on the large-grid fast paths (the external substep marching down the rows, k_profq in 8 paced
-    # rows with its vectors in LDS, strip order), the other on the shapes small grids use -- the same bits
+    # 20 more steps: one context on the large-grid fast paths (two external substeps per pass marching down the rows, k_profq in 8
+    # paced rows with its vectors in LDS, strip order), the other on the shapes small grids use (one substep per launch, one row
+    # per wavefront ...) -- the same bits
     ga.run(20)
-    general = {"POMGPU_EXT_NOMARCH": "1", "POMGPU_PROFQ_ROWS2": "1", "POMGPU_PROFQ_NOPACE": "1", "POMGPU_COL_STRIP": "0"}
+    general = {"POMGPU_EXT_NOPAIR": "1", "POMGPU_EXT_NOMARCH": "1", "POMGPU_PROFQ_ROWS2": "1", "POMGPU_PROFQ_NOPACE": "1", "POMGPU_COL_STRIP": "0"}
     os.environ.update(general)
     try:
         gc.run(20)
@@ -611,4 +665,30 @@ def test_marching_external_substep_with_and_without_canonical_areas(monkeypatch,
     g.run(2)
     g.download()
     g.close()
+    assert not diff(a, b), diff(a, b)
+
+
+@pytest.mark.parametrize("case,im,jm,kb,isplit,rows2", [("seamount", 200, 93, 11, 10, "6"), ("island", 130, 97, 9, 7, "5"), ("seamount", 65, 49, 21, 30, None),
+                                                        ("basin", 257, 64, 6, 8, "30"), ("seamount", 121, 60, 8, 4, "2")])
+def test_two_external_substeps_per_pass(monkeypatch, case, im, jm, kb, isplit, rows2):
+    """k_ext_march2 (two substeps per pass over memory: the second generation marches one row behind the first, the rim's
+    intermediate generation through a third buffer set) forced onto small grids -- its default use is the full-size test:
+    ragged last segments and wavefronts, segments of 2 to 30 rows, an odd isplit (the last substep alone), the etf weights
+    of the last three substeps falling on either half of a pair, open (seamount), island and closed (basin) rims.  All fields
+    bit for bit equal to the oracle's."""
+    OracleTile, oracle_finish_initial = _oracle()
+    monkeypatch.setenv("POMGPU_EXT_PAIR", "1")
+    if rows2:
+        monkeypatch.setenv("POMGPU_EXT_ROWS2", rows2)
+    a = make_case(case, im, jm, kb, dte=6.0, isplit=isplit)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(3)
+    g = _gpu(b)
+    g.prof_begin()
+    g.run(3)
+    prof = g.prof_end()
+    g.download()
+    g.close()
+    assert prof.get("k_ext_pair", (0, 0))[0] == 3 * (isplit // 2), prof.keys()     # the path under test did run
     assert not diff(a, b), diff(a, b)

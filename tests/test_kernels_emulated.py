@@ -143,6 +143,27 @@ def test_output_and_restart_files_read_back(tmp_path):
             assert np.array_equal(f.variables[n][:], a.field(n)), n
 
 
+def test_files_written_with_the_callers_statistics_see_the_current_state(tmp_path):
+    """a caller that hands the writer its own (rank-reduced) statistics skips pomgpu_domain_stats -- and with it the side effect
+    of bringing lazily kept arrays up to date.  After an ODD number of fused external substeps the current generation of
+    ua, va, el, elb, uab, vab lives in the second buffer set: the file must hold it all the same (pomgpu_materialize)"""
+    from scipy.io import netcdf_file
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=7)
+    oracle_finish_initial(a)
+    g = PomGpu(a, libpath=EMU)
+    g.run(3)
+    g.write_file("output", tmp_path / "out.nc", title="t", time_start="s", stats=(1., 2., 3., 4., 5., 6., 7., 8.))
+    g.write_file("restart", tmp_path / "rst.nc", title="t", time_start="s", stats=(1., 2., 3., 4., 5., 6., 7., 8.))
+    g.download()
+    with netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False) as f:
+        assert float(f.variables["vtot"][0]) == 1.0 and float(f.variables["ekin"][0]) == 8.0
+        for n in ("uab", "vab", "elb"):
+            assert np.array_equal(f.variables[n][0], a.field(n)), n
+    with netcdf_file(str(tmp_path / "rst.nc"), "r", mmap=False) as f:
+        for n in ("ua", "va", "el", "elb", "uab", "vab", "rho"):
+            assert np.array_equal(f.variables[n][:], a.field(n)), n
+
+
 def test_ramped_forcing_steps():
     """lramp = .true.: ramp = time/period changes every step (advance.f:66-72)"""
     a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)

@@ -54,6 +54,7 @@ for r in range(rounds):
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         prof.pop("msg_round", None)
+        prof.pop("phase_step", None); prof.pop("phase_external", None)      # brackets around other brackets (pomgpu.h): not kernels
         ext = ("k_ext_", "k_advave_", "k_modeint_tail", "k_int_tail", "k_check_velocity", "k_check_areas", "k_copy2", "k_bcond1")
         acc.setdefault("internal", []).append(sum(v[1] for k, v in prof.items() if not k.startswith(ext)))
         acc.setdefault("external", []).append(sum(v[1] for k, v in prof.items() if k.startswith(ext)))

@@ -38,12 +38,13 @@ template <int OP> __global__ void k_rate(double *io, long long *cyc, double a, d
   if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 // hardware quotient vs the invariant-divisor form: y = 1/b (IEEE), q = a*y, two fma corrections
-__device__ __forceinline__ double div_inv2(double a, double b, double y) {
-  double q = a * y;
-  double e = __builtin_fma(-b, q, a);
-  q = __builtin_fma(e, y, q);
+__device__ __forceinline__ double div_inv2(double a, double b, double y) {      // = divi() of pomgpu_internal.hpp, the zero's sign included
+  const double q0 = a * y;
+  double e = __builtin_fma(-b, q0, a);
+  double q = __builtin_fma(e, y, q0);
   e = __builtin_fma(-b, q, a);
-  return __builtin_fma(e, y, q);
+  q = __builtin_fma(e, y, q);
+  return a == 0. ? q0 : q;
 }
 __device__ __forceinline__ double div_inv1(double a, double b, double y) {
   const double q = a * y;
@@ -63,13 +64,19 @@ __global__ void k_check(unsigned long long seed, int mode, unsigned long long *b
     } else if (mode == 1) {   // divisors with few significant bits / near powers of two, numerators near the hard cases
       b = __longlong_as_double((long long)((r2 & 0x000ff00000000fffull) | (1023ull << 52)));
       a = __longlong_as_double((long long)((r1 & 0x000fffffffffffffull) | (1023ull << 52)));
-    } else {                  // significand of b all ones on top (worst case for the reciprocal), a random
+    } else if (mode == 2) {   // significand of b all ones on top (worst case for the reciprocal), a random
       b = __longlong_as_double((long long)((0x000fffffffff0000ull | (r2 & 0xffff)) | (1023ull << 52)));
       a = __longlong_as_double((long long)((r1 & 0x000fffffffffffffull) | (1024ull << 52)));
+    } else if (mode == 3) {   // zero numerators of both signs (masked fluxes), divisors of both signs: the QUOTIENT'S SIGN must survive
+      b = __longlong_as_double((long long)((r2 & 0x800fffffffffffffull) | ((uint64_t)(1023 - 40 + (r2 >> 52) % 81) << 52)));
+      a = (r1 & 1) ? -0.0 : 0.0;
+    } else {                  // numerators whose residual a - b*q is subnormal (|a| in 2^-1074 .. 2^-960): documented as not covered, counted here
+      b = __longlong_as_double((long long)((r2 & 0x000fffffffffffffull) | ((uint64_t)(1023 + (r2 >> 52) % 4) << 52)));
+      a = __longlong_as_double((long long)((r1 & 0x800fffffffffffffull) | ((uint64_t)((r1 >> 52) % 64) << 52)));
     }
     const double y = 1.0 / b, q = a / b;
-    if (div_inv1(a, b, y) != q) b1++;
-    if (div_inv2(a, b, y) != q) b2++;
+    if (__double_as_longlong(div_inv1(a, b, y)) != __double_as_longlong(q)) b1++;      // bitwise: -0.0 is not +0.0 here
+    if (__double_as_longlong(div_inv2(a, b, y)) != __double_as_longlong(q)) b2++;
   }
   if (b1) atomicAdd(bad1, b1);
   if (b2) atomicAdd(bad2, b2);
@@ -84,11 +91,12 @@ int main() {
     k_rate<OP><<<1, 64>>>(io, cyc, 1.0000001, 0.9999999); k_rate<OP><<<1, 64>>>(io, cyc, 1.0000001, 0.9999999); long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); \
     printf("%-28s %7.2f cycles per op per wave (%lld cycles / %d)\n", names[OP], (double)c / (REP * N), c, REP * N); }
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13)
-  for (int mode = 0; mode < 3; mode++) {
+  for (int mode = 0; mode < 5; mode++) {
     hipMemset(bad, 0, 16);
     k_check<<<4096, 256>>>(12345 + mode, mode, bad, bad + 1, 1024);
     unsigned long long hb[2]; hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost);
-    printf("division check mode %d: %llu quotients; mismatches with 1 correction: %llu, with 2 corrections: %llu\n", mode, 4096ull * 256 * 1024, hb[0], hb[1]);
+    printf("division check mode %d%s: %llu quotients compared bit for bit; mismatches with 1 correction: %llu, with 2 corrections: %llu\n", mode,
+           mode == 3 ? " (signed zero numerators)" : mode == 4 ? " (numerators in the subnormal range: NOT covered by divi, documented)" : "", 4096ull * 256 * 1024, hb[0], hb[1]);
   }
   return 0;
 }
