@@ -1326,6 +1326,11 @@ __global__ void __launch_bounds__(256) k_ext_march2(KP P, Gen7 T, GenD GX, GenD 
 #undef FST
 }
 #endif
+// Tried and dropped (profiles/round3_ext_pair.txt): the two substeps as a producer and a consumer WAVEFRONT of one workgroup (A evaluates
+// substep n and mails each row -- generation Y, the static operands, the accumulators -- through LDS to B, which evaluates substep
+// n+1 two rows behind; 256 registers each, two waves per SIMD, one workgroup barrier per row).  Bit-identical, the same 1.15 GB per
+// pair, but 308-341 us per pair against 251: the waves wait at the per-row barrier (SQ_WAIT_INST_ANY 9.9e7 against 1.7e7 cycles),
+// VALU busy 19 % per wave against 53 %.
 // the ring of one substep (the cells k_ext_march2 leaves out), advave formed in place: P.x2 = the generation read, P.y2 = the generation written
 __global__ void __launch_bounds__(64) k_ext_ring(KP P, int store_f, int nlo, int nhi) {
   ext_ring_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f, nlo, nhi);
