@@ -1493,14 +1493,28 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
 // Two substeps (Q.iext, Q.iext + 1) in one pass over memory (k_ext_march2, the ring's first substep beside it) + the ring's second substep (k_ext_ring).  Q: c->P with x2 = the
 // generation read, y2 = the generation written (the other buffer set); T: a third set for the rim's / the band's intermediate
 // generation.  Returns 1 when launched, 0 when the tile is not one for this path (the caller takes the substeps one by one).
-int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) {
+// is the tile one for that path?  (without launching: pomgpu_mode_external decides with it whether an odd substep may wait for its partner)
+int launch_ext_pair_ok(const KP &Q) {
 #ifdef POMGPU_EMU
-  (void)c; (void)Q; (void)T; (void)store_f2;
+  (void)Q;
   return 0;                                                   // neighbour lanes are not emulated (tests/emu): the GPU tests cover this path
 #else
   if (getenv("POMGPU_EXT_NOPAIR")) return 0;
   const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);         // blk2d through one 32-bit buffer descriptor
   if (!fits || Q.im < 16 || Q.jm < 16) return 0;
+  // small tiles keep the one-substep kernels unless asked (tests): the ring's ~20 us of dependent latency per pair and the few
+  // wavefronts of a small tile eat the gain (profiles/round3_ext_pair.txt: the extended tile of an 8-tile split)
+  const long wave_rows = (long)grid2_halo(Q).x * (Q.jmm1 - 2);
+  if (wave_rows < 16500 && !getenv("POMGPU_EXT_PAIR")) return 0;
+  return 1;
+#endif
+}
+int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) {
+#ifdef POMGPU_EMU
+  (void)c; (void)Q; (void)T; (void)store_f2;
+  return 0;
+#else
+  if (!launch_ext_pair_ok(Q)) return 0;
   static int ncu = 0;
   if (!ncu) {
     hipDeviceProp_t pr;
@@ -1520,10 +1534,6 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   }
   if (getenv("POMGPU_EXT_ROWS2")) rows = atoi(getenv("POMGPU_EXT_ROWS2"));
   if (rows < 2) return 0;
-  // small tiles keep the one-substep kernels unless asked (tests): below ~two workgroups per CU the marching kernels lose to
-  // the one-row kernel (profiles/round2_ext_march.txt)
-  const long wave_rows = (long)grid2_halo(Q).x * (Q.jmm1 - 2);
-  if (wave_rows < 16500 && !getenv("POMGPU_EXT_PAIR")) return 0;
   const int nseg = (nrow + rows - 1) / rows;
   const int nl = RING_LO + RING_HI, n = nl * Q.im + nl * (Q.jm - nl);          // cells of the ring
   const int ring_wgs = ((n + 255) / 256 + 7) / 8 * 8;

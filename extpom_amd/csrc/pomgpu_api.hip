@@ -236,7 +236,9 @@ static void restore_materialize(pomgpu_ctx *c) {
   c->rst_pending = 0;
   launch_restore_fields(c, c->rst_fold, c->rst_fnew);
 }
+static void ext_flush_deferred(pomgpu_ctx *c);
 static void ext_canonical(pomgpu_ctx *c) {
+  ext_flush_deferred(c);                                      // a substep pomgpu_mode_external is holding back for its partner
   if (!c->ext_parity) return;
   KP &P = c->P;
   for (int n = 0; n < POMGPU_NGEN; n++) launch_copy2(c, P.b2 + (size_t)X2_SLOT[n] * P.n2, c->alt2[n]);
@@ -927,13 +929,18 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
 // Substeps iext and iext + 1 in one pass over memory (k_ext_march2, k_ext.hip): one tile -- or the extended tile of the wide-halo
 // mode -- large enough for the marching kernels, inside pomgpu_advance only (the public pomgpu_mode_external leaves elf, uaf, vaf
 // of EVERY substep in memory for its caller).  1 = both substeps done (c->con.iext = iext + 1), 0 = not applicable.
-static int ext_pair(pomgpu_ctx *c, int iext) {
+static int ext_pair_ok(pomgpu_ctx *c, int iext) {             // may substeps iext, iext + 1 share a pass?
   pomgpu_ctx *t = c;
   if (c->wide.on) { if (!c->wide.pending) return 0; t = c->wide.x; }
   else if (c->exch) return 0;
+  if (iext < 1 || iext + 1 > c->con.isplit || getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || t->P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE")) return 0;
+  return launch_ext_pair_ok(t->P);
+}
+static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
+  if (!ext_pair_ok(c, iext)) return 0;
+  pomgpu_ctx *t = c->wide.on ? c->wide.x : c;
   const int isplit = c->con.isplit;
   KP &P = t->P;
-  if (iext + 1 > isplit || getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE")) return 0;
   if (!t->alt3[0]) {
     if (hipMalloc((void **)&t->alt3[0], (size_t)POMGPU_NGEN * P.n2 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); t->alt3[0] = NULL; return 0; }
     for (int n = 1; n < POMGPU_NGEN; n++) t->alt3[n] = t->alt3[0] + (size_t)n * P.n2;
@@ -944,7 +951,7 @@ static int ext_pair(pomgpu_ctx *c, int iext) {
   if (iext == 1 || !t->areas_checked) { launch_check_areas(t); t->areas_checked = 1; }
   KP Q = P;
   for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = t->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : t->alt2[n];
-  if (!launch_ext_pair(t, Q, t->alt3, iext + 1 == isplit)) return 0;
+  if (!launch_ext_pair(t, Q, t->alt3, store_f || iext + 1 == isplit)) return 0;
   t->ext_parity ^= 1;                                         // two substeps, one change of buffer sets
   ext_buffers(t);
   c->con.iext = iext + 1; t->con.iext = iext + 1; P.iext = iext + 1; c->P.iext = iext + 1;
@@ -1319,7 +1326,38 @@ static void wide_flush(pomgpu_ctx *c) {
 }
 
 extern "C" int pomgpu_mode_interaction(pomgpu_ctx *c) { return mode_interaction(c, 0); }
-extern "C" int pomgpu_mode_external(pomgpu_ctx *c) { return mode_external(c, 1); }
+// the substep pomgpu_mode_external holds back, alone after all (its partner did not come: another entry point, a download ...)
+static void ext_flush_deferred(pomgpu_ctx *c) {
+  if (!c->ext_deferred) return;
+  const int now = c->con.iext;
+  c->con.iext = c->ext_deferred;
+  c->ext_deferred = 0;
+  (void)mode_external(c, 1);
+  c->con.iext = now;
+  c->P.iext = now;
+}
+// The reference calls mode_external isplit times in a row (advance.f:27-29) and looks at nothing in between.  An ODD substep of a tile
+// that takes two substeps per pass (k_ext_march2) is therefore held back until the next call: if that is the following substep, the
+// two run as one pass (elf, uaf, vaf of the second are stored, as the caller of this entry point may expect of every call); anything
+// else that touches the state first -- any other entry point, a download -- makes it run alone before (ext_canonical).
+extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {
+  NEED_RAW(c);
+  const int iext = c->con.iext;
+  if (c->ext_deferred) {
+    if (iext == c->ext_deferred + 1) {
+      const int first = c->ext_deferred;
+      c->ext_deferred = 0;
+      if (ext_pair(c, first, 1)) return POMGPU_OK;
+      c->con.iext = first;                                    // the pass was refused after all: the two substeps one by one
+      int rc = mode_external(c, 1);
+      c->con.iext = iext;
+      return rc ? rc : mode_external(c, 1);
+    }
+    ext_flush_deferred(c);
+  }
+  if ((iext & 1) && ext_pair_ok(c, iext)) { c->ext_deferred = iext; return POMGPU_OK; }
+  return mode_external(c, 1);
+}
 extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
   NEED_HOT(c);
   KP &P = c->P;

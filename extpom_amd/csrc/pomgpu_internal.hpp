@@ -480,6 +480,7 @@ struct pomgpu_ctx {
   double *alt2[POMGPU_NGEN]; // second buffer set of ua, va, d, el, elb, uab, vab (fused external step)
   double *alt3[POMGPU_NGEN]; // third set: the intermediate generation on the rim and next to it when two substeps share a pass (k_ext_march2); allocated on first use
   int ext_parity;            // 1 while the current generation of those five lives in alt2
+  int ext_deferred;          // pomgpu_mode_external was called for this (odd) substep and waits for its partner: the two run as one pass (k_ext_march2)
   // taurstrb / taurstrf (index 0 / 1): known to hold one value everywhere restore_interior looks, because the library wrote
   // it itself ("taurstrf = 1./trst", bounds_forcing.f:1043,1065; the shift :1054-1056 hands f's value to b).  k_ts_update then
   // forms taurstr from the two scalars instead of reading two 3-D arrays.  Any upload of those arrays ends the knowledge.
@@ -598,6 +599,7 @@ void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
 void launch_check_areas(pomgpu_ctx *c);
 int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last);   // 1 = launched (all substeps first..last), 0 = not applicable
+int launch_ext_pair_ok(const KP &Q);                                             // would launch_ext_pair take this tile?
 int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2);   // 1 = substeps Q.iext, Q.iext + 1 launched, 0 = not applicable
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate

@@ -692,3 +692,38 @@ def test_two_external_substeps_per_pass(monkeypatch, case, im, jm, kb, isplit, r
     g.close()
     assert prof.get("k_ext_pair", (0, 0))[0] == 3 * (isplit // 2), prof.keys()     # the path under test did run
     assert not diff(a, b), diff(a, b)
+
+
+def test_reference_call_sequence_pairs_its_external_substeps(monkeypatch):
+    """the Fortran host's way (advance.f:6-59 routine by routine: isplit calls of pomgpu_mode_external): an odd substep of a tile that
+    takes two substeps per pass waits for the next call and the two run as ONE pass; a download in between (here after substep 3
+    of step 2) makes the waiting substep run alone first.  Same bits as the oracle either way."""
+    OracleTile, oracle_finish_initial = _oracle()
+    monkeypatch.setenv("POMGPU_EXT_PAIR", "1")
+    isplit = 8
+    a = make_case("seamount", 96, 80, 9, dte=6.0, isplit=isplit)
+    oracle_finish_initial(a)
+    b = a.copy()
+    OracleTile(a).run(3)
+    g = _gpu(b)
+    g.prof_begin()
+    for n in range(1, 4):
+        g.set_con(iint=n)
+        g.call("get_time")
+        g.get_con()
+        g.call("lateral_viscosity")
+        g.call("mode_interaction")
+        for iext in range(1, isplit + 1):
+            g.set_con(iext=iext)
+            g.call("mode_external")
+            if n == 2 and iext == 3:
+                g.download()                                  # substep 3 was waiting for substep 4: it runs alone now
+                g.set_con(iext=iext)
+        g.set_con(iext=isplit + 1)
+        g.call("mode_internal")
+        g.check_velocity()
+    prof = g.prof_end()
+    g.download()
+    g.close()
+    assert prof.get("k_ext_pair", (0, 0))[0] == 3 * (isplit // 2) - 1, {k: v[0] for k, v in prof.items() if "ext" in k}
+    assert not diff(a, b), diff(a, b)
