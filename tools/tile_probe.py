@@ -68,6 +68,7 @@ def main():
     g.sync()
     dt = (time.perf_counter() - t0) / a.steps
     rounds = (g.exchange_rounds() - r0) / a.steps
+    prof.pop("phase_step", None); prof.pop("phase_external", None)     # brackets around other brackets (pomgpu.h): not kernels
     msg = prof.pop("msg_round", (0, 0.0))
     msg_side = prof.pop("msg_round_side", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
