@@ -65,7 +65,9 @@ def worker(rank, world, split, port, out, nml):
 
     finish_initial(st, dens, baropg)
     g.upload(st)
+    g.prof_begin()
     g.run(STEPS)
+    kernels = ",".join(sorted(g.prof_end()))
     # the output file of the reference, every rank its patch (rank 0 lays the file out first)
     if rank == 0:
         g.write_file("output", os.path.join(out, "out.nc"), title="tiles", time_start="t0", im_global=IM, jm_global=JM, create=True)
@@ -75,7 +77,7 @@ def worker(rank, world, split, port, out, nml):
     dist.barrier()
     g.download()
     np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
-             n=(halo.count if mode == "hook" else g.exchange_rounds()), **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
+             n=(halo.count if mode == "hook" else g.exchange_rounds()), kernels=np.array(kernels), **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
     g.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -98,6 +100,7 @@ def main(split, nml, exchange="hook"):
         assert int(z["n"]) > (15 if exchange in ("wide", "rccl") else 100), int(z["n"])
         if r == 0:
             print("message rounds on rank 0:", int(z["n"]))
+            print("kernels on rank 0:", str(z["kernels"]))
         sl_j = slice(0 if jo == 0 else 1, jm if jo + jm == JM else jm - 1)
         sl_i = slice(0 if io == 0 else 1, im if io + im == IM else im - 1)
         for n in BLK2D + BLK3D:

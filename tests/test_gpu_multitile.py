@@ -40,6 +40,18 @@ def test_library_exchange_and_wide_halo_external_mode(args):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [["xy", "wide"], ["y", "wide"]])
+def test_wide_halo_mode_with_two_substeps_per_pass(args):
+    """the extended tile of the wide-halo mode under k_ext_march2 (two external substeps per pass over memory; its default on tiles
+    as large as those of a 2-GPU split of the bench grid, forced here): owned cells equal the single-tile oracle bit for bit"""
+    env = dict(os.environ, POMGPU_EXT_PAIR="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py")] + args, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "k_ext_pair" in r.stdout, r.stdout[-1500:]         # the path under test did run (the worker prints rank 0's kernel list)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["x", "rccl"], ["xy", "rccl"], ["y", "npg2", "rccl"]])
 def test_rccl_between_distinct_ranks_one_gpu_each(args):
     """bench.py's N > 1 path as a parity test: rank r on GPU r, the library's RCCL transport (main and side stream, both
