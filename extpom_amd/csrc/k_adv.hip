@@ -760,36 +760,73 @@ __device__ __forceinline__ double aam_point(const KP &P, double dx, double dy, d
          sqrt(sq((u_e - u_c) / dx) + sq((v_n - v_c) / dy) +
               .5 * sq(.25 * (u_n + u_ne - u_s - u_se) / dy + .25 * (v_e + v_ne - v_w - v_nw) / dx));
 }
+// the same with the four divisions by dx, dy through divi() (their reciprocals from k_coef_static: correctly rounded quotients, the same
+// bits -- pomgpu_internal.hpp).  The counters put k_aam_pair on its arithmetic, not on memory (profiles/round3_pmc_kernels.txt: VALU
+// 0.13 of every wave's cycles at 8 waves per SIMD): 8 division macros (~69 cycles each) + 2 square roots per lane; forming the
+// reciprocals in the kernel (round 2) only moved the divisions.
+__device__ __forceinline__ double aam_point_r(const KP &P, const InvD &dx, const InvD &dy, double u_c, double u_e, double u_n, double u_ne, double u_s,
+                                              double u_se, double v_c, double v_n, double v_e, double v_ne, double v_w, double v_nw) {
+  return P.horcon * dx.b * dy.b *
+         sqrt(sq(divi(u_e - u_c, dx)) + sq(divi(v_n - v_c, dy)) +
+              .5 * sq(divi(.25 * (u_n + u_ne - u_s - u_se), dy) + divi(.25 * (v_e + v_ne - v_w - v_nw), dx)));
+}
+// AAM_KCH levels per wavefront, the operands of level k+1 requested while level k is worked on: one level per wavefront was 1.3 M
+// wavefronts of seven loads, ~600 cycles of dependent fp64 and two stores each -- 4.0 TB/s of real traffic, bound by that chain at
+// 8 waves per SIMD (neither memory nor arithmetic: the divisions through reciprocals bought 1.3 %).
+#ifndef AAM_KCH
+#define AAM_KCH 7
+#endif
+struct AamLev { double2 u_s, u_0, u_n, v_0, v_n; };
 __global__ void __launch_bounds__(256) k_aam_pair(KP P) {
-  // banded XCD-aware decode as MARCH3, with 124 output columns per wavefront
+  // banded XCD-aware decode as MARCH3, with 124 output columns per wavefront; the level index counts chunks of AAM_KCH levels
   const int g_ = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   const int L_ = g_ >> 6, xcd_ = L_ & 7, m_ = L_ >> 3;
   const int nbx_ = (P.iml / 2 + 61) / 62, bpl_ = nbx_ * (P.g_rb / 4);
+  const int nch_ = (P.kbm1 + AAM_KCH - 1) / AAM_KCH;
   const int p_ = m_ % bpl_, t_ = m_ / bpl_;
-  const int k = t_ % P.kb + 1;
-  const int band_ = (t_ / P.kb) * 8 + xcd_;
+  const int k0 = (t_ % nch_) * AAM_KCH + 1;
+  const int band_ = (t_ / nch_) * 8 + xcd_;
   const int lane = g_ & 63;
   const int ia0 = 2 * ((p_ % nbx_) * 62 + lane - 1) + 1;
   const int j = band_ * P.g_rb + (p_ / nbx_) * 4 + (int)threadIdx.y + 1;
-  if (k > P.kbm1 || j < 2 || j > P.jmm1) return;            // wave-uniform
+  if (k0 > P.kbm1 || j < 2 || j > P.jmm1) return;            // wave-uniform
+  const int k1 = k0 + AAM_KCH - 1 < P.kbm1 ? k0 + AAM_KCH - 1 : P.kbm1;
   const bool out = (lane >= 1 && lane <= 62 && ia0 <= P.iml);
 #ifdef POMGPU_EMU
   if (!out) return;
 #endif
   const int ia = ia0 < 1 ? 1 : (ia0 > P.iml - 1 ? P.iml - 1 : ia0), ib = ia + 1;
   const int iw = ia > 1 ? ia - 1 : 1, ie = ib < P.iml ? ib + 1 : P.iml;
-  const double2 u_s = LD2(A3(u), ia, j - 1, k), u_0 = LD2(A3(u), ia, j, k), u_n = LD2(A3(u), ia, j + 1, k);
-  const double2 v_0 = LD2(A3(v), ia, j, k), v_n = LD2(A3(v), ia, j + 1, k);
   const double2 dx = *(const double2 *)&F2(dx, ia, j), dy = *(const double2 *)&F2(dy, ia, j);
-  const double uE_s = halo_e(u_s.x, [&] { return u_(ie, j - 1, k); }), uE_0 = halo_e(u_0.x, [&] { return u_(ie, j, k); }),
-               uE_n = halo_e(u_n.x, [&] { return u_(ie, j + 1, k); });
-  const double vE_0 = halo_e(v_0.x, [&] { return v_(ie, j, k); }), vE_n = halo_e(v_n.x, [&] { return v_(ie, j + 1, k); });
-  const double vW_0 = halo_w(v_0.y, [&] { return v_(iw, j, k); }), vW_n = halo_w(v_n.y, [&] { return v_(iw, j + 1, k); });
-  if (!out) return;
-  if (ia0 >= 2 && ia0 <= P.imm1)
-    F3(aam, ia0, j, k) = aam_point(P, dx.x, dy.x, u_0.x, u_0.y, u_n.x, u_n.y, u_s.x, u_s.y, v_0.x, v_n.x, v_0.y, v_n.y, vW_0, vW_n);
-  if (ia0 + 1 <= P.imm1)
-    F3(aam, ia0 + 1, j, k) = aam_point(P, dx.y, dy.y, u_0.y, uE_0, u_n.y, uE_n, u_s.y, uE_s, v_0.y, v_n.y, vE_0, vE_n, v_0.x, v_n.x);
+#ifndef AAM_PLAIN_DIV
+  const double2 rdx = *(const double2 *)&K2(RDX, ia, j), rdy = *(const double2 *)&K2(RDY, ia, j);
+  const InvD dxa = {dx.x, rdx.x}, dya = {dy.x, rdy.x}, dxb = {dx.y, rdx.y}, dyb = {dy.y, rdy.y};
+#endif
+  auto lev = [&](int k) {
+    AamLev L;
+    L.u_s = LD2(A3(u), ia, j - 1, k); L.u_0 = LD2(A3(u), ia, j, k); L.u_n = LD2(A3(u), ia, j + 1, k);
+    L.v_0 = LD2(A3(v), ia, j, k); L.v_n = LD2(A3(v), ia, j + 1, k);
+    return L;
+  };
+  AamLev cur = lev(k0);
+  for (int k = k0; k <= k1; k++) {
+    const AamLev nxt = lev(k < k1 ? k + 1 : k1);              // in flight during this level (the last one re-requests itself)
+    const double2 u_s = cur.u_s, u_0 = cur.u_0, u_n = cur.u_n, v_0 = cur.v_0, v_n = cur.v_n;
+    const double uE_s = halo_e(u_s.x, [&] { return u_(ie, j - 1, k); }), uE_0 = halo_e(u_0.x, [&] { return u_(ie, j, k); }),
+                 uE_n = halo_e(u_n.x, [&] { return u_(ie, j + 1, k); });
+    const double vE_0 = halo_e(v_0.x, [&] { return v_(ie, j, k); }), vE_n = halo_e(v_n.x, [&] { return v_(ie, j + 1, k); });
+    const double vW_0 = halo_w(v_0.y, [&] { return v_(iw, j, k); }), vW_n = halo_w(v_n.y, [&] { return v_(iw, j + 1, k); });
+#ifndef AAM_PLAIN_DIV
+    const double aa = aam_point_r(P, dxa, dya, u_0.x, u_0.y, u_n.x, u_n.y, u_s.x, u_s.y, v_0.x, v_n.x, v_0.y, v_n.y, vW_0, vW_n);
+    const double ab = aam_point_r(P, dxb, dyb, u_0.y, uE_0, u_n.y, uE_n, u_s.y, uE_s, v_0.y, v_n.y, vE_0, vE_n, v_0.x, v_n.x);
+#else
+    const double aa = aam_point(P, dx.x, dy.x, u_0.x, u_0.y, u_n.x, u_n.y, u_s.x, u_s.y, v_0.x, v_n.x, v_0.y, v_n.y, vW_0, vW_n);
+    const double ab = aam_point(P, dx.y, dy.y, u_0.y, uE_0, u_n.y, uE_n, u_s.y, uE_s, v_0.y, v_n.y, vE_0, vE_n, v_0.x, v_n.x);
+#endif
+    if (out && ia0 >= 2 && ia0 <= P.imm1) F3(aam, ia0, j, k) = aa;
+    if (out && ia0 + 1 <= P.imm1) F3(aam, ia0 + 1, j, k) = ab;
+    cur = nxt;
+  }
 }
 #undef LD2
 #undef A3
@@ -809,7 +846,8 @@ void launch_aam(pomgpu_ctx *c) {
   if (pair_ok && P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
     const long nbands = (P.jml + P.g_rb - 1) / P.g_rb, rounds = (nbands + 7) / 8;
     const long bpl = (long)((P.iml / 2 + 61) / 62) * (P.g_rb / 4);
-    LAUNCHN(c, "k_aam_pair", k_aam_pair, dim3((unsigned)(8 * rounds * P.kb * bpl), 1, 1), blk2(), c->P);
+    const long nch = (P.kbm1 + AAM_KCH - 1) / AAM_KCH;          // chunks of levels per wavefront
+    LAUNCHN(c, "k_aam_pair", k_aam_pair, dim3((unsigned)(8 * rounds * nch * bpl), 1, 1), blk2(), c->P);
   } else {
     LAUNCH(c, k_aam, gridm(c->P), blk2(), c->P);
   }

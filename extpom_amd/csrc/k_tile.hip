@@ -29,6 +29,8 @@ __global__ void k_coef_static(KP P) {
   K2(CVB, i, j) = F2(dx, i, jn) - F2(dx, i, js);
   K2(R2DXSX, i, j) = 2.0 / (F2(dx, i, j) + F2(dx, iw, j));
   K2(R2DYSY, i, j) = 2.0 / (F2(dy, i, j) + F2(dy, i, js));
+  K2(RDX, i, j) = 1.0 / F2(dx, i, j);
+  K2(RDY, i, j) = 1.0 / F2(dy, i, j);
   // reciprocals of the vertical grid arrays (divi(), pomgpu_internal.hpp); 1/0 = inf where dz, dzz are 0 (level kb): never used
   if (j == 1)
     for (int n = i - 1; n < POM_NBLK1D * P.kb; n += P.iml) P.r1[n] = 1.0 / P.b1[n];

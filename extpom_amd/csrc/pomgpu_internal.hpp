@@ -132,6 +132,7 @@ enum pomgpu_coef2 {
   C2_DX4, C2_DY4,      // the same four-point sums of dx and dy               (static)
   C2_CVA, C2_CVB,      // dy(i+1,j)-dy(i-1,j), dx(i,j+1)-dx(i,j-1)            (static; curvature terms)
   C2_R2DXSX, C2_R2DYSY,// 2.0/DXSX, 2.0/DYSY                                  (static; realvertvl's dxl/dyb)
+  C2_RDX, C2_RDY,      // RN(1/dx), RN(1/dy): the reciprocals divi() needs         (static; k_aam_pair's four divisions per cell)
   C2__count
 };
 static_assert(C2__count <= POMGPU_NCOEF2, "raise POMGPU_NCOEF2");
