@@ -482,6 +482,8 @@ template <int TAU> __device__ __forceinline__ void c_ts_update(const KP &P, cons
   F3(sb, i, j, k) = sbn;
   if (lev && act) F3(rho, i, j, k) = dens_point(P, sn, tn, i, j, k);
 }
+// (Tried: 7 levels per wavefront with the next level's operands in flight, as k_aam_pair now does -- 4.08 against 3.90 ms: this kernel's
+// 2.5 M one-level wavefronts at 8 waves per SIMD already keep its 17 passes moving at 5.5 TB/s; the chunked form holds 110 VGPRs, 4 waves.)
 __device__ __forceinline__ void c_mask_ts(const KP &P, const int i, const int j, const int k);
 __global__ void k_mask_ts(KP P) {   // the mask of bcond(4) alone
   MARCH3(c_mask_ts(P, i, j, k))
