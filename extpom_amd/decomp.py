@@ -72,7 +72,16 @@ def make_tile(rank: int, im_global: int, jm_global: int, im_local: int, jm_local
 
 
 def choose_tile_grid(n: int, im_global: int, jm_global: int) -> tuple[int, int]:
-    """Pick nproc_x x nproc_y = n with the most square tiles (fewest halo cells)."""
+    """Pick nproc_x x nproc_y = n.  The reference leaves the split to the user (im_local, jm_local in pom.h); here: whole rows
+    (1 x n) when the tiles keep at least 128 rows, else the most square tiles (fewest halo cells).
+
+    Measured (tools/grid_sweep.sh, one tile of 2048x1536x50 on one MI355X, ms per step without transfers): 8 tiles 1x8 6.97,
+    2x4 7.14, 4x2 7.31, 8x1 7.60; 4 tiles 1x4 12.27, 2x2 12.57, 4x1 12.67; 2 tiles 1x2 21.28, 2x1 22.77 -- full-width rows keep
+    every wavefront of the 3-D kernels full (a 514-column row ends in a wavefront with 18 of 62 columns), a tile then has two
+    neighbours instead of eight and its edge lines are contiguous in memory."""
+    iml, jml = local_size(im_global, jm_global, 1, n)
+    if n > 1 and jml >= 128 and tile_grid(im_global, jm_global, iml, jml) == (1, n):
+        return 1, n
     best = None
     for nx in range(1, n + 1):
         if n % nx:

@@ -52,7 +52,8 @@ def test_decomposition_matches_distribute_mpi():
         decomp.make_tile(0, 282, 306, 100, 306, n_proc=2)   # "im_local or jm_local is too low"
     for n in (1, 2, 4, 8):
         nx, ny = decomp.choose_tile_grid(n, 2048, 1536)
-        assert nx * ny == n
+        assert (nx, ny) == (1, n)                           # whole rows while the tiles stay tall enough (profiles/round3_tile_grids.txt)
+    assert decomp.choose_tile_grid(4, 65, 49) == (2, 2)
 
 
 @pytest.mark.parametrize("case", ["seamount", "island", "basin"])
