@@ -1618,7 +1618,7 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
-  { KP g = c->P; set_band_geometry(g); c->P.g_strip = g.g_strip; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, honoured per step (tools/kbench.py)
+  { KP g = c->P; set_band_geometry(g); c->P.g_strip = g.g_strip; c->P.g_lin = g.g_lin; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, honoured per step (tools/kbench.py)
   // advance.f:14-18: file-driven in the reference; here they run once the host has supplied records
   if (c->frc_on && (rc = pomgpu_surface_forcing(c))) return rc;
   if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;

@@ -41,6 +41,7 @@ struct KP {
          tbias, tprni, umol, horcon, ispi, isp2i, smoth, sw, time, vmaxl;
   int mode, ntp, nadv, nbct, nbcs, nitera, npg, isplit, iext, iint, iend;
   int g_rb, g_nbx, g_bpl;    // launch geometry of the banded cell kernels (set_band_geometry)
+  int g_lin;                 // row-sharing column kernels: tiles whose block-rows leave the eight XCD bands under 90 % full take the balanced order (HALO_XCD_DECODE_R)
   int g_strip;               // row-sharing column kernels: an XCD walks its band in strips this many workgroups wide (0: row by row)
   // host-evaluated loop invariants (libm pow): solver.f:1273, :1297
   double const1_profq, cb_profq;
@@ -373,7 +374,6 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
 // profiles/round2_strip_order.txt): width 2 +6..10 %, 4 +-0, 8 -2..5 %, 11-12 -2.5..5 % (advct, advq), 16 -1..3 % against
 // whole rows; set_band_geometry picks the width nearest 12 that divides the row evenly.
 #define HALO_XCD_ORDER                                                                    \
-  int byl__, bxg__;                                                                       \
   if (P.g_strip > 0) {                                                                    \
     const int st__ = P.g_strip, nfull__ = nbx__ / st__, wlast__ = nbx__ - nfull__ * st__; \
     int s__ = m__ / (rpx__ * st__);                                                       \
@@ -386,19 +386,38 @@ static inline double divi(double a, const InvD &d) { return a / d.b; }
     if (byl__ >= rpx__) return;                                                           \
   }
 #define HALO_XCD_DECODE HALO_XCD_DECODE_R(COL_ROWS)
+// Tiles whose block-rows fill less than 90 % of the eight bands (a 194-row tile of a 1 x 8 split: 25 block-rows of 8 -> bands of
+// 4, 4, ..., 1, 0 block-rows: one XCD idle, one at a quarter) take the BALANCED order instead (P.g_lin): the workgroups in
+// strip-major order (strip, block-row, column inside the strip -- a strip is g_strip wide, or the whole row), XCD x owns the
+// contiguous share [x*T/8, (x+1)*T/8) of that sequence: shares differ by one workgroup at most, an XCD's workgroups are still
+// neighbours.  tools/lin_ab.sh, one tile of 2048x1536x50, the four kernels together: 1 x 8 split (25 block-rows) 1.83 -> 1.67 ms,
+// 1 x 4 (49) 3.11 -> 3.03, 1 x 2 (97 block-rows, 93 % full) 5.47 -> 5.65: the banded order stays where the bands are nearly full.
 #define HALO_XCD_DECODE_R(ROWS__)                                                         \
   const int g__ = (int)(blockIdx.x * blockDim.x + threadIdx.x);                           \
   const int L__ = g__ >> 6, nwx__ = (P.iml + 61) / 62, nbx__ = (nwx__ + COL_WX - 1) / COL_WX; \
   const int nby__ = (P.jml + ROWS__ - 1) / ROWS__;                                        \
   const int rpx__ = (nby__ + 7) / 8, m__ = L__ >> 3;                                      \
-  HALO_XCD_ORDER                                                                          \
-  const int by__ = (L__ & 7) * rpx__ + byl__;                                             \
-  if (by__ >= nby__) return;                                                              \
+  int by__, bxg__;                                                                        \
+  if (P.g_lin && 10 * nby__ < 72 * rpx__) {                                               \
+    const int x__ = L__ & 7, T__ = nby__ * nbx__;                                         \
+    const int c0__ = (int)(((long)x__ * T__) >> 3), c1__ = (int)(((long)(x__ + 1) * T__) >> 3); \
+    const int t__ = c0__ + m__;                                                           \
+    if (t__ >= c1__) return;                                                              \
+    const int st__ = P.g_strip > 0 ? P.g_strip : nbx__, per__ = st__ * nby__, s__ = t__ / per__; \
+    const int rem__ = t__ - s__ * per__, w__ = (s__ + 1) * st__ <= nbx__ ? st__ : nbx__ - s__ * st__; \
+    by__ = rem__ / w__; bxg__ = s__ * st__ + rem__ % w__;                                 \
+  } else {                                                                                \
+    int byl__;                                                                            \
+    HALO_XCD_ORDER                                                                        \
+    by__ = (L__ & 7) * rpx__ + byl__;                                                     \
+    if (by__ >= nby__) return;                                                            \
+  }                                                                                       \
   const int lane = g__ & 63;                                                              \
   const int i0 = (bxg__ * COL_WX + (int)threadIdx.y % COL_WX) * 62 + lane;                \
   const int j = by__ * ROWS__ + (int)threadIdx.y / COL_WX + 1;
 static inline dim3 grid1_halo_r(const KP &P, int rows) {
   const int nwx = (P.iml + 61) / 62, nbx = (nwx + COL_WX - 1) / COL_WX, nby = (P.jml + rows - 1) / rows, rpx = (nby + 7) / 8;
+  if (P.g_lin && 10 * nby < 72 * rpx) return dim3((unsigned)(8 * ((nby * nbx + 7) / 8)), 1, 1);
   return dim3((unsigned)(8 * rpx * nbx), 1, 1);
 }
 static inline dim3 grid1_halo(const KP &P) { return grid1_halo_r(P, COL_ROWS); }
@@ -573,6 +592,17 @@ static inline void set_band_geometry(KP &P) {
   P.g_strip = nbx >= 20 ? (nbx + nstr - 1) / nstr : 0;
   const char *es = getenv("POMGPU_COL_STRIP");
   if (es) P.g_strip = atoi(es);
+  P.g_lin = getenv("POMGPU_NO_LIN") ? 0 : 1;
+  // cell launches: of the band heights the L2 budget allows, the one that leaves the fewest empty band slots (8 bands per round)
+  if (!e) {
+    long best = -1, bslots = 0;
+    for (long r = 4; r <= rows; r += 4) {
+      const long nb = (P.jml + r - 1) / r, slots = (nb + 7) / 8 * 8 * r;
+      if (best < 0 || slots < bslots || (slots == bslots && r > best)) { best = r; bslots = slots; }
+    }
+    P.g_rb = (int)best;
+    P.g_bpl = P.g_nbx * (int)(best / 4);
+  }
 }
 
 // kernel launchers implemented in the k_*.hip files (one per fused phase of the step)
