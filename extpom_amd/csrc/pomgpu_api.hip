@@ -950,9 +950,18 @@ static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
   P.iext = iext;
   if (iext == 1 || !t->areas_checked) { launch_check_areas(t); t->areas_checked = 1; }
   KP Q = P;
-  for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = t->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : t->alt2[n];
-  if (!launch_ext_pair(t, Q, t->alt3, store_f || iext + 1 == isplit)) return 0;
-  t->ext_parity ^= 1;                                         // two substeps, one change of buffer sets
+  // Every launch moves the current generation to the other buffer set; the loop should end in the blk2d arrays (else ext_canonical
+  // copies seven arrays back: 0.09 ms at 2048x1536).  If the launches still to come (pairs, and a last single substep of an odd
+  // rest) would leave it in alt2, ONE pair goes alt2 -> alt3 with the stale blk2d arrays as its scratch set, and the two sets
+  // swap names: 15 pairs = blk2d -> alt2 -> alt3 (now called alt2) -> blk2d -> ...
+  const int rest = isplit - iext + 1, launches = rest / 2 + (rest & 1);
+  const bool stay = t->ext_parity == 1 && !(launches & 1) && !getenv("POMGPU_EXT_TWO_SETS");
+  double *canon[POMGPU_NGEN];
+  for (int n = 0; n < POMGPU_NGEN; n++) canon[n] = P.b2 + (size_t)X2_SLOT[n] * P.n2;
+  for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = stay ? t->alt3[n] : t->ext_parity ? canon[n] : t->alt2[n];
+  if (!launch_ext_pair(t, Q, stay ? canon : t->alt3, store_f || iext + 1 == isplit)) return 0;
+  if (stay) for (int n = 0; n < POMGPU_NGEN; n++) { double *x = t->alt2[n]; t->alt2[n] = t->alt3[n]; t->alt3[n] = x; }
+  else t->ext_parity ^= 1;                                    // two substeps, one change of buffer sets
   ext_buffers(t);
   c->con.iext = iext + 1; t->con.iext = iext + 1; P.iext = iext + 1; c->P.iext = iext + 1;
   if (c->wide.on && iext + 1 == isplit) wide_flush(c);        // the tile's arrays, ghost cells included, are current again
