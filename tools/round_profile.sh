@@ -12,6 +12,9 @@ for set in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$set -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$set.log 2>&1
 done
 python3 tools/pmc_summarise.py $O > $O/pmc_summary.csv 2>&1 || true
+# profiles/traffic.json of THIS build (bench.py quotes roofline.traffic only when the build ids agree), then the line that carries it
+python3 tools/make_traffic_json.py $O/pmc_summary.csv > $O/traffic_make.log 2>&1 && cp profiles/traffic.json $O/traffic.json
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
 POM_BENCH_REHEARSE=1 timeout -k 10 400 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 > $O/rehearse2.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
 POM_BENCH_REHEARSE=1 timeout -k 10 400 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 > $O/rehearse4.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
 find $O -name "*kernel_stats.csv" | head -3
