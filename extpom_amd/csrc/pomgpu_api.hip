@@ -890,6 +890,27 @@ static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-2
 }
 // store_f: write elf, uaf, vaf on every substep (the public entry point: the caller may look at them);
 // pomgpu_advance stores them on the last substep only -- nothing reads them in between
+// Rows [1 + lo, jm - hi] of a tile as a tile of its own, same leading dimension: every blk2d array, the scratch and coefficient
+// arrays, both generations, the mask bytes and the j-indexed boundary values begin `lo` rows later.
+static KP row_window(const KP &P, int lo, int hi) {
+  KP Q = P;
+  const size_t sh = (size_t)lo * P.iml;
+  Q.b2 += sh;
+  for (int n = 0; n < POMGPU_NSCR2; n++) if (Q.s2[n]) Q.s2[n] += sh;
+  for (int n = 0; n < POMGPU_NCOEF2; n++) if (Q.c2[n]) Q.c2[n] += sh;
+  for (int n = 0; n < POMGPU_NGEN; n++) { Q.x2[n] += sh; Q.y2[n] += sh; }
+  if (Q.m8) Q.m8 += sh;
+  int s = 0;
+#define BD_(name, shape) Q.bdoff[s++] += BDW_##shape;
+#define BDW_J ((size_t)lo)
+#define BDW_I 0
+#define BDW_JK 0
+#define BDW_IK 0
+  POM_BDRY(BD_)
+#undef BD_
+  Q.jm = P.jm - lo - hi; Q.jmm1 = Q.jm - 1; Q.jml = Q.jm;
+  return Q;
+}
 static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-353
   NEED_RAW(c);
   if (c->wide.on && c->wide.pending) {                        // the substep runs on the extended tile (wide_begin)
@@ -911,6 +932,17 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
     // once per internal step (and after any upload): are art, aru, arv what initialize.f:361-367 makes of dx, dy?  Then
     // k_ext_march forms them in registers instead of reading three arrays per substep.  On the device, no host round trip.
     if (fuse_adv && (P.iext == 1 || !c->areas_checked)) { launch_check_areas(c); c->areas_checked = 1; }
+    if (c->parent && !getenv("POMGPU_WIDE_FULL")) {
+      // The extended tile of the wide-halo mode: its stale rim grows by one line per substep (see "How far stale cells spread"
+      // below), so substep n need not compute the n - 1 outermost rows of an extended side at all -- they are wrong already and
+      // nobody reads them again.  The window's own outermost row is "the row an exchange would have filled", as the extended
+      // tile's was.  (Rows only: a window in i would need a width apart from the leading dimension.)
+      const pomgpu_wide &Wd = c->parent->wide;
+      int cut = P.iext - 1 < Wd.w - 5 ? P.iext - 1 : Wd.w - 5;
+      if (cut < 0) cut = 0;
+      const int lo = Wd.oy > 0 ? cut : 0, hi = P.jm - c->parent->P.jm - Wd.oy > 0 ? cut : 0;
+      if (lo + hi > 0 && P.jm - lo - hi >= 16) Q = row_window(Q, lo, hi);
+    }
     launch_ext_step(c, Q, store_f || P.iext == P.isplit, fuse_adv);   // :211-347
     c->ext_parity ^= 1;
     ext_buffers(c);
