@@ -85,6 +85,106 @@ __global__ void k_baropg(KP P, int sum2d) {
   F3(drhoy, i, j, P.kb) = P.ramp * F3(drhoy, i, j, P.kb);
 }
 
+// The same routine with halo-lane wavefronts and the rows of a workgroup shared through LDS (k_advct_col's layout): the
+// anomaly rho-rmean of a cell is formed ONCE, by the lane that owns the cell; the western neighbour's comes from the neighbour
+// lane, the southern one from the wavefront below through a slab (the first wavefront of a workgroup also forms the row under
+// the workgroup).  Two loads per wavefront and level instead of six, the next level's in flight, one barrier per level.
+// Expressions and their order are k_baropg's.
+#ifndef BPG_ROWS
+#define BPG_ROWS 16                                         /* kbench, one context: 2 rows 1.40, 4 1.30, 8 1.24, 16 1.15 ms; one thread per column (k_baropg) 1.32 */
+#endif
+__global__ void __launch_bounds__(64 * BPG_ROWS) k_baropg_rs(KP P, int sum2d) {
+  HALO_XCD_DECODE_R(BPG_ROWS)
+  const int r = WAVE_UNIFORM((int)threadIdx.y);
+  const bool jvalid = j <= P.jml;
+  const int jc = jvalid ? j : P.jml;
+  const bool own = jvalid && lane >= 1 && lane <= 62 && i0 >= 1 && i0 <= P.iml;
+#ifdef POMGPU_EMU
+  if (!own) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
+  const int iw = i > 1 ? i - 1 : 1, js = jc > 1 ? jc - 1 : 1;
+  const bool in = own && i0 >= 2 && i0 <= P.imm1 && jc >= 2 && jc <= P.jmm1;
+  const int kbm1 = P.kbm1;
+  const double dtc = dt_(i, jc), dts = dt_(i, js);
+  const double dtw = halo_w(dtc, [&] { return dt_(iw, jc); });
+  const double sx = .25 * (dtc + dtw), sy = .25 * (dtc + dts);
+  const double mx = F2(dum, i, jc), my = F2(dvm, i, jc);
+  const double dyc = dy_(i, jc);
+  const double ex = dyc + halo_w(dyc, [&] { return dy_(iw, jc); }), ey = dx_(i, jc) + dx_(i, js);
+  const BufA brho = BUF3(A3(rho)), brm = BUF3(A3(rmean)), box = BUF3(A3(drhox)), boy = BUF3(A3(drhoy));
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
+  const unsigned osh = (r == 0) ? BOFF2(i, js) : BOFF_NONE;   // the row under the workgroup: its first wavefront's job
+  const unsigned ost = in ? oc : BOFF_NONE;
+#ifndef POMGPU_EMU
+  __shared__ double slab[2][BPG_ROWS + 1][64];
+#endif
+  struct Lev { double rho, rm, rho_s, rm_s; };
+  auto load = [&](Lev &L, int k) {
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    L.rho = bld(brho, oc, lv); L.rm = bld(brm, oc, lv);
+    L.rho_s = bld(brho, osh, lv); L.rm_s = bld(brm, osh, lv);
+  };
+  double rc0 = 0., rw0 = 0., rs0 = 0., ax = 0., ay = 0., rx = 0., ry = 0.;
+  auto step = [&](const int k, const Lev &cur, Lev &nxt) {
+    const int par = k & 1;
+    load(nxt, k + 2 <= kbm1 ? k + 2 : kbm1);                // two levels ahead: in flight during this iteration and the next
+    const double rc = cur.rho - cur.rm;
+#ifndef POMGPU_EMU
+    slab[par][r + 1][lane] = rc;
+    if (r == 0) slab[par][0][lane] = cur.rho_s - cur.rm_s;
+    __syncthreads();
+    const double rs = slab[par][r][lane];
+#else
+    (void)par;
+    const double rs = F3(rho, i, js, k) - F3(rmean, i, js, k);
+#endif
+    const double rw = halo_w(rc, [&] { return F3(rho, iw, jc, k) - F3(rmean, iw, jc, k); });
+    if (k == 1) {
+      ax = .5 * P.grav * (-F1(zz, 1)) * (dtc + dtw) * (rc - rw);                              // :859-860
+      ay = .5 * P.grav * (-F1(zz, 1)) * (dtc + dts) * (rc - rs);                              // :895-896
+    } else {
+      const double zm = F1(zz, k - 1) - F1(zz, k), zp = F1(zz, k - 1) + F1(zz, k);
+      ax = ax + P.grav * .25 * zm * (dtc + dtw) * (rc - rw + rc0 - rw0) +
+           P.grav * .25 * zp * (dtc - dtw) * (rc + rw - rc0 - rw0);                           // :867-875
+      ay = ay + P.grav * .25 * zm * (dtc + dts) * (rc - rs + rc0 - rs0) +
+           P.grav * .25 * zp * (dtc - dts) * (rc + rs - rc0 - rs0);                           // :903-911
+    }
+    const double ox = P.ramp * (sx * ax * mx * ex), oy = P.ramp * (sy * ay * my * ey);        // :883-885,931
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    bst(box, ost, lv, ox);
+    bst(boy, ost, lv, oy);
+    rx = rx + ox * F1(dz, k);
+    ry = ry + oy * F1(dz, k);
+    rc0 = rc; rw0 = rw; rs0 = rs;
+  };
+  Lev ra, rb, rc_;
+  load(ra, 1);
+  load(rb, 2 <= kbm1 ? 2 : kbm1);
+  rc_ = ra;
+  for (int k = 1; k <= kbm1; k += 3) {                        // the conditions are uniform for the whole workgroup (barrier inside)
+    step(k, ra, rc_);
+    if (k + 1 <= kbm1) step(k + 1, rb, ra);
+    if (k + 2 <= kbm1) step(k + 2, rc_, rb);
+  }
+  if (!own) return;
+  if (in) {
+    if (sum2d) { F2(drx2d, i, jc) = rx; F2(dry2d, i, jc) = ry; }
+    F3(drhox, i, jc, P.kb) = P.ramp * F3(drhox, i, jc, P.kb);                                 // :928-935, k=kb
+    F3(drhoy, i, jc, P.kb) = P.ramp * F3(drhoy, i, jc, P.kb);
+  } else if (sum2d) {                                         // rim and padding columns: whatever drhox, drhoy hold there
+    double qx = 0., qy = 0.;
+    if (i <= P.im && jc <= P.jm)
+      for (int k = 1; k <= kbm1; k++) {
+        const double dzk = F1(dz, k);
+        qx = qx + F3(drhox, i, jc, k) * dzk;
+        qy = qy + F3(drhoy, i, jc, k) * dzk;
+      }
+    F2(drx2d, i, jc) = qx;
+    F2(dry2d, i, jc) = qy;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // baropg_mcc -- solver.f:943-1159 (npg = 2): McCalpin's 4th-order pressure gradient.  Same shape as
 // k_baropg: the anomaly rho-rmean is formed on the fly, drho / rhou of the level above ride in
@@ -217,6 +317,81 @@ __global__ void k_vertvl(KP P, int mask) {
     wk = wk + F1(dz, k) * ((ce * u_(i + 1, j, k) - cw * u_(i, j, k) + cn * v_(i, j + 1, k) - cs * v_(i, j, k)) / area + det);
     F3(w, i, j, k + 1) = (mask && k + 1 <= P.kbm1) ? wk * m : wk;
   }
+}
+
+// The same routine with halo-lane wavefronts and tall workgroups (k_baropg_rs's layout): u(i+1) is the eastern neighbour lane's
+// value, v(j+1) the value of the wavefront above, through an LDS slab (the last wavefront of a workgroup also loads the row above
+// the workgroup): two loads per wavefront and level instead of four, two levels in flight; the division by the cell area
+// through its reciprocal (divi: the same quotient, bit for bit).  Expressions and their order are k_vertvl's.
+#ifndef VVL_ROWS
+#define VVL_ROWS 8                                          /* kbench, one context: 8 rows 0.830, 16 rows 0.839 ms; one thread per column (k_vertvl) 0.870 */
+#endif
+__global__ void __launch_bounds__(64 * VVL_ROWS) k_vertvl_rs(KP P, int mask) {
+  HALO_XCD_DECODE_R(VVL_ROWS)
+  const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
+  const bool jvalid = j <= P.jml;
+  const int jc = jvalid ? j : P.jml;
+  const bool own = jvalid && lane >= 1 && lane <= 62 && i0 >= 1 && i0 <= P.im && jc <= P.jm;
+#ifdef POMGPU_EMU
+  if (!own) return;
+#endif
+  const int i = i0 < 1 ? 1 : (i0 > P.iml ? P.iml : i0);
+  const int iw = i > 1 ? i - 1 : 1, ie = i < P.iml ? i + 1 : P.iml;
+  const int js = jc > 1 ? jc - 1 : 1, jn = jc < P.jml ? jc + 1 : P.jml;
+  const bool in = own && i0 >= 2 && i0 <= P.imm1 && jc >= 2 && jc <= P.jmm1;
+  const int kbm1 = P.kbm1;
+  const double m = mask ? F2(fsm, i, jc) : 1.;
+  const double dyc = dy_(i, jc), dtc = dt_(i, jc), dxc = dx_(i, jc);
+  const double dyw = halo_w(dyc, [&] { return dy_(iw, jc); }), dtw = halo_w(dtc, [&] { return dt_(iw, jc); });
+  const double dye = halo_e(dyc, [&] { return dy_(ie, jc); }), dte = halo_e(dtc, [&] { return dt_(ie, jc); });
+  const double cw = .25 * (dyc + dyw) * (dtc + dtw);
+  const double ce = .25 * (dye + dyc) * (dte + dtc);
+  const double cs = .25 * (dxc + dx_(i, js)) * (dtc + dt_(i, js));
+  const double cn = .25 * (dx_(i, jn) + dxc) * (dt_(i, jn) + dtc);
+  const InvD area = inv_of(dxc * dyc);
+  const double det = (F2(etf, i, jc) - F2(etb, i, jc)) / P.dti2;
+  const BufA bu = BUF3(A3(u)), bv = BUF3(A3(v)), bw = BUF3(A3(w));
+  const unsigned oc = BOFF2(i, jc), lvb = LVB;
+  const int jh = j0w + VVL_ROWS <= P.jml ? j0w + VVL_ROWS : P.jml;     // the row above the workgroup: its last wavefront's job
+  const unsigned onh = (r == VVL_ROWS - 1) ? BOFF2(i, jh) : BOFF_NONE;
+  const unsigned ost = in ? oc : BOFF_NONE;
+#ifndef POMGPU_EMU
+  __shared__ double slab[2][VVL_ROWS + 1][64];
+#endif
+  struct Lev { double u, v, vh; };
+  auto load = [&](Lev &L, int k) {
+    const unsigned lv = (unsigned)WAVE_UNIFORM(k - 1) * lvb;
+    L.u = bld(bu, oc, lv); L.v = bld(bv, oc, lv); L.vh = bld(bv, onh, lv);
+  };
+  double wk = 0.5 * (F2(vfluxb, i, jc) + F2(vfluxf, i, jc));                                  // :2004
+  bst(bw, ost, 0u, mask ? wk * m : wk);
+  auto step = [&](const int k, const Lev &cur, Lev &nxt) {
+    const int par = k & 1;
+    load(nxt, k + 2 <= kbm1 ? k + 2 : kbm1);                // two levels ahead
+#ifndef POMGPU_EMU
+    slab[par][r][lane] = cur.v;
+    if (r == VVL_ROWS - 1) slab[par][VVL_ROWS][lane] = cur.vh;
+    __syncthreads();
+    const double v_n = slab[par][r + 1][lane];
+#else
+    (void)par;
+    const double v_n = F3(v, i, jn, k);
+#endif
+    const double u_e = halo_e(cur.u, [&] { return F3(u, ie, jc, k); });
+    wk = wk + F1(dz, k) * (divi(ce * u_e - cw * cur.u + cn * v_n - cs * cur.v, area) + det);
+    bst(bw, ost, (unsigned)WAVE_UNIFORM(k) * lvb, (mask && k + 1 <= kbm1) ? wk * m : wk);
+  };
+  Lev ra, rb, rc;
+  load(ra, 1);
+  load(rb, 2 <= kbm1 ? 2 : kbm1);
+  rc = ra;
+  for (int k = 1; k <= kbm1; k += 3) {                        // the conditions are uniform for the whole workgroup (barrier inside)
+    step(k, ra, rc);
+    if (k + 1 <= kbm1) step(k + 1, rb, ra);
+    if (k + 2 <= kbm1) step(k + 2, rc, rb);
+  }
+  if (own && !in && mask)                                     // rim columns: the mask of bcondorl(5) alone
+    for (int k = 1; k <= kbm1; k++) F3(w, i, jc, k) = w_(i, jc, k) * m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1397,7 +1572,10 @@ static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml 
 // baropg, vertvl: four paced rows per workgroup (same-context A/B against 2 unpaced rows: -2..-3 %; 8 rows: +3 % on baropg)
 #define COLV_G(P) dim3(((P).iml + 63) / 64, ((P).jml + 3) / 4, 1)
 #define COLV_B dim3(64, 4, 1)
-void launch_baropg(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg, COLV_G(c->P), COLV_B, c->P, sum2d); }
+void launch_baropg(pomgpu_ctx *c, int sum2d) {
+  if (getenv("POMGPU_BAROPG_CELLS")) { LAUNCH(c, k_baropg, COLV_G(c->P), COLV_B, c->P, sum2d); return; }   // developer switch: one thread per column, six loads per level
+  LAUNCHN(c, "k_baropg", k_baropg_rs, grid1_halo_r(c->P, BPG_ROWS), blk_col_r(BPG_ROWS), c->P, sum2d);
+}
 void launch_baropg_mcc(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg_mcc, colgrid(c->P), colblk(), c->P, sum2d); }
 void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n) {
   const KP &P = c->P;
@@ -1419,7 +1597,10 @@ void launch_int_uvmean(pomgpu_ctx *c) {
   else if (kb <= 56) launch_int_uvmean_reg_t<56>(c);
   else launch_int_uvmean_reg_t<64>(c);
 }
-void launch_vertvl(pomgpu_ctx *c, int mask) { LAUNCH(c, k_vertvl, COLV_G(c->P), COLV_B, c->P, mask); }
+void launch_vertvl(pomgpu_ctx *c, int mask) {
+  if (getenv("POMGPU_VERTVL_CELLS")) { LAUNCH(c, k_vertvl, COLV_G(c->P), COLV_B, c->P, mask); return; }   // developer switch: one thread per column, four loads per level
+  LAUNCHN(c, "k_vertvl", k_vertvl_rs, grid1_halo_r(c->P, VVL_ROWS), blk_col_r(VVL_ROWS), c->P, mask);
+}
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
 void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
   if (!lines_only) { LAUNCH(c, k_profq_prod, colgrid(c->P), colblk(), c->P, rho_rt); return; }
