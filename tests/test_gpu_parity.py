@@ -332,16 +332,18 @@ def test_config2_seamount_256x256x30_matches_oracle():
 
 
 @pytest.mark.parametrize("switches", [("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
-                                       "POMGPU_REALVERTVL_CELLS"), ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"),
+                                       "POMGPU_REALVERTVL_CELLS", "POMGPU_BAROPG_CELLS", "POMGPU_VERTVL_CELLS"), ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"),
                                       ("POMGPU_EXT_LOOP",), ("POMGPU_RHO_ROUNDTRIP", "POMGPU_TAU_ARRAYS", "POMGPU_IO_SYNC"),
-                                      ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH"), ("POMGPU_PROFQ_ROWS2", "POMGPU_PROFQ_NOPACE", "POMGPU_EXT_NOMARCH")])
+                                      ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH"), ("POMGPU_PROFQ_ROWS2", "POMGPU_PROFQ_NOPACE", "POMGPU_EXT_NOMARCH", "POMGPU_NO_LIN", "POMGPU_EXT_TWO_SETS")])
 def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
     multi-tile runs, selected through the library's developer switches, on an even and an odd grid; second set: the
     external substep with advave and the rim cells as kernels of their own; third: all external substeps in one launch with
     a grid-wide barrier (k_ext_loop, opt-in); fourth: rho's round trip as a kernel of its own, taurstr read from its arrays;
     fifth / sixth: k_profq's 8-row paced workgroups (the large-grid shape) on grids whose last workgroup row is ragged and the
-    strip order of the row-sharing column kernels (width 1), and k_profq's 2-row shape without the pacing barrier"""
+    strip order of the row-sharing column kernels (width 1), and k_profq's 2-row shape without the pacing barrier, the banded XCD
+    order of the row-sharing kernels on these ragged grids (the default there is the balanced one); the first set also takes baropg and
+    vertvl back to one thread per column"""
     OracleTile, oracle_finish_initial = _oracle()
     for v in switches:
         monkeypatch.setenv(v, "1")

@@ -193,16 +193,18 @@ def test_kb_above_the_register_kernels_bound():
 
 
 FALLBACK_ENV = ("POMGPU_THOMAS_SCRATCH", "POMGPU_NO_PAIR", "POMGPU_EXT_SPLIT", "POMGPU_ADVQ_SINGLE", "POMGPU_ADVT2_SINGLE",
-                "POMGPU_REALVERTVL_CELLS")
+                "POMGPU_REALVERTVL_CELLS", "POMGPU_BAROPG_CELLS", "POMGPU_VERTVL_CELLS")
 
 
-@pytest.mark.parametrize("switches", [FALLBACK_ENV, ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"), ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH")])
+@pytest.mark.parametrize("switches", [FALLBACK_ENV, ("POMGPU_ADVAVE_SEPARATE", "POMGPU_EXT_RIM_KERNEL"), ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH"),
+                                      ("POMGPU_PROFQ_ROWS8", "POMGPU_COL_STRIP", "POMGPU_EXT_MARCH", "POMGPU_NO_LIN")])
 def test_general_kernels_behind_the_fast_paths(monkeypatch, switches):
     """the scratch-vector / one-column-per-lane / split kernels that serve kb > 64, odd im_local and
     multi-tile runs stay bit-identical too (selected here through the library's developer switches); second set:
     the external substep with advave and the rim cells as kernels of their own (ispadv != 1, mode = 2 take that path); third:
     the launch geometry of wide tiles -- k_profq's 8-row workgroups and the strip order of the row-sharing kernels (strips 3
-    workgroups wide on a row of 4: a full and a ragged strip) -- every workgroup decoded exactly once"""
+    workgroups wide on a row of 4: a full and a ragged strip) -- every workgroup decoded exactly once, in the balanced XCD order
+    this ragged grid takes by default and (fourth) in the banded one"""
     for v in switches:
         monkeypatch.setenv(v, "3" if v == "POMGPU_COL_STRIP" else "1")
     im, jm = (200, 30) if "POMGPU_COL_STRIP" in switches else (65, 49)
