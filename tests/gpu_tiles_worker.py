@@ -34,7 +34,7 @@ def worker(rank, world, split, port, out, nml):
     dev = rank if mode == "rccl" else 0
     torch.cuda.set_device(dev)
     from extpom_amd.model import PomGpu
-    nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2)}[split]
+    nx, ny = {"x": (2, 1), "y": (1, 2), "xy": (2, 2), "y4": (1, 4)}[split]
     iml, jml = decomp.local_size(IM, JM, nx, ny)
     tile = decomp.make_tile(rank, IM, JM, iml, jml, n_proc=world)
     st = make_case("island", IM, JM, KB, tile=tile, dte=6.0, isplit=ISPLIT, **nml)
@@ -88,7 +88,7 @@ def main(split, nml, exchange="hook"):
     from oracle.pyoracle import OracleTile, oracle_finish_initial
     out = tempfile.mkdtemp()
     port = 29700 + (os.getpid() % 200)
-    world = 4 if split == "xy" else 2
+    world = 4 if split in ("xy", "y4") else 2
     mp.spawn(worker, args=(world, split, port, out, dict(nml, _exchange=exchange)), nprocs=world, join=True)
     g = make_case("island", IM, JM, KB, dte=6.0, isplit=ISPLIT, **nml)
     oracle_finish_initial(g)

@@ -52,6 +52,18 @@ def test_wide_halo_mode_with_two_substeps_per_pass(args):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [["y4", "wide"], ["y4", "transport"]])
+def test_whole_row_tiles_the_default_split(args):
+    """1 x 4 whole-row tiles (decomp.choose_tile_grid's choice, what bench.py --gpus N runs): the two inner tiles are extended on both
+    sides in the wide-halo mode (the shrinking row window of their external substeps, the balanced XCD order of ragged tiles), have two
+    neighbours and no corner messages: owned cells equal the single-tile oracle bit for bit"""
+    env = dict(os.environ, POM_TILES_GRID="72x150x12")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_worker.py")] + args, capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "TILES-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["x", "rccl"], ["xy", "rccl"], ["y", "npg2", "rccl"]])
 def test_rccl_between_distinct_ranks_one_gpu_each(args):
     """bench.py's N > 1 path as a parity test: rank r on GPU r, the library's RCCL transport (main and side stream, both
