@@ -258,12 +258,16 @@ def test_library_transport_serves_every_exchange_point(nx, ny, nml):
 WIDE_GRID, WIDE_ISPLIT = (67, 59), 7        # w = 7 + 4 = 11 extra cells; 2x2 tiles of ~35 x 31
 
 
-@pytest.mark.parametrize("nx,ny,case,nml", [(2, 2, "island", {}), (2, 1, "seamount", {}), (1, 2, "seamount", dict(npg=2)), (3, 2, "island", dict(nadv=1))])
+@pytest.mark.parametrize("nx,ny,case,nml", [(2, 2, "island", {}), (2, 1, "seamount", {}), (1, 2, "seamount", dict(npg=2)), (3, 2, "island", dict(nadv=1)),
+                                            (1, 3, "seamount", {})])
 def test_wide_halo_external_mode(nx, ny, case, nml):
     """pomgpu_set_wide_external: ONE wide exchange per internal step instead of six narrow ones per external substep;
-    owned cells equal the single-tile oracle bit for bit, with a fraction of the message rounds"""
+    owned cells equal the single-tile oracle bit for bit, with a fraction of the message rounds.  (1 x 3: whole-row tiles, the
+    middle one extended on both sides -- the rows its substeps skip as they go stale, row_window in pomgpu_api.hip, on either side)"""
     if nx == 3:
         grid = (97, 59)
+    elif ny == 3:
+        grid = (41, 101)
     else:
         grid = WIDE_GRID
     narrow = run_tiles(nx, ny, nml, library_exchange=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
