@@ -5,11 +5,17 @@ lateral_viscosity, mode_interaction, isplit external substeps, mode_internal, ch
     python bench.py --gpus N --steps K --warmup W [--workload basin2048|seamount256|basin1024|...]
 
 N=1 runs in this process.  N>1: one rank per GPU, the global grid split into N tiles (strong scaling: the
-global grid is fixed) -- either started by the caller under torch.distributed.run (WORLD_SIZE set), or, when
-`python bench.py --gpus N` is called plainly, by this script itself: the parent starts
-`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process before it
-touches the GPU, relays the child's output and exits with its code (reference launch shape: pom.sh:1
-`mpiexec -n 8`, parallel_mpi.f:6-20).  Rank 0 prints ONE JSON line.  `value` = im_global*jm_global*kb*K / max-over-ranks wall time of the K timed
+global grid is fixed) -- started by the caller under torch.distributed.run (WORLD_SIZE set), or, when
+`python bench.py --gpus N` is called plainly, by this script itself (`python -m torch.distributed.run --nproc-per-node N
+bench.py <same arguments>` as a CHILD process; reference launch shape: pom.sh:1 `mpiexec -n 8`, parallel_mpi.f:6-20).
+Either way a rank's process is only a SUPERVISOR: it never touches the GPU.  It runs the measurement as a sequence of
+PASSES, each a fresh child process per rank with a rendezvous of its own and deadlines of its own:
+  1. the primary tile grid, every message round on the kernels' stream (one stream, one communicator: POMGPU_NO_OVERLAP=1);
+  2. the primary tile grid with the second stream and the second (split) communicator -- north_star's overlapped halo exchange;
+  3. the alternate tile grid (2x4 beside 1x8, parallel_mpi.f:54-65) under whichever of 1 / 2 was faster.
+A pass that hangs or dies is a child that exits non-zero: its supervisors end it, say in which phase it stopped, and the
+next pass starts from clean processes; the line's `value` is the fastest completed pass on the primary grid, `passes`
+lists them all.  Rank 0 prints ONE JSON line.  `value` = im_global*jm_global*kb*K / max-over-ranks wall time of the K timed
 steps, state resident in HBM before the timed region starts.
 
 Extra objects on the same line:
@@ -124,18 +130,21 @@ def _sample_dims(workload):
     return case, max(65, im // 8), max(49, jm // 8), kb
 
 
-def _cpu_sample(workload, seconds=12.0, reference=False):
-    """ONE host core, bounded sample: same case/namelist/kb on a 1/8 x 1/8 horizontal grid.  reference=False: the
-    plain-C oracle; True: the flang-built UNMODIFIED reference (oracle/_ref, built where /root/reference exists and
-    shipped prebuilt), driven subroutine by subroutine in the order of its own `advance` (oracle/refharness.py)."""
+def _cpu_run(workload, full, seconds=12.0, reference=False):
+    """ONE host core.  full=True: the bench's OWN grid and state (identical inputs: same case, namelist, im x jm x kb), internal
+    steps 1-3, of which 2 and 3 are timed (step 1 skips the 3-D body, advance.f:362); full=False: a bounded sample on a
+    1/8 x 1/8 horizontal grid for `seconds`.  reference=False: the plain-C oracle; True: the flang build of the reference's own
+    sources (oracle/_ref, present only where /root/reference was at build time), driven in the order of its own `advance`."""
     from extpom_amd.cases import make_case
     from oracle.pyoracle import OracleTile, oracle_finish_initial
-    case, sim, sjm, kb = _sample_dims(workload)
-    st = make_case(case, sim, sjm, kb, **NML)
+    case, im, jm, kb, _ = WORKLOADS[workload]
+    if not full:
+        case, im, jm, kb = _sample_dims(workload)
+    st = make_case(case, im, jm, kb, **NML)
     oracle_finish_initial(st)
     if reference:
         from oracle.refharness import RefLib
-        lib = RefLib(sim, sjm, kb)
+        lib = RefLib(im, jm, kb)
         lib.put(st)
         it = [0]
 
@@ -146,14 +155,16 @@ def _cpu_sample(workload, seconds=12.0, reference=False):
     else:
         ot = OracleTile(st)
         step = lambda: ot.run(1)
-    step(); step()
+    step()
+    if not full:
+        step()
     t0 = time.perf_counter()
     n = 0
-    while n < 4 or (time.perf_counter() - t0 < seconds and n < 400):
+    while (n < 2) if full else (n < 4 or (time.perf_counter() - t0 < seconds and n < 400)):
         step()
         n += 1
     dt = time.perf_counter() - t0
-    return sim * sjm * kb * n / dt, f"{case} {sim}x{sjm}x{kb}", n, dt
+    return im * jm * kb * n / dt, f"{case} {im}x{jm}x{kb}", n, dt
 
 
 def _reference_sample(workload):
@@ -163,7 +174,7 @@ def _reference_sample(workload):
     box = {}
 
     def work():
-        box["r"] = _cpu_sample(workload, reference=True)
+        box["r"] = _cpu_run(workload, False, reference=True)
     threading.stack_size(1 << 30)
     th = threading.Thread(target=work)
     th.start()
@@ -171,48 +182,119 @@ def _reference_sample(workload):
     return box["r"]
 
 
-def cpu_reference(workload):
-    """the reference itself on one core, if its build for the sample's size travelled with the repo; in a child
-    process, so that nothing it does can take the bench down"""
+def _child_json(extra, timeout):
     import subprocess
-    from oracle.refharness import have_ref
-    case, sim, sjm, kb = _sample_dims(workload)
-    if not have_ref(sim, sjm, kb):
-        return None
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sample", "--reference", "--workload", workload],
-                       capture_output=True, text=True, timeout=240)
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "reference",
-            "sample": f"{d['what']}, {d['n']} internal steps of the unmodified reference (solver.f advance.f bounds_forcing.f, "
-                      f"AMD flang -O2), {d['seconds']:.1f} s"}
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"{' '.join(extra)}: rc {r.returncode}: {r.stderr.strip()[-300:]}")
+    return json.loads(lines[-1])
 
 
 def cpu_baseline(workload):
-    v, what, n, dt = _cpu_sample(workload)
-    return {"value": v, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{what}, {n} internal steps of the plain-C oracle (gcc -O2, bit-identical to the flang-built reference), {dt:.1f} s"}
+    """THE cpu_baseline of the line: the plain-C oracle (kind "port": the CPU restatement that is bit-identical to the flang
+    build of the reference, tests/test_oracle_vs_reference.py) on the bench's own grid and state, one core, in a child process
+    (a second copy of the 50 GB state: freed when the child ends)."""
+    d = _child_json(["--cpu-sample", "--full-grid", "--workload", workload], 900)
+    return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{d['what']} = the bench's own grid and initial state (identical inputs), internal steps 2-3 of the plain-C oracle "
+                      f"(gcc -O2, one core; step 1 untimed: it skips the 3-D body, advance.f:362), {d['seconds']:.1f} s"}
+
+
+def cpu_baseline_sample(workload, reference):
+    """labelled extras: the 1/8 x 1/8 sample (a 64 times smaller working set: friendlier to the caches than the bench grid),
+    with the oracle and -- where its build is present -- with the reference's own flang-built sources"""
+    from oracle.refharness import have_ref
+    case, sim, sjm, kb = _sample_dims(workload)
+    if reference and not have_ref(sim, sjm, kb):
+        return None
+    d = _child_json(["--cpu-sample", "--workload", workload] + (["--reference"] if reference else []), 240)
+    who = ("the reference's own sources (solver.f advance.f bounds_forcing.f, AMD flang -O2; linked with input hooks for the PnetCDF "
+           "readers this image lacks, oracle/ref_traps.c)") if reference else "the plain-C oracle (gcc -O2)"
+    return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "reference" if reference else "port",
+            "sample": f"SAMPLE {d['what']} (1/64 of the bench grid's area), {d['n']} internal steps of {who}, {d['seconds']:.1f} s"}
 
 
 def cpu_baseline_all_cores(workload):
-    """the same sample on every host core at once (one independent copy per core, as the reference's MPI ranks
-    would each hold a tile): the host's aggregate rate, memory-bandwidth contention included.  The copies are plain
-    child processes of this script (`--cpu-sample`), each bounded by a timeout."""
+    """every host core of the box's CPU share at once, as the reference would use them: the bench's own grid split into one
+    whole-row tile per core by the reference's own decomposition arithmetic (extpom_amd/decomp.py = distribute_mpi,
+    parallel_mpi.f:34-122), every exchange2d/3d_mpi a real message between the ranks (gloo).  The ranks are child processes
+    of this script (`--cpu-tiles-worker`)."""
+    import socket
     import subprocess
+    case, im, jm, kb, _ = WORKLOADS[workload]
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))        # a 1-GPU box's CPU share
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-sample", "--workload", workload],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
-    res = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=180)
-            res.append(json.loads(out.strip().splitlines()[-1]))
-        except Exception:                                          # noqa: BLE001 -- a lost copy only lowers the sum
-            p.kill()
-    if not res:
+    while cores > 1 and (jm - 2) // cores < 8:
+        cores -= 1
+    if cores < 2:
         return None
-    return {"value": sum(r["value"] for r in res), "unit": "cell-updates/s", "cores": len(res), "kind": "port",
-            "sample": f"{len(res)} concurrent copies of {res[0]['what']} (one process per core), "
-                      f"{min(r['n'] for r in res)}-{max(r['n'] for r in res)} internal steps each"}
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(cores):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(cores), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   POM_TILE_GRID=f"1x{cores}")
+        for k in list(env):
+            if k.startswith("TORCHELASTIC_"):
+                env.pop(k)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-tiles-worker", "--workload", workload],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    out0 = None
+    ok = True
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=600)
+            ok = ok and p.returncode == 0
+            if r == 0:
+                out0 = out
+        except Exception:                                          # noqa: BLE001
+            p.kill()
+            ok = False
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if not ok or not lines:
+        return None
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{d['what']} split into 1x{cores} whole-row tiles (one process per core, the reference's distribute_mpi arithmetic, "
+                      f"{d['rounds_per_step']:.0f} halo exchanges per step as gloo messages), internal steps 2-{1 + d['n']} of the plain-C oracle, {d['seconds']:.1f} s"}
+
+
+def _cpu_tiles_worker(workload):
+    """one rank of cpu_baseline_all_cores"""
+    import torch.distributed as dist
+    from extpom_amd import dist as pdist
+    from extpom_amd.cases import finish_initial
+    from extpom_amd.halo import Halo
+    from oracle.pyoracle import OracleTile
+    import torch
+    torch.set_num_threads(1)
+    rank, world, _ = pdist.init("gloo")
+    case, im, jm, kb, _ = WORKLOADS[workload]
+    tile = pdist.tile_for_rank(rank, world, im, jm)
+    st = build_state(workload, tile)
+    halo = Halo(tile)
+    ot = OracleTile(st, exch2d=halo.numpy_hook2d(), exch3d=halo.numpy_hook3d(), order=halo.numpy_order_hook())
+    finish_initial(st, lambda s, a, b, c: ot.call("dens", ot.a3(a), ot.a3(b), ot.a3(c)),
+                   lambda s: ot.call("baropg_mcc" if int(s.npg) == 2 else "baropg"))
+    ot.run(1)
+    dist.barrier()
+    c0 = halo.count
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        ot.run(1)
+        n += 1
+        flag = torch.tensor([1.0 if time.perf_counter() - t0 < 12.0 else 0.0])
+        dist.broadcast(flag, 0)                                  # rank 0's clock decides for everybody whether another step follows
+        if n >= 6 or (n >= 2 and flag.item() == 0.0):
+            break
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"value": im * jm * kb * n / dt, "what": f"{case} {im}x{jm}x{kb}", "n": n, "seconds": dt,
+                          "rounds_per_step": (halo.count - c0) / n}))
+    dist.destroy_process_group()
 
 
 def side_config(workload, device, stream, steps=40, warmup=5):
@@ -235,8 +317,8 @@ def side_config(workload, device, stream, steps=40, warmup=5):
 
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (one process
-    per GPU, rendezvous on 127.0.0.1), pass its output through and return its exit code.  The parent never initialises
+    """`python bench.py --gpus N` without a launcher: start the N rank supervisors as a child torch.distributed.run (one
+    per GPU, rendezvous on 127.0.0.1), pass its output through and return its exit code.  This process never initialises
     the GPU, and nothing is re-executed in place."""
     import socket
     import subprocess
@@ -265,36 +347,267 @@ def launch_ranks(n):
     return child.wait()
 
 
+# ---- tile grids ----------------------------------------------------------------------------------------------------
+def tile_grids(workload, n, asked=None):
+    """(primary, alternate) as "AxB" strings (nproc_x x nproc_y, parallel_mpi.f:54-65).  Primary: what --tiles asks for; else
+    BASELINE's own words where it names a decomposition (configs[2]: "1024x1024x40 ... 2x4 tile decomposition on 8 GPUs"); else
+    decomp.choose_tile_grid (whole rows, 1 x N: measured 3-5 % faster per tile).  Alternate: the other
+    of {whole rows, most square}, so that a scaling line for configs[2] / [3] always carries 2x4 beside 1x8."""
+    from extpom_amd import decomp
+    case, im, jm, kb, _ = WORKLOADS[workload]
+
+    def valid(nx, ny):
+        iml, jml = decomp.local_size(im, jm, nx, ny)
+        return nx * ny == n and decomp.tile_grid(im, jm, iml, jml) == (nx, ny)
+
+    rows = (1, n) if valid(1, n) else None
+    square = None
+    for nx in range(1, n + 1):
+        if n % nx == 0 and valid(nx, n // nx) and nx <= n // nx and (nx, n // nx) != (1, n):
+            square = (nx, n // nx)                              # the most square one with nx <= ny: 2x4 of 8, 2x2 of 4
+    if asked:
+        nx, ny = (int(v) for v in asked.lower().split("x"))
+        if not valid(nx, ny):
+            raise SystemExit(f"bench: --tiles {asked} does not split {im}x{jm} into {n} tiles")
+        prim = (nx, ny)
+    elif workload == "basin1024" and n == 8 and valid(2, 4):
+        prim = (2, 4)
+    else:
+        prim = decomp.choose_tile_grid(n, im, jm)
+    alt = rows if prim != rows else square
+    if alt == prim:
+        alt = None
+    f = lambda g: f"{g[0]}x{g[1]}" if g else None
+    return f(prim), f(alt)
+
+
+# ---- the rank supervisor (N > 1) -------------------------------------------------------------------------------------------
+def supervise(args):
+    """One per rank, started by torch.distributed.run.  Touches no GPU.  Runs the passes (module docstring) as child processes
+    and -- on rank 0 -- merges their lines into the ONE line of the contract."""
+    import datetime
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))   # CPU only: the supervisors' own channel
+    store = dist.distributed_c10d._get_default_store()
+    prim, alt = tile_grids(args.workload, world, args.tiles)
+    plan = [dict(tiles=prim, overlap=False), dict(tiles=prim, overlap=True)]
+    if alt and not args.no_alternate:
+        plan.append(dict(tiles=alt, overlap=None))              # None: whichever of the first two was faster
+    if args.only_pass is not None:
+        plan = [plan[args.only_pass]]
+    results = []
+    for k, ps in enumerate(plan):
+        ps["index"] = k
+        if ps["overlap"] is None:
+            done = [r for r in results if r["ok"]]
+            ps["overlap"] = bool(done and min(done, key=lambda r: r["ms_per_step"])["overlap"])
+        box = [None]
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                box[0] = (sk.getsockname()[1], tempfile.mkdtemp(prefix="pombench_"))
+        dist.broadcast_object_list(box, src=0)
+        port, tmpd = box[0]
+        env = dict(os.environ)
+        for name in list(env):
+            if name.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC", "GROUP_RANK", "ROLE_")):
+                env.pop(name)                                   # the child's rendezvous is its own (rank 0 of the pass hosts the store)
+        env.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   POM_TILE_GRID=ps["tiles"], POM_BENCH_PHASE_FILE=os.path.join(tmpd, f"phase{rank}"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if ps["overlap"]:
+            env.pop("POMGPU_NO_OVERLAP", None)
+        else:
+            env["POMGPU_NO_OVERLAP"] = "1"
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--rank-pass", json.dumps(ps)]
+
+        def die_with_parent():                                  # an orphaned pass must not outlive its supervisor
+            try:
+                import ctypes
+                ctypes.CDLL("libc.so.6").prctl(1, signal.SIGKILL)   # PR_SET_PDEATHSIG
+            except Exception:                                   # noqa: BLE001
+                pass
+        t_start = time.perf_counter()
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, preexec_fn=die_with_parent)
+        lines = []
+        rd = threading.Thread(target=lambda: lines.extend(child.stdout), daemon=True)
+        rd.start()
+        failkey = f"pass{k}_failed"
+        limit = float(os.environ.get("POM_BENCH_PASS_LIMIT", 420.0 + 4.0 * (args.steps + args.warmup)))
+        why = None
+        while True:
+            rc = child.poll()
+            if rc is not None:
+                if rc != 0:
+                    store.add(failkey, 1)
+                    why = f"exit code {rc}"
+                break
+            if store.add(failkey, 0) > 0:                       # another rank's child failed: ours can only wait for it for ever
+                why = "ended because another rank's process failed"
+            elif time.perf_counter() - t_start > limit:
+                store.add(failkey, 1)
+                why = f"no result within {limit:.0f} s"
+            if why:
+                child.kill()                                    # exactly the process this supervisor started
+                child.wait()
+                break
+            time.sleep(0.25)
+        rd.join(timeout=5)
+        phase = None
+        try:
+            phase = open(env["POM_BENCH_PHASE_FILE"]).read().strip()
+        except OSError:
+            pass
+        mine = {"rank": rank, "rc": child.returncode, "why": why, "phase": phase}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        line = None
+        for l in lines:
+            t = l.strip()
+            if t.startswith("{") and t.endswith("}"):
+                line = json.loads(t)
+            elif t:
+                print(t, file=sys.stderr)
+        ok = all(e["rc"] == 0 for e in everyone) and (rank != 0 or line is not None)
+        okbox = [ok]
+        dist.broadcast_object_list(okbox, src=0)
+        ok = okbox[0]
+        res = {"tiles": ps["tiles"], "overlap": ps["overlap"], "ok": ok, "wall_s": round(time.perf_counter() - t_start, 1)}
+        if ok and rank == 0:
+            res.update(ms_per_step=line["ms_per_step"], value=line["value"], line=line)
+        if not ok:
+            whys = [e["why"] for e in everyone if e["why"]]
+            first = ([w for w in whys if w.startswith("exit code")] or [w for w in whys if w.startswith("no result")] or whys or ["unknown"])[0]
+            res["failed"] = {"ranks": [e["rank"] for e in everyone if e["rc"] != 0], "first": first, "why_by_rank": {e["rank"]: e["why"] for e in everyone}, "phase_by_rank": {e["rank"]: e["phase"] for e in everyone}}
+            if rank == 0:
+                print(f"bench: pass {k} (tiles {ps['tiles']}, overlap {'on' if ps['overlap'] else 'off'}) did not complete: {res['failed']}", file=sys.stderr, flush=True)
+        if ok and rank != 0:
+            res.update(ms_per_step=0.0, value=0.0)
+        results.append(res)
+        msbox = [res.get("ms_per_step")]
+        dist.broadcast_object_list(msbox, src=0)                # every supervisor plans the next pass from the same numbers
+        res["ms_per_step"] = msbox[0]
+    code = 0
+    if rank == 0:
+        good = [r for r in results if r["ok"]]
+        first = [r for r in good if r["tiles"] == prim] or good
+        if not first:
+            print("bench: no pass completed -- no measurement", file=sys.stderr, flush=True)
+            code = 6
+        else:
+            best = min(first, key=lambda r: r["ms_per_step"])
+            out = best["line"]
+            out["config"]["tiles_primary"] = prim
+            out["config"]["tiles_note"] = ("primary grid: " + ("--tiles" if args.tiles else "BASELINE configs[2] names 2x4" if (args.workload == "basin1024" and world == 8 and prim == "2x4")
+                                           else "whole rows (1xN), the faster split per tile: DESIGN.md section 7") + "; `passes` carries the alternate grid beside it")
+            keep = ("ms_per_step", "value", "device_ms_per_step", "kernel_ms_sum_rank0", "message_rounds_ms_rank0", "message_rounds_side_stream_ms_rank0")
+            out["passes"] = []
+            for r in results:
+                e = {"tiles": r["tiles"], "overlap": r["overlap"], "ok": r["ok"], "wall_s": r["wall_s"]}
+                if r["ok"]:
+                    ln = r["line"]
+                    e.update({q: ln.get(q) for q in keep})
+                    e.update(rccl_nranks=ln["config"].get("rccl_nranks"), message_rounds_per_step=ln["config"].get("message_rounds_per_step"),
+                             message_rounds_per_step_on_side_stream=ln["config"].get("message_rounds_per_step_on_side_stream"), tile=ln["config"].get("tile"),
+                             exchange=ln["config"].get("exchange"), primary=(r is best))
+                else:
+                    e["failed"] = r["failed"]
+                out["passes"].append(e)
+            print(json.dumps(out), flush=True)
+    cbox = [code]
+    dist.broadcast_object_list(cbox, src=0)                     # every supervisor leaves with rank 0's verdict
+    dist.barrier()
+    dist.destroy_process_group()
+    return cbox[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("POM_BENCH_WORKLOAD", "basin2048"), choices=sorted(WORKLOADS))
+    ap.add_argument("--tiles", default=None, help="N > 1: the primary tile grid AxB = nproc_x x nproc_y (default: whole rows 1xN; 2x4 for basin1024 on 8 "
+                                                  "GPUs, as BASELINE configs[2] names it); the alternate grid is measured beside it")
+    ap.add_argument("--no-alternate", action="store_true", help="N > 1: skip the pass on the alternate tile grid")
+    ap.add_argument("--only-pass", type=int, default=None, help="N > 1, developer: run only pass 0 (overlap off), 1 (overlap on) or 2 (alternate grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side-config", action="store_true",
                     help="N=1: also time BASELINE configs[1] (seamount 256x256x30) in the same run; off by default so that a profile "
                          "of the default command holds the headline workload's kernels only")
     ap.add_argument("--reference", action="store_true", help="internal: with --cpu-sample, time oracle/_ref instead of the oracle")
-    ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle sample and print it (no GPU)")
+    ap.add_argument("--full-grid", action="store_true", help="internal: with --cpu-sample, the bench's own grid instead of the 1/8 x 1/8 sample")
+    ap.add_argument("--cpu-sample", action="store_true", help="internal: run the one-core oracle leg and print it (no GPU)")
+    ap.add_argument("--cpu-tiles-worker", action="store_true", help="internal: one rank of the all-cores oracle leg (no GPU)")
+    ap.add_argument("--rank-pass", default=None, help="internal: this process is one rank of one pass (started by its supervisor)")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with events in the timed region")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="f32: BASELINE configs[4]'s STUDY variant (libpomgpu_f32.so: 3-D arrays stored as fp32, arithmetic and the external "
-                         "mode fp64; one GPU).  Not a parity path (DESIGN.md section 8) and never the headline: the line says so in `dtype`")
+                         "mode fp64).  Not a parity path (DESIGN.md section 8) and never the headline: the line says so in `dtype`")
     args = ap.parse_args()
     if args.cpu_sample:
-        v, what, n, dt = _reference_sample(args.workload) if args.reference else _cpu_sample(args.workload)
+        v, what, n, dt = _reference_sample(args.workload) if args.reference else _cpu_run(args.workload, args.full_grid)
         print(json.dumps({"value": v, "what": what, "n": n, "seconds": dt}))
+        return
+    if args.cpu_tiles_worker:
+        _cpu_tiles_worker(args.workload)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))                      # nothing in this process has touched the GPU
+    if args.gpus > 1 and args.rank_pass is None:
+        sys.exit(supervise(args))                              # ... nor does a rank's supervisor
+    measure(args)
 
+
+def _selftest_rank(args, this_pass, plan):
+    """POM_BENCH_SELFTEST='{"hang": [pass, rank], "fail": [pass, rank]}' (tests/test_host_logic.py, no GPU): a stand-in for one
+    rank of one pass that joins its pass's rendezvous and then completes, hangs or dies as told -- what the supervisors make of
+    it is what is tested.  Its line says SELFTEST in `metric`: it can never pass for a measurement."""
+    import torch
+    from extpom_amd import dist as pdist
+    rank, world, _ = pdist.init("gloo")
+    k = this_pass["index"]
+    pf = os.environ.get("POM_BENCH_PHASE_FILE")
+    if pf:
+        open(pf, "w").write("connect")
+    if plan.get("fail") == [k, rank]:
+        sys.exit(9)
+    if plan.get("hang") == [k, rank]:
+        time.sleep(3600)
+    torch.distributed.barrier()
+    if rank == 0:
+        ms = 10.0 + k - (3.0 if this_pass["overlap"] else 0.0)
+        print(json.dumps({"metric": "SELFTEST -- not a measurement", "value": 1.0 / ms, "ms_per_step": ms, "n_gpus": world, "steps": args.steps,
+                          "config": {"tiles": os.environ.get("POM_TILE_GRID"), "overlap": this_pass["overlap"], "rccl_nranks": 0,
+                                     "no_overlap_env": os.environ.get("POMGPU_NO_OVERLAP")}}), flush=True)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def measure(args):
+    """the measuring process: N = 1, or one rank of one pass"""
+    this_pass = json.loads(args.rank_pass) if args.rank_pass else None
+    if this_pass is not None and os.environ.get("POM_BENCH_SELFTEST"):
+        return _selftest_rank(args, this_pass, json.loads(os.environ["POM_BENCH_SELFTEST"]))
     import torch
     from extpom_amd import decomp, dist as pdist
     # POM_BENCH_REHEARSE=1: developer rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on GPU 0,
     # gloo with host-staged halos instead of RCCL (RCCL refuses two ranks on one device).  Not a measurement.
     rehearse = os.environ.get("POM_BENCH_REHEARSE") == "1"
-    rank, world, local = pdist.init("gloo" if rehearse else None)
+    # the ranks' CONTROL plane (barriers, the clock's maximum, the RCCL unique id) is a gloo group on the CPU: the only RCCL
+    # communicators of the process are the library's own (data path), so no two communicators ever meet on the GPU by accident
+    rank, world, local = pdist.init("gloo")
     if rehearse:
         local = 0
     if world != args.gpus:
@@ -316,17 +629,17 @@ def main():
         torch.cuda.set_stream(ts)
         stream = ts.cuda_stream
     f32 = args.storage == "f32"
-    if f32 and world > 1:
-        print("bench: --storage f32 is a one-GPU study (the fp32-storage variant has no tile exchange)", file=sys.stderr)
-        sys.exit(2)
     from extpom_amd import lib as _L
     g = gpu_initialise(st, local, stream, _L.LIBPATH_F32 if f32 else None)
     build_id = g.L.pomgpu_build_id().decode()
     exchange = "none"
+    rccl_nranks = 0
     # N > 1: a rank that is lost, or a message round whose partner never posts, would leave the others waiting inside
     # RCCL for ever.  Every phase -- connecting, the first steps (RCCL sets its channels up lazily), the timed steps --
-    # gets a deadline; a rank that misses one says where it was and leaves with a non-zero code, which ends the job.
+    # gets a deadline; a rank that misses one says where it was and leaves with a non-zero code, which ends the pass
+    # (its supervisor tells the other ranks' supervisors, bench.supervise).
     phase = ["start", None]
+    phase_file = os.environ.get("POM_BENCH_PHASE_FILE")
 
     def deadline(name, seconds):
         import threading
@@ -334,6 +647,12 @@ def main():
             phase[1].cancel()
             phase[1] = None
         phase[0] = name
+        if phase_file:
+            try:
+                with open(phase_file, "w") as f:
+                    f.write(name)
+            except OSError:
+                pass
         if world > 1 and seconds:
             def expired():
                 print(f"bench[{rank}]: '{name}' did not complete within {seconds:.0f} s -- giving up", file=sys.stderr, flush=True)
@@ -342,7 +661,7 @@ def main():
             phase[1].daemon = True
             phase[1].start()
 
-    deadline("connect", 300.0)
+    deadline("connect", 180.0)
     if world > 1:
         # The library serves every exchange point itself: pack -> one grouped ncclSend/ncclRecv round (RCCL over
         # xGMI, enqueued on the kernels' stream by the library, no Python in the loop) -> unpack; and the 2-D
@@ -354,7 +673,8 @@ def main():
             exchange = "library exchange, host-staged mover (rehearsal)"
         else:
             if H.connect_rccl(g, tile, rank, world):
-                exchange = "library exchange, native RCCL send/recv on the kernels' stream (+ a second stream and communicator for the early part of the wide exchange and wr)"
+                exchange = "library exchange, native RCCL send/recv on the kernels' stream"
+                rccl_nranks = g.rccl_nranks()
             elif os.environ.get("POM_BENCH_ALLOW_P2P") == "1":   # developer switch: torch.distributed's RCCL P2P carries the same messages
                 print(f"bench[{rank}]: native RCCL transport unavailable; using torch.distributed P2P", file=sys.stderr)
                 bench_halo = H.DeviceHalo(g, tile, dev)
@@ -377,7 +697,7 @@ def main():
 
     # warm-up, then a profiled step to find the dominant kernel.  At N > 1 the first rounds also set up the RCCL
     # connections
-    deadline("warm-up steps", 300.0)
+    deadline("warm-up steps", 180.0)
     g.run(max(args.warmup, 1))
     barrier()
     deadline("profiled step", 120.0)
@@ -401,13 +721,17 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     timed = g.prof_end()
-    deadline("wrap-up", 300.0)
+    deadline("wrap-up", 180.0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     g.get_con()
     err = int(st.error_status)
+    if world > 1:                                              # a rank whose step failed fails the pass: every rank learns it
+        t = torch.tensor([float(err)], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        err = int(t.item())
 
     if rank == 0:
         cells = im * jm * kb
@@ -461,14 +785,19 @@ def main():
         step_gbs = P_STEP * BPV * cells / (dt / args.steps) / 1e9
         share = sorted(((k, v[1]) for k, v in prof.items()), key=lambda kv: -kv[1])
         tot = sum(v for _, v in share) or 1.0
+        overlap_on = bool(this_pass and this_pass.get("overlap"))
         out = {
-            "metric": "3D cell-updates/sec (whole internal step incl. the isplit external substeps)",
+            "metric": "3D cell-updates/sec on internal mode (one internal step = the 3-D baroclinic step and its isplit 2-D external substeps; whole-step wall time)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32-storage of the 3-D arrays / f64 arithmetic and external mode (STUDY variant, not a parity path)" if f32 else "f64",
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
+                       "overlap": (("second stream + second communicator for the early part of the wide exchange and wr" if overlap_on
+                                    else "off: every message round on the kernels' stream (POMGPU_NO_OVERLAP)") if world > 1 else None),
+                       "rccl_nranks": rccl_nranks,                  # what ncclCommCount reports for the library's communicator (0: no RCCL transport)
+                       "message_rounds_ms_rank0": round(msg_ms, 3),
                        "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0,
                        "message_rounds_per_step_on_side_stream": (g.exchange_rounds_side() - rounds0s) / args.steps if world > 1 else 0},
             "roofline": roof,
@@ -493,29 +822,40 @@ def main():
             "host_libc": _libc_version(),     # bit-parity with the reference leans on this libm's pow (THIRD_PARTY_NOTICES.md)
         }
         if not args.no_cpu_baseline and world == 1:
-            port = cpu_baseline(args.workload)
-            ref = None
-            try:
-                ref = cpu_reference(args.workload)
-            except Exception as e:                                 # noqa: BLE001 -- e.g. the MPI runtime the reference links is absent
-                print(f"bench: reference CPU baseline unavailable ({e})", file=sys.stderr)
-            out["cpu_baseline"] = ref or port                       # the reference itself where its build is present
-            if ref:
-                out["cpu_baseline_port"] = port
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload)
+            # the oracle on the bench's own grid (kind "port") is THE cpu_baseline; the sample figures are labelled extras
+            free_state = args.workload in ("basin2048", "basin1024")
+            if free_state and not args.side_config:
+                g.close()                                         # the CPU legs need the host's memory, not the GPU's
+                g = None
+                st = None
+            for name, fn in (("cpu_baseline", lambda: cpu_baseline(args.workload)),
+                             ("cpu_baseline_all_cores", lambda: cpu_baseline_all_cores(args.workload)),
+                             ("cpu_baseline_sample_reference", lambda: cpu_baseline_sample(args.workload, True)),
+                             ("cpu_baseline_sample_port", lambda: cpu_baseline_sample(args.workload, False))):
+                try:
+                    r = fn()
+                    if r:
+                        out[name] = r
+                except Exception as e:                             # noqa: BLE001 -- a CPU leg must not cost the GPU measurement its line
+                    print(f"bench: {name} unavailable ({e})", file=sys.stderr)
+            if "cpu_baseline" not in out and "cpu_baseline_sample_port" in out:
+                out["cpu_baseline"] = out["cpu_baseline_sample_port"]
         if world == 1 and args.workload == "basin2048" and args.side_config:
             # BASELINE configs[1] (seamount 256x256x30) in the same run: a launch-latency-bound size, reported beside
             # the headline grid so that both ends of the size range are on the line
-            g.close()
+            if g is not None:
+                g.close()
             g = None
             out["config1_seamount256"] = side_config("seamount256", local, stream)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if g is not None:
         g.close()
     if world > 1:
         torch.distributed.barrier()
         deadline("done", 0)
         torch.distributed.destroy_process_group()
+    if err:
+        sys.exit(7)                                            # error_status = 1 on some rank: the pass did not measure a valid run
 
 
 if __name__ == "__main__":

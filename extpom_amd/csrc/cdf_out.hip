@@ -199,7 +199,7 @@ static int write_file(pomgpu_ctx *c, const char *path, const pomgpu_file_meta *m
   }
   size_t total = 0;
   for (const Var &v : S.vars) total += var_doubles(*J, v);
-  bool async = !bad && total > 0 && !getenv("POMGPU_IO_SYNC");
+  bool async = !bad && total > 0 && !SW(c, IO_SYNC);
 #ifdef POMGPU_EMU
   async = false;
 #else

@@ -845,7 +845,7 @@ void launch_aam(pomgpu_ctx *c) {
 #else
   const bool pair_ok = true;
 #endif
-  if (pair_ok && P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) {
+  if (pair_ok && P.iml % 2 == 0 && !SW(c, NO_PAIR)) {
     const long nbands = (P.jml + P.g_rb - 1) / P.g_rb, rounds = (nbands + 7) / 8;
     const long bpl = (long)((P.iml / 2 + 61) / 62) * (P.g_rb / 4);
     const long nch = (P.kbm1 + AAM_KCH - 1) / AAM_KCH;          // chunks of levels per wavefront
@@ -884,7 +884,7 @@ void launch_smol(pomgpu_ctx *c, const double *ff) { LAUNCH(c, k_smol, gridm(c->P
 void launch_copy3(pomgpu_ctx *c, double *dst, const double *src) { LAUNCH(c, k_copy3, gridm(c->P), blk2(), c->P, dst, src); }
 void launch_advt2_diff(pomgpu_ctx *c, const double *fb, const double *fc, double *ff) { LAUNCH(c, k_advt2_diff, gridm(c->P), blk2(), c->P, fb, fc, ff); }
 void launch_ts_update(pomgpu_ctx *c, double fold, double fnew, int rt, int store_rst) {
-  if (c->tau_known[0] && c->tau_known[1] && !getenv("POMGPU_TAU_ARRAYS"))
+  if (c->tau_known[0] && c->tau_known[1] && !SW(c, TAU_ARRAYS))
     LAUNCHN(c, "k_ts_update", (k_ts_update<1>), gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst, c->tau_val[0], c->tau_val[1]);
   else
     LAUNCHN(c, "k_ts_update", (k_ts_update<0>), gridm(c->P), blk2(), c->P, fold, fnew, rt, store_rst, 0., 0.);
@@ -898,6 +898,6 @@ void launch_restore_shift(pomgpu_ctx *c) { LAUNCH(c, k_restore_shift, gridm(c->P
 void launch_restore_load(pomgpu_ctx *c, const double *tr, const double *sr, double tau) { LAUNCH(c, k_restore_load, gridm(c->P), blk2(), c->P, tr, sr, tau); }
 void launch_dens(pomgpu_ctx *c, const double *si, const double *ti, double *rhoo) { LAUNCH(c, k_dens, gridm(c->P), blk2(), c->P, si, ti, rhoo); }
 void launch_realvertvl(pomgpu_ctx *c) {
-  if (getenv("POMGPU_REALVERTVL_CELLS")) LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P);
+  if (SW(c, REALVERTVL_CELLS)) LAUNCH(c, k_realvertvl, gridm(c->P), blk2(), c->P);
   else LAUNCHN(c, "k_realvertvl_col", k_realvertvl_col, grid2(c->P), blk2(), c->P);
 }

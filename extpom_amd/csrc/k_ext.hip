@@ -1387,7 +1387,7 @@ k_ext_loop(KP P, int rim_rows, int first, int last, unsigned *bar, unsigned base
     }
     if (n == last) break;
     tgt += nblk;
-    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) *d_err = 1; return; }
+    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) atomicOr(d_err, POMGPU_DERR_BARRIER); return; }
     {
       KP Q = P;
 #pragma unroll
@@ -1397,7 +1397,7 @@ k_ext_loop(KP P, int rim_rows, int first, int last, unsigned *bar, unsigned base
     }
     if (n + 1 == last) break;
     tgt += nblk;
-    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) *d_err = 1; return; }
+    if (!ext_grid_barrier(bar, tgt)) { if (threadIdx.x == 0 && threadIdx.y == 0) atomicOr(d_err, POMGPU_DERR_BARRIER); return; }
   }
 }
 #endif
@@ -1449,7 +1449,7 @@ void launch_advave_b(pomgpu_ctx *c) { LAUNCH(c, k_advave_b, grid2(c->P), blk2(),
 void launch_advave_c(pomgpu_ctx *c) { LAUNCH(c, k_advave_c, grid2(c->P), blk2(), c->P); }
 void launch_advave_fused(pomgpu_ctx *c) {
   const KP &P = c->P;
-  if (P.iml % 2 == 0 && !getenv("POMGPU_NO_PAIR")) LAUNCHN(c, "k_advave_pair", k_advave_pair, dim3((P.iml / 2 + 61) / 62, (P.jml + 3) / 4, 1), blk2(), c->P);
+  if (P.iml % 2 == 0 && !SW(c, NO_PAIR)) LAUNCHN(c, "k_advave_pair", k_advave_pair, dim3((P.iml / 2 + 61) / 62, (P.jml + 3) / 4, 1), blk2(), c->P);
   else LAUNCH(c, k_advave_fused, grid2_halo(c->P), blk2(), c->P);
 }
 void launch_advave_m2a(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2a, grid2(c->P), blk2(), c->P); }
@@ -1463,12 +1463,12 @@ void launch_ext_update(pomgpu_ctx *c) { LAUNCH(c, k_ext_update, grid2(c->P), blk
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
   const int n = 3 * Q.im + 3 * (Q.jm > 3 ? Q.jm - 3 : 0);
   dim3 g = grid2_halo(Q);
-  if (getenv("POMGPU_EXT_RIM_KERNEL") && !fuse_adv) {         // developer switch: the rim as a launch of its own
+  if (SW(c, EXT_RIM_KERNEL) && !fuse_adv) {         // developer switch: the rim as a launch of its own
     LAUNCHN(c, "k_ext_step", k_ext_step<0>, g, blk2(), Q, store_f, 0);
     LAUNCH(c, k_ext_step_rim, dim3((n + 63) / 64, 1, 1), dim3(64, 1, 1), Q, store_f);
     return;
   }
-  if (fuse_adv && !getenv("POMGPU_EXT_NOMARCH")) {            // large tiles: a wavefront marches down `rows` rows (k_ext_march)
+  if (fuse_adv && !SW(c, EXT_NOMARCH)) {            // large tiles: a wavefront marches down `rows` rows (k_ext_march)
     // rows per wavefront: enough wavefronts first (>= ~7400, i.e. 3.6 per wave slot of the chip), then taller segments (fewer
     // halo rows): 7 at 2048x1536 (5-9 within 2 %), 2 at 1024x1024 (2.13 ms per step against 2.43 with 7 and 2.52 with the
     // one-row kernel); below ~16500 wavefront-rows (the extended tile of a 4- or 8-tile split of that grid) the one-row kernel
@@ -1476,12 +1476,12 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     const long wave_rows = (long)g.x * (Q.jmm1 - 2);
     int rows = (int)(wave_rows / 7400);
     rows = rows < 2 ? 2 : (rows > 7 ? 7 : rows);
-    if (getenv("POMGPU_EXT_ROWS")) rows = atoi(getenv("POMGPU_EXT_ROWS"));
+    if (SW(c, EXT_ROWS)) rows = (int)SWV(c, EXT_ROWS);
     const int nseg = rows > 0 ? (Q.jmm1 - 3 + 1 + rows - 1) / rows : 0, nbx = (int)g.x;
     const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
-    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (wave_rows >= 16500 || getenv("POMGPU_EXT_MARCH"))) {
+    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (wave_rows >= 16500 || SW(c, EXT_MARCH))) {
       const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
-      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, getenv("POMGPU_EXT_AREAS_LOAD") ? 0 : 1);
+      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
       return;
     }
   }
@@ -1494,18 +1494,18 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
 // generation read, y2 = the generation written (the other buffer set); T: a third set for the rim's / the band's intermediate
 // generation.  Returns 1 when launched, 0 when the tile is not one for this path (the caller takes the substeps one by one).
 // is the tile one for that path?  (without launching: pomgpu_mode_external decides with it whether an odd substep may wait for its partner)
-int launch_ext_pair_ok(const KP &Q) {
+int launch_ext_pair_ok(const pomgpu_switches &sw, const KP &Q) {
 #ifdef POMGPU_EMU
-  (void)Q;
+  (void)Q; (void)sw;
   return 0;                                                   // neighbour lanes are not emulated (tests/emu): the GPU tests cover this path
 #else
-  if (getenv("POMGPU_EXT_NOPAIR")) return 0;
+  if (sw.on[SW_EXT_NOPAIR]) return 0;
   const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);         // blk2d through one 32-bit buffer descriptor
   if (!fits || Q.im < 16 || Q.jm < 16) return 0;
   // small tiles keep the one-substep kernels unless asked (tests): the ring's ~20 us of dependent latency per pair and the few
   // wavefronts of a small tile eat the gain (profiles/round3_ext_pair.txt: the extended tile of an 8-tile split)
   const long wave_rows = (long)grid2_halo(Q).x * (Q.jmm1 - 2);
-  if (wave_rows < 16500 && !getenv("POMGPU_EXT_PAIR")) return 0;
+  if (wave_rows < 16500 && !sw.on[SW_EXT_PAIR]) return 0;
   return 1;
 #endif
 }
@@ -1514,7 +1514,7 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   (void)c; (void)Q; (void)T; (void)store_f2;
   return 0;
 #else
-  if (!launch_ext_pair_ok(Q)) return 0;
+  if (!launch_ext_pair_ok(c->sw, Q)) return 0;
   static int ncu = 0;
   if (!ncu) {
     hipDeviceProp_t pr;
@@ -1532,7 +1532,7 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
     const double cost = (double)((nwg + ncu - 1) / ncu) * (r + 4.5);
     if (cost < best) { best = cost; rows = r; }
   }
-  if (getenv("POMGPU_EXT_ROWS2")) rows = atoi(getenv("POMGPU_EXT_ROWS2"));
+  if (SW(c, EXT_ROWS2)) rows = (int)SWV(c, EXT_ROWS2);
   if (rows < 2) return 0;
   const int nseg = (nrow + rows - 1) / rows;
   const int nl = RING_LO + RING_HI, n = nl * Q.im + nl * (Q.jm - nl);          // cells of the ring
@@ -1555,7 +1555,7 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   if (!gen_of(Q.x2, GX) || !gen_of(Q.y2, GZ) || !gen_of(T, GT)) return 0;
   // launch 1: the ring's first substep (X -> T) as the first workgroups, the marching workgroups beside them (X -> Z, band of Y -> T)
   LAUNCHN(c, "k_ext_pair", k_ext_march2, dim3((unsigned)(ring_wgs + nseg * ncg), 1, 1), blk2(), Q, Tg, GX, GZ, GT, store_f2, ring_wgs, rows, (const int *)c->d_areas,
-          getenv("POMGPU_EXT_AREAS_LOAD") ? 0 : 1);
+          SW(c, EXT_AREAS_LOAD) ? 0 : 1);
   // launch 2: the ring's second substep (T -> Z)
   KP R2 = Q;
   for (int g = 0; g < POMGPU_NGEN; g++) R2.x2[g] = T[g];
@@ -1576,7 +1576,7 @@ int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last) {
   // lines for the L2 write-back of the release and 325 lanes poll one counter; 65x49 (28 workgroups): 0.35 against 0.39 ms,
   // nothing on the step.  A launch boundary on this chip (~1.5-2 us + the ~20 us the substep's dependent loads take anyway)
   // is cheaper than this barrier; an XCD-hierarchical one (MI355X_MICROARCH.md: ~6 us + the publish) would be the next try.
-  if (!getenv("POMGPU_EXT_LOOP") || last <= first || c->ext_loop_off) return 0;
+  if (!SW(c, EXT_LOOP) || last <= first || c->ext_loop_off) return 0;
   static int occ = -1, ncu = 0;
   if (occ < 0) {
     hipDeviceProp_t pr;

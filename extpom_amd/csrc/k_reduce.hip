@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_check_velocity_fin(KP P, const double *
     out[0] = best.v;
     out[1] = (best.n >= 0) ? (double)(best.n % P.im + 1) : 0.;
     out[2] = (best.n >= 0) ? (double)(best.n / P.im + 1) : 0.;
-    if (best.v > P.vmaxl) *err = 1;
+    if (best.v > P.vmaxl) atomicOr(err, POMGPU_DERR_VELOCITY);
   }
 }
 // ---------------------------------------------------------------------------------------------

@@ -93,6 +93,7 @@ __global__ void k_baropg(KP P, int sum2d) {
 #ifndef BPG_ROWS
 #define BPG_ROWS 16                                         /* kbench, one context: 2 rows 1.40, 4 1.30, 8 1.24, 16 1.15 ms; one thread per column (k_baropg) 1.32 */
 #endif
+static_assert(COL_WX == 1, "k_baropg_rs / k_vertvl_rs take threadIdx.y as the row inside the workgroup: one wavefront per workgroup row");
 __global__ void __launch_bounds__(64 * BPG_ROWS) k_baropg_rs(KP P, int sum2d) {
   HALO_XCD_DECODE_R(BPG_ROWS)
   const int r = WAVE_UNIFORM((int)threadIdx.y);
@@ -1573,7 +1574,7 @@ static inline dim3 colgrid(const KP &P) { return dim3((P.iml + 63) / 64, (P.jml 
 #define COLV_G(P) dim3(((P).iml + 63) / 64, ((P).jml + 3) / 4, 1)
 #define COLV_B dim3(64, 4, 1)
 void launch_baropg(pomgpu_ctx *c, int sum2d) {
-  if (getenv("POMGPU_BAROPG_CELLS")) { LAUNCH(c, k_baropg, COLV_G(c->P), COLV_B, c->P, sum2d); return; }   // developer switch: one thread per column, six loads per level
+  if (SW(c, BAROPG_CELLS)) { LAUNCH(c, k_baropg, COLV_G(c->P), COLV_B, c->P, sum2d); return; }   // developer switch: one thread per column, six loads per level
   LAUNCHN(c, "k_baropg", k_baropg_rs, grid1_halo_r(c->P, BPG_ROWS), blk_col_r(BPG_ROWS), c->P, sum2d);
 }
 void launch_baropg_mcc(pomgpu_ctx *c, int sum2d) { LAUNCH(c, k_baropg_mcc, colgrid(c->P), colblk(), c->P, sum2d); }
@@ -1588,7 +1589,7 @@ template <int KBT> static void launch_int_uvmean_reg_t(pomgpu_ctx *c) {
 }
 void launch_int_uvmean(pomgpu_ctx *c) {
   const int kb = c->P.kb;
-  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P);
+  if (SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6) LAUNCH(c, k_int_uvmean, colgrid(c->P), colblk(), c->P);
   else if (kb <= 24) launch_int_uvmean_reg_t<24>(c);
   else if (kb <= 32) launch_int_uvmean_reg_t<32>(c);
   else if (kb <= 40) launch_int_uvmean_reg_t<40>(c);
@@ -1598,7 +1599,7 @@ void launch_int_uvmean(pomgpu_ctx *c) {
   else launch_int_uvmean_reg_t<64>(c);
 }
 void launch_vertvl(pomgpu_ctx *c, int mask) {
-  if (getenv("POMGPU_VERTVL_CELLS")) { LAUNCH(c, k_vertvl, COLV_G(c->P), COLV_B, c->P, mask); return; }   // developer switch: one thread per column, four loads per level
+  if (SW(c, VERTVL_CELLS)) { LAUNCH(c, k_vertvl, COLV_G(c->P), COLV_B, c->P, mask); return; }   // developer switch: one thread per column, four loads per level
   LAUNCHN(c, "k_vertvl", k_vertvl_rs, grid1_halo_r(c->P, VVL_ROWS), blk_col_r(VVL_ROWS), c->P, mask);
 }
 void launch_profq_bc(pomgpu_ctx *c) { LAUNCH(c, k_profq_bc, colgrid(c->P), colblk(), c->P); }
@@ -1612,8 +1613,8 @@ void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
   // 8 paced rows per workgroup (one workgroup per CU at 2 waves per SIMD) where that still leaves every CU three workgroups
   // (a 514x769 tile of an 8-tile split: 3.4 per CU, k_profq 1.27 -> 1.22 ms, the tile's step 7.15 -> 6.9)
   // (developer switches: POMGPU_PROFQ_ROWS8 / _ROWS2 force a shape, POMGPU_PROFQ_NOPACE drops the barrier)
-  const int rows8 = !getenv("POMGPU_PROFQ_ROWS2") && (getenv("POMGPU_PROFQ_ROWS8") || (long)((c->P.iml + 63) / 64) * ((c->P.jml + 7) / 8) >= 3 * 256);
-  rho_rt = (rho_rt ? 1 : 0) | (getenv("POMGPU_PROFQ_NOPACE") ? 0 : 2);
+  const int rows8 = !SW(c, PROFQ_ROWS2) && (SW(c, PROFQ_ROWS8) || (long)((c->P.iml + 63) / 64) * ((c->P.jml + 7) / 8) >= 3 * 256);
+  rho_rt = (rho_rt ? 1 : 0) | (SW(c, PROFQ_NOPACE) ? 0 : 2);
 #define PQ(FP, FF)                                                                                                                       \
   do {                                                                                                                                   \
     if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, PROFQ_BIG>), dim3((c->P.iml + 63) / 64, (c->P.jml + PROFQ_BIG - 1) / PROFQ_BIG, 1), dim3(64, PROFQ_BIG, 1), c->P, rho_rt); \
@@ -1635,7 +1636,7 @@ static void launch_proft_reg(pomgpu_ctx *c, double *f, const double *wfsurf, con
 }
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   const int kb = c->P.kb;
-  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
+  if (SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6) LAUNCH(c, k_proft, colgrid(c->P), colblk(), c->P, f, wfsurf, fsurf, nbc);
   else if (kb <= 24) launch_proft_reg<24>(c, f, wfsurf, fsurf, nbc);
   else if (kb <= 32) launch_proft_reg<32>(c, f, wfsurf, fsurf, nbc);
   else if (kb <= 40) launch_proft_reg<40>(c, f, wfsurf, fsurf, nbc);
@@ -1653,7 +1654,7 @@ template <int KBT> static void launch_profuv_reg_t(pomgpu_ctx *c) {
 }
 int launch_profuv_reg(pomgpu_ctx *c) {
   const int kb = c->P.kb;
-  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) return 0;
+  if (SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6) return 0;
   if (kb <= 24) launch_profuv_reg_t<24>(c);
   else if (kb <= 32) launch_profuv_reg_t<32>(c);
   else if (kb <= 40) launch_profuv_reg_t<40>(c);
@@ -1669,7 +1670,7 @@ template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c) {
 }
 static int launch_uv_filter_reg(pomgpu_ctx *c) {
   const int kb = c->P.kb;
-  if (getenv("POMGPU_THOMAS_SCRATCH") || kb > 64 || kb < 6) return 0;
+  if (SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6) return 0;
   if (kb <= 24) launch_uv_filter_reg_t<24>(c);
   else if (kb <= 32) launch_uv_filter_reg_t<32>(c);
   else if (kb <= 40) launch_uv_filter_reg_t<40>(c);

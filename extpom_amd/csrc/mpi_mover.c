@@ -11,6 +11,7 @@
  *
  * Side-stream rounds (pomgpu_transport_side_agree): the ranks' own answers are reduced here with MPI_Allreduce(MIN),
  * so that all of them or none move rounds to the library's second stream. */
+#include <limits.h>
 #include <mpi.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,12 +48,14 @@ static void mover_fn(void *user, const double *const *send, const size_t *scount
   for (int d = 0; d < 8 && !bad; d++) {
     if (m->nbr[d] < 0) continue;
     if (rcount[d]) {
+      if (rcount[d] > (size_t)INT_MAX) { bad = 1; break; }     /* MPI counts are ints */
       bad |= grow(&m->hr[d], &m->cr[d], rcount[d]);
       if (!bad) MPI_Irecv(m->hr[d], (int)rcount[d], MPI_DOUBLE, m->nbr[d], OPP[d], m->comm, &req[nreq++]);
     }
   }
   for (int d = 0; d < 8 && !bad; d++) {
     if (m->nbr[d] < 0 || !scount[d]) continue;
+    if (scount[d] > (size_t)INT_MAX) { bad = 1; break; }
     bad |= grow(&m->hs[d], &m->cs[d], scount[d]);
     if (!bad && hipMemcpy(m->hs[d], send[d], scount[d] * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
     if (!bad) MPI_Isend(m->hs[d], (int)scount[d], MPI_DOUBLE, m->nbr[d], d, m->comm, &req[nreq++]);
@@ -62,11 +65,17 @@ static void mover_fn(void *user, const double *const *send, const size_t *scount
     if (m->nbr[d] >= 0 && rcount[d] && hipMemcpy(recv[d], m->hr[d], rcount[d] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) bad = 1;
   m->rounds++;
   if (bad) {                  /* a mover cannot return a status: a rank that lost a round must not go on with stale ghost cells */
-    fprintf(stderr, "pomgpu_mpi_mover: a message round failed (HIP copy or host staging buffer)\n");
+    fprintf(stderr, "pomgpu_mpi_mover: a message round failed (HIP copy, host staging buffer, or a message of more than INT_MAX doubles)\n");
     MPI_Abort(m->comm, 1);
   }
 }
 
+static mpi_mover *g_installed[64];   /* movers this library has installed, by slot: pomgpu_mpi_mover_remove frees them */
+static void mover_free(mpi_mover *m) {
+  if (!m) return;
+  for (int d = 0; d < 8; d++) { if (m->hs[d]) (void)hipHostFree(m->hs[d]); if (m->hr[d]) (void)hipHostFree(m->hr[d]); }
+  free(m);
+}
 /* fcomm: the Fortran handle of the communicator (MPI_Comm_f2c); neighbours8 in the order W E S N SW SE NW NE, -1 = none.
  * Collective over the communicator.  Returns a pomgpu_status. */
 int pomgpu_mpi_mover_install(pomgpu_ctx *ctx, int fcomm, const int *neighbours8) {
@@ -81,8 +90,23 @@ int pomgpu_mpi_mover_install(pomgpu_ctx *ctx, int fcomm, const int *neighbours8)
   int mine = rc == POMGPU_OK ? pomgpu_transport_side_capable(ctx) : 0, all = 0, worst = 0, myrc = rc;
   MPI_Allreduce(&mine, &all, 1, MPI_INT, MPI_MIN, m->comm);
   MPI_Allreduce(&myrc, &worst, 1, MPI_INT, MPI_MIN, m->comm);
-  if (worst != POMGPU_OK) return rc != POMGPU_OK ? rc : POMGPU_EINVAL;
+  if (worst != POMGPU_OK) {                                   /* some rank could not: nobody keeps a mover */
+    if (rc == POMGPU_OK) (void)pomgpu_set_transport(ctx, NULL, NULL, NULL);
+    mover_free(m);
+    return rc != POMGPU_OK ? rc : POMGPU_EINVAL;
+  }
+  for (int k = 0; k < 64; k++) if (!g_installed[k]) { g_installed[k] = m; break; }
   return pomgpu_transport_side_agree(ctx, all);
+}
+/* takes the mover off the context (back to a single tile's behaviour) and frees its pinned staging buffers; call it before
+ * pomgpu_destroy, after the last step.  Not collective. */
+int pomgpu_mpi_mover_remove(pomgpu_ctx *ctx) {
+  if (!ctx) return POMGPU_EINVAL;
+  void *stream = pomgpu_stream(ctx);
+  const int rc = pomgpu_set_transport(ctx, NULL, NULL, NULL);  /* synchronises what the mover may still be part of */
+  for (int k = 0; k < 64; k++)
+    if (g_installed[k] && g_installed[k]->stream == stream) { mover_free(g_installed[k]); g_installed[k] = NULL; }
+  return rc;
 }
 /* Fortran-callable without an interface block (by-reference arguments, trailing underscore) is not offered: the host
  * binds it through ISO_C_BINDING like the rest of the C ABI (extpom_amd/fortran/pomgpu_iface.f90). */

@@ -229,6 +229,7 @@ static void rho_materialize(pomgpu_ctx *c) {
   launch_roundtrip(c, SLOT3(c, P3_rho), SLOT3(c, P3_rmean), 2);
 }
 static void side_join(pomgpu_ctx *c);
+static void early_invalidate(pomgpu_ctx *c);
 static void restore_materialize(pomgpu_ctx *c) {
   side_join(c);                                               // whoever asks for materialised state also waits for the side stream
   rho_materialize(c);
@@ -282,12 +283,12 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   // (POMGPU_PAD3 = 4-KiB pages): at the benchmark size the arrays are an exact multiple of 16 MiB apart, so that the ~10
   // arrays a kernel reads at one (i,j,k) sit at the same offset of the memory interleave; upload / download copy
   // array by array then
+  pomgpu_switches_read(c->sw);                                // the developer switches: once per context, never on the launch path
   {
-    const char *e = getenv("POMGPU_PAD3");
-    const long pages = e ? atol(e) : 0;
+    const long pages = SW(c, PAD3) ? SWV(c, PAD3) : 0;
     P.a3 = P.n3 + (pages > 0 ? (size_t)pages * 512 : 0);
   }
-  set_band_geometry(P);
+  set_band_geometry(P, c->sw);
   size_t off = 0; int s = 0;
 #define BD_(name, shape) P.bdoff[s++] = off; off += BDN_##shape;
 #define BDN_J ((size_t)P.jml)
@@ -336,7 +337,7 @@ static int ctx_create(pomgpu_ctx **out, const pomgpu_dims *d, int device, void *
   if (ok && hipMalloc((void **)&c->d_areas, sizeof(int)) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_areas, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
   if (ok && hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream) != hipSuccess) ok = false;
-  if (getenv("POMGPU_DEBUG_ALLOC"))
+  if (SW(c, DEBUG_ALLOC))
     fprintf(stderr, "pomgpu_create: b1 %p r1 %p b2 %p b3 %p bd %p s3[0] %p s3[4] %p s2[0] %p c2[0] %p\n", (void *)P.b1, (void *)P.r1, (void *)P.b2,
             (void *)P.b3, (void *)P.bd, (void *)P.s3[0], (void *)P.s3[4], (void *)P.s2[0], (void *)P.c2[0]);
   if (!ok) {
@@ -390,6 +391,20 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   free(c);
 }
 
+// One developer switch of one context, after its creation (pomgpu_internal.hpp: POMGPU_SWITCHES).  name with or without the
+// "POMGPU_" prefix; value NULL clears it, anything else sets it (numbers are read with atol).  For tools and tests only.
+extern "C" int pomgpu_debug_switch(pomgpu_ctx *c, const char *name, const char *value) {
+  if (!c || !name) return POMGPU_EINVAL;
+  if (strncmp(name, "POMGPU_", 7) == 0) name += 7;
+  for (int n = 0; n < SW__count; n++)
+    if (strcmp(POMGPU_SW_NAMES[n], name) == 0) {
+      pomgpu_ctx *two[2] = {c, c->wide.x};
+      for (pomgpu_ctx *t : two)
+        if (t) { t->sw.on[n] = value ? 1 : 0; t->sw.val[n] = value ? atol(value) : 0; }
+      return POMGPU_OK;
+    }
+  return fail(c, POMGPU_EINVAL, "debug_switch: no switch named %s", name);
+}
 extern "C" const char *pomgpu_last_error(const pomgpu_ctx *c) { return c ? c->err : "null context"; }
 extern "C" void *pomgpu_stream(pomgpu_ctx *c) { return c ? (void *)c->stream : NULL; }
 
@@ -398,11 +413,11 @@ static int pull_err(pomgpu_ctx *c) {
   int e = 0;
   HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (e) {
-    c->con.error_status = 1;
-    // k_ext_loop (opt-in) raises the same flag when a spin at its grid barrier times out.  Its abort word is sticky and its
-    // arrival counter is out of step then: clear both and keep this context off that path (a shared or oversubscribed GPU
-    // does not guarantee that all workgroups are resident, which the barrier needs)
+  if (e) c->con.error_status = 1;
+  if (e & POMGPU_DERR_BARRIER) {
+    // k_ext_loop (opt-in) gave up at its grid barrier.  Its abort word is sticky and its arrival counter is out of step then:
+    // clear both and keep this context off that path (a shared or oversubscribed GPU does not guarantee that all workgroups
+    // are resident, which the barrier needs).  A velocity violation (POMGPU_DERR_VELOCITY) leaves that path alone.
     pomgpu_ctx *two[2] = {c, c->wide.x};
     for (pomgpu_ctx *t : two)
       if (t && t->ext_bar) {
@@ -455,6 +470,7 @@ extern "C" int pomgpu_upload(pomgpu_ctx *c, const double *b1, const double *b2, 
   ext_canonical(c);
   restore_materialize(c);
   c->wide.static_done = 0;                                    // the extended tile's copy of the grid metrics is stale
+  early_invalidate(c);                                        // ... and so is whatever an early gather has already moved
   if (b2) { int rc = check_masks(c, b2); if (rc) return rc; }
   if (b1) HIPCHK(c, hipMemcpyAsync(P.b1, b1, sizeof(double) * POM_NBLK1D * P.kb, hipMemcpyHostToDevice, c->stream));
   if (b2) HIPCHK(c, hipMemcpyAsync(P.b2, b2, sizeof(double) * POM_NBLK2D * P.n2, hipMemcpyHostToDevice, c->stream));
@@ -527,6 +543,7 @@ extern "C" int pomgpu_upload_2d(pomgpu_ctx *c, int s, const double *h) {
   HIPCHK(c, hipMemcpyAsync(SLOT2(c, s), h, sizeof(double) * c->P.n2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!wide_travels_every_step(s)) c->wide.static_done = 0;   // e.g. forcing fields uploaded every step are gathered every step anyway
+  early_invalidate(c);
   refresh_coefs(c);
   return POMGPU_OK;
 }
@@ -655,7 +672,7 @@ static void seq_advave(pomgpu_ctx *c) {                       // solver.f:6-198
 static void seq_advct(pomgpu_ctx *c, int sum2d = 0, int defer_xch = 0) {   // solver.f:201-408
   KP &P = c->P;
   if (!c->exch) { launch_advct_col(c, sum2d); return; }       // one tile: nothing to exchange, fluxes stay in registers
-  if (c->tp.on && !getenv("POMGPU_ADVCT_SPLIT")) {            // tiles, the library's own exchange: see k_advct_edge
+  if (c->tp.on && !SW(c, ADVCT_SPLIT)) {            // tiles, the library's own exchange: see k_advct_edge
     pomgpu_transport &T = c->tp;
     const size_t ne = 2 * (size_t)P.kbm1 * P.jm, nn = 2 * (size_t)P.kbm1 * P.im;
     launch_advct_edge(c, T.nbr[1] >= 0 ? T.send[1] : NULL, T.nbr[3] >= 0 ? T.send[3] : NULL);
@@ -712,7 +729,7 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
   KP &P = c->P;
   launch_profq_bc(c);
   double *ufkb = D3(c, uf) + (size_t)(P.kb - 1) * P.n2;
-  const int lines = c->exch && c->tp.on && !getenv("POMGPU_PROD_FULL");   // tiles, the library's own exchange
+  const int lines = c->exch && c->tp.on && !SW(c, PROD_FULL);   // tiles, the library's own exchange
   if (lines) {
     // the production term's lines (k_profq_prod_lines) depend on nothing profq_bc or the exchange below delivers:
     // :1289-1290, :1374 (and advance.f:400 for w) travel in ONE round
@@ -805,9 +822,16 @@ static void side_end(pomgpu_ctx *c, hipEvent_t ev) {
   c->cur = c->stream;
   if (c->wide.x) c->wide.x->cur = c->stream;
 }
+// "The early part of this step's wide exchange has been posted" (early_started) is a fact about the MESSAGE PATTERN of the step:
+// wide_begin posts the late part only while it holds, and every rank must post alike.  Joining the side stream therefore only
+// waits; the flag falls when wide_begin has used it, or when something rewrites the arrays the early part carried (an upload:
+// early_invalidate -- to be called on all ranks alike, like the upload itself).
 static void side_join(pomgpu_ctx *c) {                        // everything the side stream holds, before the main stream goes on
-  if (c->early_started) { (void)hipStreamWaitEvent(c->stream, c->ev_early, 0); c->early_started = 0; }
+  if (c->early_started) (void)hipStreamWaitEvent(c->stream, c->ev_early, 0);
   if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }
+}
+static void early_invalidate(pomgpu_ctx *c) {
+  if (c->early_started) { (void)hipStreamWaitEvent(c->stream, c->ev_early, 0); c->early_started = 0; }
 }
 // the side stream and its three events, created on first use; 1 = they exist
 int pomgpu_side_stream(pomgpu_ctx *c) {
@@ -850,7 +874,7 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      
   rho_materialize(c);                                         // a deferred round trip no step has consumed (baropg reads rho)
   KP &P = c->P;
   if (P.mode != 2) {
-    const bool lib_x = c->tp.on && c->exch && !getenv("POMGPU_ADVCT_SPLIT");
+    const bool lib_x = c->tp.on && c->exch && !SW(c, ADVCT_SPLIT);
     seq_advct(c, sum2d, lib_x);                               // lib_x: advx, advy travel with aam below
     if (P.npg == 1) seq_baropg(c, sum2d, defer_rt);
     else if (P.npg == 2) seq_baropg_mcc(c, sum2d, defer_rt);
@@ -923,16 +947,16 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
   }
   KP &P = c->P;
   P.iext = c->con.iext;
-  if (!c->exch && !getenv("POMGPU_EXT_SPLIT")) {              // one tile: one kernel per substep, two buffer generations
+  if (!c->exch && !SW(c, EXT_SPLIT)) {              // one tile: one kernel per substep, two buffer generations
     // advave every substep (ispadv = 1 is hard-coded in the reference, initialize.f:156): it rides in the substep's kernel
-    const int fuse_adv = c->con.ispadv == 1 && P.mode != 2 && !getenv("POMGPU_ADVAVE_SEPARATE");
+    const int fuse_adv = c->con.ispadv == 1 && P.mode != 2 && !SW(c, ADVAVE_SEPARATE);
     if (!fuse_adv && c->con.ispadv > 0 && c->con.iext % c->con.ispadv == 0) seq_advave(c);   // :235 (reads ua, va, d of the current generation)
     KP Q = P;
     for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
     // once per internal step (and after any upload): are art, aru, arv what initialize.f:361-367 makes of dx, dy?  Then
     // k_ext_march forms them in registers instead of reading three arrays per substep.  On the device, no host round trip.
     if (fuse_adv && (P.iext == 1 || !c->areas_checked)) { launch_check_areas(c); c->areas_checked = 1; }
-    if (c->parent && !getenv("POMGPU_WIDE_FULL")) {
+    if (c->parent && !SW(c, WIDE_FULL)) {
       // The extended tile of the wide-halo mode: its stale rim grows by one line per substep (see "How far stale cells spread"
       // below), so substep n need not compute the n - 1 outermost rows of an extended side at all -- they are wrong already and
       // nobody reads them again.  The window's own outermost row is "the row an exchange would have filled", as the extended
@@ -965,8 +989,8 @@ static int ext_pair_ok(pomgpu_ctx *c, int iext) {             // may substeps ie
   pomgpu_ctx *t = c;
   if (c->wide.on) { if (!c->wide.pending) return 0; t = c->wide.x; }
   else if (c->exch) return 0;
-  if (iext < 1 || iext + 1 > c->con.isplit || getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || t->P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE")) return 0;
-  return launch_ext_pair_ok(t->P);
+  if (iext < 1 || iext + 1 > c->con.isplit || SW(c, EXT_SPLIT) || c->con.ispadv != 1 || t->P.mode == 2 || SW(c, ADVAVE_SEPARATE)) return 0;
+  return launch_ext_pair_ok(c->sw, t->P);
 }
 static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
   if (!ext_pair_ok(c, iext)) return 0;
@@ -987,7 +1011,7 @@ static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
   // rest) would leave it in alt2, ONE pair goes alt2 -> alt3 with the stale blk2d arrays as its scratch set, and the two sets
   // swap names: 15 pairs = blk2d -> alt2 -> alt3 (now called alt2) -> blk2d -> ...
   const int rest = isplit - iext + 1, launches = rest / 2 + (rest & 1);
-  const bool stay = t->ext_parity == 1 && !(launches & 1) && !getenv("POMGPU_EXT_TWO_SETS");
+  const bool stay = t->ext_parity == 1 && !(launches & 1) && !SW(c, EXT_TWO_SETS);
   double *canon[POMGPU_NGEN];
   for (int n = 0; n < POMGPU_NGEN; n++) canon[n] = P.b2 + (size_t)X2_SLOT[n] * P.n2;
   for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = stay ? t->alt3[n] : t->ext_parity ? canon[n] : t->alt2[n];
@@ -1007,7 +1031,7 @@ static int ext_loop_all(pomgpu_ctx *c) {
   else if (c->exch) return 0;
   KP &P = t->P;
   const int isplit = c->con.isplit;
-  if (getenv("POMGPU_EXT_SPLIT") || c->con.ispadv != 1 || P.mode == 2 || getenv("POMGPU_ADVAVE_SEPARATE") || isplit < 2) return 0;
+  if (SW(c, EXT_SPLIT) || c->con.ispadv != 1 || P.mode == 2 || SW(c, ADVAVE_SEPARATE) || isplit < 2) return 0;
   P.iext = 1;
   KP Q = P;
   for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = t->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : t->alt2[n];
@@ -1247,7 +1271,7 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
   // the width follows the number of external substeps per internal step: the state (blkcon) must have been uploaded
   if (c->con.isplit < 1) return fail(c, POMGPU_EINVAL, "wide external mode: isplit = %d -- upload the state (pomgpu_upload / pomgpu_set_con) first", c->con.isplit);
   int w = c->con.isplit + 4;
-  if (getenv("POMGPU_WIDE_W")) w = atoi(getenv("POMGPU_WIDE_W"));   // developer switch: shows that fewer cells are not enough
+  if (SW(c, WIDE_W)) w = (int)SWV(c, WIDE_W);   // developer switch: shows that fewer cells are not enough
   if (w < 1 || min_im < w + 3 || min_jm < w + 3 || P.im < w + 3 || P.jm < w + 3) {
     snprintf(c->err, sizeof c->err, "wide external mode: tiles of %d x %d cells are narrower than w + 3 = %d", min_im, min_jm, w + 3);
     return POMGPU_EINVAL;                                     // not an error of the run: the per-point exchanges stay in use
@@ -1269,6 +1293,8 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
   int rc = ctx_create(&Wd.x, &d, c->device, (void *)c->stream, POMGPU_CTX_2D);
   if (rc) return fail(c, rc, "wide external mode: cannot create the %d x %d extended tile", d.im, d.jm);
   Wd.x->parent = c;
+  Wd.x->sw = c->sw;                                           // the extended tile runs under its tile's switches
+  set_band_geometry(Wd.x->P, Wd.x->sw);
   // staging buffers: the per-step arrays of one neighbour block (w+1 lines of the tile's edge; corners (w+1)^2)
   size_t need[8];
   const size_t per = (size_t)NEL(WIDE_HALO) * (w + 1), edge = (size_t)NEL(WIDE_BD_J) * (w + 1);
@@ -1337,7 +1363,7 @@ static int wide_begin(pomgpu_ctx *c) {
   pomgpu_wide &Wd = c->wide;
   pomgpu_ctx *x = Wd.x;
   int rc;
-  if (c->con.isplit + 4 > Wd.w && !getenv("POMGPU_WIDE_W"))     // the stale rim grows by one cell per substep (see above)
+  if (c->con.isplit + 4 > Wd.w && !SW(c, WIDE_W))     // the stale rim grows by one cell per substep (see above)
     return fail(c, POMGPU_EINVAL, "wide external mode: isplit = %d now, the extended tile was made for isplit <= %d -- call pomgpu_set_wide_external again", c->con.isplit, Wd.w - 4);
   if (!Wd.static_done && (rc = wide_static(c))) return rc;
   if (c->early_started) {                                     // the rest of the gather here, then wait for the part that ran beside
@@ -1373,7 +1399,7 @@ static void ext_flush_deferred(pomgpu_ctx *c) {
   const int now = c->con.iext;
   c->con.iext = c->ext_deferred;
   c->ext_deferred = 0;
-  (void)mode_external(c, 1);
+  if (mode_external(c, 1)) c->con.error_status = 1;           // the held substep failed: the context says so at the next entry point / get_con (pomgpu.h)
   c->con.iext = now;
   c->P.iext = now;
 }
@@ -1416,8 +1442,8 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     // xflux(im,j): the same formula on the same operands the tile holds in its own ghost cells (q, qb, u, dt, aam
     // have all been exchanged), i.e. the value it computes itself.  The fused flux+step kernel therefore serves
     // tiles as well, without that exchange.  (pomgpu_advq, the stand-alone entry point, keeps the reference's form.)
-    if (!c->exch || !getenv("POMGPU_ADVQ_EXCHANGE")) {
-      if (getenv("POMGPU_ADVQ_SINGLE")) {
+    if (!c->exch || !SW(c, ADVQ_EXCHANGE)) {
+      if (SW(c, ADVQ_SINGLE)) {
         launch_advq_col(c, D3(c, q2), D3(c, q2b), D3(c, uf), 1);
         launch_advq_col(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), 1);
       } else {
@@ -1431,7 +1457,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       launch_advq_step(c, D3(c, q2), D3(c, q2b), D3(c, uf), x0, y0, 1);
       launch_advq_step(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), x1, y1, 1);
     }
-    const int qfuse = !getenv("POMGPU_QFILTER_SPLIT");
+    const int qfuse = !SW(c, QFILTER_SPLIT);
     seq_profq(c, qfuse, lib_x);                               // with the interior's Asselin filter (:416-421) on its way up
     xch(c, 2, D3(c, uf) + P.n2, P.kbm2, D3(c, vf) + P.n2, P.kbm2);   // :411-412
     launch_bcond6_edges(c);                                   // :414
@@ -1442,7 +1468,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
         seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
       } else if (k.nadv == 2) {
-        if (P.nitera == 1 && !getenv("POMGPU_ADVT2_SINGLE")) {   // T and S in one pass
+        if (P.nitera == 1 && !SW(c, ADVT2_SINGLE)) {   // T and S in one pass
           launch_coef_eta(c);
           launch_advt2x2_col(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
           // solver.f:728 exchanges T, then S; advance.f:436-437 below exchanges both again with nothing written
@@ -1469,7 +1495,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       c->rho_rt_pending = 0;                                  // dens has rewritten rho(1..kbm1)
       c->rst_pending = 1; c->rst_fold = fold; c->rst_fnew = fnew;
     }
-    if (c->P.kb >= 6 && c->P.kb <= 64 && !getenv("POMGPU_THOMAS_SCRATCH")) {
+    if (c->P.kb >= 6 && c->P.kb <= 64 && !SW(c, THOMAS_SCRATCH)) {
       launch_advuv_col(c);                                    // :459-460 advu, advv in one pass
       launch_profuv_reg(c);                                   // :461-462 profu, profv with register-resident elimination vectors
     } else {
@@ -1481,7 +1507,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
     else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);     // :466-467
     launch_uv_filter(c);                                      // :469-514
-    if (lib_x && !getenv("POMGPU_UV_FULL_EXCHANGE")) {
+    if (lib_x && !SW(c, UV_FULL_EXCHANGE)) {
       // :516-521 exchange all kb levels of ub, u, uf, vb, v, vf.  For u, uf, v, vf the levels 1..kbm1 are redundant: uf, vf
       // were exchanged at :466-467 and not written since, and u = uf, v = vf are copies.  What is not valid in a ghost
       // column is their level kb (profu / profv write it on owned columns only).  ub, vb are needed in full: the filter
@@ -1659,19 +1685,19 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
-  { KP g = c->P; set_band_geometry(g); c->P.g_strip = g.g_strip; c->P.g_lin = g.g_lin; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, honoured per step (tools/kbench.py)
+  { KP g = c->P; set_band_geometry(g, c->sw); c->P.g_strip = g.g_strip; c->P.g_lin = g.g_lin; c->P.g_rb = g.g_rb; c->P.g_nbx = g.g_nbx; c->P.g_bpl = g.g_bpl; }   // developer switches POMGPU_COL_STRIP, POMGPU_BAND_BYTES, follow pomgpu_debug_switch from step to step (tools/kbench.py)
   // advance.f:14-18: file-driven in the reference; here they run once the host has supplied records
   if (c->frc_on && (rc = pomgpu_surface_forcing(c))) return rc;
   if (c->lat_on && (rc = pomgpu_lateral_bc(c))) return rc;
   // the vertical integrals of advx, advy, drhox, drhoy come out of advct / baropg themselves: on one tile, and on
   // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
-  const bool tiles_fused = c->wide.on && c->tp.on && !getenv("POMGPU_ADVCT_SPLIT");
+  const bool tiles_fused = c->wide.on && c->tp.on && !SW(c, ADVCT_SPLIT);
   const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
   const int ph_step = prof_phase_open(c);                     // "phase_step": this whole step on the kernels' stream
   if ((rc = wide_early_start(c))) return rc;                  // most of the wide exchange, beside lateral_viscosity
   // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)
   const pom_blkcon &k0 = c->con;
-  const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !getenv("POMGPU_RHO_ROUNDTRIP");   // rho's readers before dens: k_profq, k_profq_prod(_lines)
+  const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !SW(c, RHO_ROUNDTRIP);   // rho's readers before dens: k_profq, k_profq_prod(_lines)
   if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
   const int ph_ext = prof_phase_open(c);                      // "phase_external": the isplit substeps of mode_external (advance.f:27-29)

@@ -22,6 +22,9 @@
 #define POMGPU_MAXREC 8
 #define POMGPU_KBMAX 128   // per-column private arrays in the tridiagonal kernels
 #define POMGPU_CTX_2D 1
+// bits of the device error word (pomgpu_ctx::d_err)
+#define POMGPU_DERR_VELOCITY 1   // check_velocity: vamax > vmaxl (advance.f:631-637)
+#define POMGPU_DERR_BARRIER 2    // k_ext_loop gave up at its grid barrier
 #define POMGPU_NGEN 7        // arrays of the external mode that exist in two generations (enum pomgpu_x2)
 
 // Kernel parameters, passed by value with every launch.
@@ -432,6 +435,57 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
 #define TID_K (int)(blockIdx.z * blockDim.z + threadIdx.z + 1)
 
 // ---- host side ---------------------------------------------------------------------------------
+// Developer switches: environment variables POMGPU_<NAME>, read ONCE when a context is created
+// (pomgpu_create) into the context -- no getenv on the launch path, and every context of a process keeps the switch set
+// it was created under.  pomgpu_debug_switch (include/pomgpu.h) changes one of them afterwards: tools/kbench.py lets
+// variants take turns on ONE context with it, tests give the ranks of one process different switch sets.
+#define POMGPU_SWITCHES(X)                                                                                                    \
+  X(THOMAS_SCRATCH) X(NO_PAIR) X(EXT_SPLIT) X(ADVAVE_SEPARATE) X(EXT_RIM_KERNEL) X(EXT_LOOP) X(EXT_NOMARCH) X(EXT_MARCH)      \
+  X(EXT_ROWS) X(EXT_NOPAIR) X(EXT_PAIR) X(EXT_ROWS2) X(EXT_TWO_SETS) X(EXT_AREAS_LOAD) X(BAROPG_CELLS) X(VERTVL_CELLS)        \
+  X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
+  X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
+  X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
+  X(EXT_NOCHAIN) X(EDGE_SPLIT)
+enum pomgpu_sw {
+#define POMGPU_SW_(name) SW_##name,
+  POMGPU_SWITCHES(POMGPU_SW_)
+#undef POMGPU_SW_
+  SW__count
+};
+struct pomgpu_switches {
+  unsigned char on[SW__count];   // the variable is set (whatever its value: presence is the switch)
+  long val[SW__count];           // atol of its value (switches that carry a number: EXT_ROWS, COL_STRIP, WIDE_W ...)
+};
+static const char *const POMGPU_SW_NAMES[SW__count] = {
+#define POMGPU_SW_(name) #name,
+  POMGPU_SWITCHES(POMGPU_SW_)
+#undef POMGPU_SW_
+};
+static inline void pomgpu_switches_read(pomgpu_switches &s) {
+  for (int n = 0; n < SW__count; n++) {
+    char var[64] = "POMGPU_";
+    size_t k = 7;
+    for (const char *q = POMGPU_SW_NAMES[n]; *q && k + 1 < sizeof var; q++) var[k++] = *q;
+    var[k] = 0;
+    const char *e = getenv(var);
+    s.on[n] = e ? 1 : 0;
+    s.val[n] = e ? atol(e) : 0;
+  }
+}
+// order-independent digest of the switches that every rank of a decomposition must share (they choose which message
+// rounds exist and on which stream / communicator they run): the ranks compare it before any collective depends on it
+static inline unsigned pomgpu_switches_collective_digest(const pomgpu_switches &s) {
+  static const int coll[] = {SW_ADVCT_SPLIT, SW_ADVQ_EXCHANGE, SW_PROD_FULL, SW_QFILTER_SPLIT, SW_UV_FULL_EXCHANGE, SW_NO_OVERLAP,
+                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT};
+  unsigned h = 2166136261u;
+  for (size_t n = 0; n < sizeof coll / sizeof coll[0]; n++) {
+    h = (h ^ (unsigned)(s.on[coll[n]] ? 1 + coll[n] : 0)) * 16777619u;
+    h = (h ^ (unsigned)s.val[coll[n]]) * 16777619u;
+  }
+  return h & 0x3fffffffu;
+}
+#define SW(c, NAME) ((c)->sw.on[SW_##NAME] != 0)
+#define SWV(c, NAME) ((c)->sw.val[SW_##NAME])
 struct ProfEntry { const char *name; long launches; double ms; };
 struct pomgpu_ctx;
 
@@ -477,6 +531,7 @@ struct pomgpu_wide {
 
 struct pomgpu_ctx {
   KP P;
+  pomgpu_switches sw;        // developer switches, read from the environment once at pomgpu_create (never on the launch path)
   int device;
   hipStream_t stream;
   bool own_stream;
@@ -575,10 +630,10 @@ static inline dim3 gridm(const KP &P) {
   const long rounds = (nbands + 7) / 8;
   return dim3((unsigned)(8 * rounds * P.kb * P.g_bpl), 1, 1);
 }
-static inline void set_band_geometry(KP &P) {
+static inline void set_band_geometry(KP &P, const pomgpu_switches &sw) {
   long budget = 3L << 20;                       // bytes of one XCD's L2 a band may occupy per level
-  const char *e = getenv("POMGPU_BAND_BYTES");
-  if (e && atol(e) >= 1024) budget = atol(e);
+  const bool e = sw.on[SW_BAND_BYTES] != 0;
+  if (e && sw.val[SW_BAND_BYTES] >= 1024) budget = sw.val[SW_BAND_BYTES];
   long rows = budget / ((long)P.iml * 8 * 24);  // ~24 arrays (2-D coefficients + 3-D operands) in flight
   rows = (rows / 4) * 4;
   if (rows < 4) rows = 4;
@@ -590,9 +645,8 @@ static inline void set_band_geometry(KP &P) {
   const int nbx = ((P.iml + 61) / 62 + COL_WX - 1) / COL_WX;
   const int nstr = (nbx + 11) / 12;
   P.g_strip = nbx >= 20 ? (nbx + nstr - 1) / nstr : 0;
-  const char *es = getenv("POMGPU_COL_STRIP");
-  if (es) P.g_strip = atoi(es);
-  P.g_lin = getenv("POMGPU_NO_LIN") ? 0 : 1;
+  if (sw.on[SW_COL_STRIP]) P.g_strip = (int)sw.val[SW_COL_STRIP];
+  P.g_lin = sw.on[SW_NO_LIN] ? 0 : 1;
   // cell launches: of the band heights the L2 budget allows, the one that leaves the fewest empty band slots (8 bands per round)
   if (!e) {
     long best = -1, bslots = 0;
@@ -630,7 +684,7 @@ void launch_ext_update(pomgpu_ctx *c);
 void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv);
 void launch_check_areas(pomgpu_ctx *c);
 int launch_ext_loop(pomgpu_ctx *c, const KP &Q, int first, int last);   // 1 = launched (all substeps first..last), 0 = not applicable
-int launch_ext_pair_ok(const KP &Q);                                             // would launch_ext_pair take this tile?
+int launch_ext_pair_ok(const pomgpu_switches &sw, const KP &Q);                                             // would launch_ext_pair take this tile?
 int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2);   // 1 = substeps Q.iext, Q.iext + 1 launched, 0 = not applicable
 void launch_copy2(pomgpu_ctx *c, double *dst, const double *src);
 void launch_lat(pomgpu_ctx *c, int phase, const double *rec, double fold, double fnew);   // phase 0 load, 1 shift, 2 interpolate

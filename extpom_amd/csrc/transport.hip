@@ -34,6 +34,7 @@ struct RcclApi {
   const char *(*GetErrorString)(ncclResult_t);
   ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *);   // optional (RCCL >= 2.18): the side stream's communicator
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);   // the ranks' agreement on side-stream rounds
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);         // optional: how many ranks the communicator really has (pomgpu_rccl_nranks)
 };
 static RcclApi g_rccl;
 struct RcclComm { ncclComm_t comm, comm2; int rank, nranks; };
@@ -61,6 +62,7 @@ static int rccl_load(const char *path) {
   SYM(AllReduce, "ncclAllReduce")
 #undef SYM
   *(void **)(&a.CommSplit) = dlsym(h, "ncclCommSplit");       // absent in old libraries: no side-stream rounds then
+  *(void **)(&a.CommCount) = dlsym(h, "ncclCommCount");
   g_rccl = a;
   return 0;
 }
@@ -136,27 +138,35 @@ int pomgpu_tp_side_ok(pomgpu_ctx *c) {
 }
 // this rank's own answer (not yet an agreement): a second stream exists or can be made, nothing switches the overlap off
 static int side_capable_local(pomgpu_ctx *c) {
-  if (getenv("POMGPU_NO_OVERLAP")) return 0;
+  if (SW(c, NO_OVERLAP) || SW(c, NO_SIDE_COMM)) return 0;      // this context's switches (read at pomgpu_create)
   return pomgpu_side_stream(c);
 }
+// The answer a host reduces over ALL ranks with min (callback movers: the library cannot reach the other ranks itself):
+// 0 = this rank cannot serve side-stream rounds, 1 = it can but wants the wr exchange on the main stream (WR_MAIN),
+// 2 = it can and wr may run beside the next step.  The minimum is what pomgpu_transport_side_agree takes.
 extern "C" int pomgpu_transport_side_capable(pomgpu_ctx *c) {
   if (!c || !c->tp.on) return 0;
 #ifndef POMGPU_EMU
   if (!c->tp.fn) { RcclComm *r = (RcclComm *)c->tp.rccl; if (!r || !r->comm2) return 0; }
 #endif
-  return side_capable_local(c);
+  if (!side_capable_local(c)) return 0;
+  return SW(c, WR_MAIN) ? 1 : 2;
 }
+// the digest of the switches every rank of a decomposition must share (pomgpu_internal.hpp): hosts with a callback mover
+// compare it over their ranks before the first step (RCCL: pomgpu_rccl_init does it over the communicator)
+extern "C" unsigned pomgpu_switch_digest(pomgpu_ctx *c) { return c ? pomgpu_switches_collective_digest(c->sw) : 0u; }
 extern "C" int pomgpu_transport_side_agree(pomgpu_ctx *c, int agreed) {
   if (!c) return POMGPU_EINVAL;
   pomgpu_transport &T = c->tp;
   if (!T.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: set a transport first");
   if (c->wide.on) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: before pomgpu_set_wide_external");
-  if (!agreed) { T.side_agreed = 0; T.wr_side = 0; return POMGPU_OK; }
+  if (agreed <= 0) { T.side_agreed = 0; T.wr_side = 0; return POMGPU_OK; }
   // "yes" can only come from the host's reduction over all ranks -- which included this rank's own answer
-  if (!pomgpu_transport_side_capable(c)) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: this rank reported that it cannot (the minimum over all ranks is 0)");
+  const int mine = pomgpu_transport_side_capable(c);
+  if (mine < 1 || agreed > mine) return pomgpu_fail(c, POMGPU_EINVAL, "transport_side_agree: %d cannot be the minimum over all ranks, this rank answered %d", agreed, mine);
   if (!T.fn) return POMGPU_OK;                                // RCCL: pomgpu_rccl_init has agreed already, nothing to raise
   T.side_agreed = 1;
-  T.wr_side = getenv("POMGPU_WR_MAIN") ? 0 : 1;               // a process-wide developer switch: callback movers live in one process or one launcher
+  T.wr_side = agreed >= 2 ? 1 : 0;
   return POMGPU_OK;
 }
 // One message round on the SIDE stream: send2[d] -> neighbour d, recv2[d] <- neighbour d.  Every rank must issue its
@@ -283,6 +293,20 @@ int pomgpu_tp_setup(pomgpu_ctx *c, const int *nbr8) {
   return pomgpu_tp_reserve(c, need);   // side_agreed / wr_side: set by pomgpu_tp_rccl before this, 0 after pomgpu_tp_free otherwise
 }
 
+// how many ranks RCCL itself says the communicator has (ncclCommCount): 0 without the RCCL transport, -1 when the library
+// cannot tell.  bench.py puts it on its line: a scaling number then shows that RCCL connected N ranks.
+extern "C" int pomgpu_rccl_nranks(pomgpu_ctx *c) {
+#ifndef POMGPU_EMU
+  if (!c || !c->tp.on || !c->tp.rccl) return 0;
+  RcclComm *r = (RcclComm *)c->tp.rccl;
+  int n = -1;
+  if (!g_rccl.CommCount || g_rccl.CommCount(r->comm, &n) != ncclSuccess) return -1;
+  return n;
+#else
+  (void)c;
+  return 0;
+#endif
+}
 extern "C" long pomgpu_exchange_rounds(pomgpu_ctx *c) { return c ? c->tp.rounds : 0; }
 extern "C" long pomgpu_exchange_rounds_side(pomgpu_ctx *c) { return c ? c->tp.rounds_side : 0; }
 
@@ -299,38 +323,54 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
     delete r;
     return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: ncclCommInitRank: %s", g_rccl.GetErrorString(e));
   }
-  // the side stream's communicator: the same ranks, split off the first (collective, like the init above).  Without
-  // ncclCommSplit the library keeps every round on the main stream.
-  const char *tf = getenv("POMGPU_TEST_SPLIT_FAIL_RANK");     // tests: this rank behaves as if its split had failed
-  const bool forced_fail = tf && atoi(tf) == rank;
-  if (g_rccl.CommSplit && !getenv("POMGPU_NO_SIDE_COMM")) {
+  // Everything below that is collective depends on answers every rank gives for itself: its switches, whether it can make a
+  // second stream, whether its library has ncclCommSplit.  So the answers are reduced over the communicator FIRST (one
+  // all-reduce that every rank reaches whatever it answers) and only what ALL ranks agreed on is then done by all of them:
+  //   v[0] may a second communicator be split off (min)      v[1] may wr go to the side stream (min)
+  //   v[2], v[3] the digest of the switches every rank must share and its negative (min of both: equal iff all ranks agree)
+  // A rank on which an all-reduce itself fails leaves with an error; its partners' deadline (bench.py, the host's own) ends
+  // them -- they cannot be told.
+  auto allmin = [&](int *v, int n) -> const char * {          // NULL = done, v holds the minimum over the ranks
+    int *d = NULL;
+    bool ok = hipMalloc((void **)&d, 2 * n * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, v, n * sizeof(int), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ncclResult_t ea = ncclSuccess;
+    if (ok) ea = g_rccl.AllReduce(d, d + n, n, ncclInt32, ncclMin, r->comm, c->stream);
+    ok = ok && ea == ncclSuccess && hipMemcpyAsync(v, d + n, n * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? NULL : (ea != ncclSuccess ? g_rccl.GetErrorString(ea) : "HIP");
+  };
+  auto give_up = [&](const char *what, const char *why) {
+    if (r->comm2) (void)g_rccl.CommDestroy(r->comm2);
+    (void)g_rccl.CommDestroy(r->comm);
+    delete r;
+    return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: %s: %s", what, why);
+  };
+  const int digest = (int)pomgpu_switches_collective_digest(c->sw);
+  int v[4] = {(g_rccl.CommSplit && side_capable_local(c)) ? 1 : 0, SW(c, WR_MAIN) ? 0 : 1, digest, -digest};
+  const int mine_split = v[0];
+  if (const char *why = allmin(v, 4)) return give_up("the ranks' agreement on side-stream rounds failed", why);
+  if (v[2] != -v[3])                                          // every rank sees the same two minima: all of them refuse together
+    return give_up("the ranks were started with different POMGPU_* switch sets",
+                   "ADVCT_SPLIT ADVQ_EXCHANGE PROD_FULL QFILTER_SPLIT UV_FULL_EXCHANGE NO_OVERLAP NO_SIDE_COMM WR_MAIN WIDE_W WIDE_FULL EXT_SPLIT "
+                   "ADVAVE_SEPARATE EDGE_SPLIT choose which message rounds exist: give every rank the same environment");
+  int agreed[2] = {v[0], v[1]};
+  if (agreed[0]) {
+    // the side stream's communicator: the same ranks, split off the first -- collective, entered by ALL ranks or by none
     const ncclResult_t e2 = g_rccl.CommSplit(r->comm, 0, rank, &r->comm2, NULL);
     if (e2 != ncclSuccess) { r->comm2 = NULL; fprintf(stderr, "pomgpu: ncclCommSplit: %s -- message rounds stay on one stream\n", g_rccl.GetErrorString(e2)); }
-  }
-  // Side-stream rounds: all ranks or none.  Every rank contributes (can I: second communicator + second stream + no
-  // switch against it; may wr go there: POMGPU_WR_MAIN unset) and takes the minimum over the communicator.  Every rank
-  // reaches this all-reduce whatever its own answer is; a rank on which it fails leaves with an error (its partners'
-  // deadline -- bench.py, the host's own -- ends them: they cannot be told).
-  int mine[2] = {(r->comm2 != NULL && !forced_fail && side_capable_local(c)) ? 1 : 0, getenv("POMGPU_WR_MAIN") ? 0 : 1};
-  int agreed[2] = {0, 0};
-  {
-    int *dflag = NULL;
-    bool ok = hipMalloc((void **)&dflag, 4 * sizeof(int)) == hipSuccess;
-    ok = ok && hipMemcpyAsync(dflag, mine, sizeof mine, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-    ncclResult_t ea = ncclSuccess;
-    if (ok) ea = g_rccl.AllReduce(dflag, dflag + 2, 2, ncclInt32, ncclMin, r->comm, c->stream);
-    ok = ok && ea == ncclSuccess && hipMemcpyAsync(agreed, dflag + 2, sizeof agreed, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
-    (void)hipFree(dflag);
-    if (!ok) {
-      if (r->comm2) (void)g_rccl.CommDestroy(r->comm2);
-      (void)g_rccl.CommDestroy(r->comm);
-      delete r;
-      return pomgpu_fail(c, POMGPU_EHIP, "rccl_init: the ranks' agreement on side-stream rounds failed: %s", ea != ncclSuccess ? g_rccl.GetErrorString(ea) : "HIP");
+    // tests (a single rank that is its own neighbour, tests/gpu_rccl_self.py): this rank behaves as if its split had failed
+    if (SW(c, TEST_SPLIT_FAIL_RANK) && (int)SWV(c, TEST_SPLIT_FAIL_RANK) == rank) {
+      fprintf(stderr, "pomgpu: POMGPU_TEST_SPLIT_FAIL_RANK=%d is set -- rank %d reports a failed ncclCommSplit (test hook)\n", rank, rank);
+      if (r->comm2) { (void)g_rccl.CommDestroy(r->comm2); r->comm2 = NULL; }
     }
+    int got[1] = {r->comm2 != NULL ? 1 : 0};
+    if (const char *why = allmin(got, 1)) return give_up("the ranks' agreement on the second communicator failed", why);
+    agreed[0] = got[0];
   }
   if (!agreed[0] && r->comm2) { (void)g_rccl.CommDestroy(r->comm2); r->comm2 = NULL; }
-  if (!agreed[0] && mine[0] && rank == 0) fprintf(stderr, "pomgpu: a rank cannot serve side-stream rounds -- every rank keeps its message rounds on one stream\n");
+  if (!agreed[0] && mine_split && rank == 0) fprintf(stderr, "pomgpu: a rank cannot serve side-stream rounds -- every rank keeps its message rounds on one stream\n");
   c->tp.side_agreed = agreed[0];
   c->tp.wr_side = agreed[0] && agreed[1];
   c->tp.rccl = r;

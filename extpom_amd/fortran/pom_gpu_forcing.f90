@@ -21,12 +21,14 @@ subroutine wind
     n = (iint+cont_bry)/iwind+1
     call read_wind_pnetcdf(n, wu, wv)
     rc = pomgpu_set_forcing_record(pom_ctx, 0_c_int, int(n, c_int), c_loc(wu), c_loc(wv))
+    if (rc /= 0) error_status = 1
   end if
   if (iint.eq.1 .or. mod(iint+cont_bry,iwind).eq.0) then         ! :890-902
     if (iint.ne.iend) then
       n = (iint+cont_bry+iwind)/iwind+1
       call read_wind_pnetcdf(n, wu, wv)
       rc = pomgpu_set_forcing_record(pom_ctx, 0_c_int, int(n, c_int), c_loc(wu), c_loc(wv))
+      if (rc /= 0) error_status = 1
     end if
   end if
   call pomgpu_push_con                                           ! iint, time
@@ -47,12 +49,14 @@ subroutine heat
     n = (iint+cont_bry)/iheat+1
     call read_heat_pnetcdf(n, shf, swr)
     rc = pomgpu_set_forcing_record(pom_ctx, 1_c_int, int(n, c_int), c_loc(shf), c_loc(swr))
+    if (rc /= 0) error_status = 1
   end if
   if (iint.eq.1 .or. mod(iint+cont_bry,iheat).eq.0) then         ! :934-946
     if (iint.ne.iend) then
       n = (iint+cont_bry+iheat)/iheat+1
       call read_heat_pnetcdf(n, shf, swr)
       rc = pomgpu_set_forcing_record(pom_ctx, 1_c_int, int(n, c_int), c_loc(shf), c_loc(swr))
+      if (rc /= 0) error_status = 1
     end if
   end if
   call pomgpu_push_con
@@ -73,6 +77,7 @@ subroutine surface
     n = (iint+cont_bry)/isrf+1
     call read_surface_pnetcdf(n, sst, sss)
     rc = pomgpu_set_forcing_record(pom_ctx, 2_c_int, int(n, c_int), c_loc(sst), c_loc(sss))
+    if (rc /= 0) error_status = 1
   end if
   call pomgpu_push_con
   if (pomgpu_surface(pom_ctx) /= 0) error_status = 1
@@ -109,5 +114,6 @@ contains
            c_loc(tbnf), c_loc(sbnf), c_loc(vbnf), c_loc(ubnf), c_loc(tbsf), c_loc(sbsf), c_loc(vbsf), c_loc(ubsf), &
            c_loc(elw), c_loc(ele), c_loc(eln), c_loc(els) /)
     rc = pomgpu_set_lateral_record(pom_ctx, int(n, c_int), a)
+    if (rc /= 0) error_status = 1
   end subroutine
 end subroutine

@@ -18,7 +18,19 @@ subroutine pomgpu_host_connect_mpi
     write(6,'(/''Error: pomgpu_mpi_mover_install failed'')')
     return
   end if
-  rc = pomgpu_set_wide_external(pom_ctx, 1_c_int, int(min_im, c_int), int(min_jm, c_int))   ! EINVAL = tiles too narrow: per-point exchanges stay
+  rc = pomgpu_set_wide_external(pom_ctx, 1_c_int, int(min_im, c_int), int(min_jm, c_int))   ! EINVAL (-1) = tiles too narrow: per-point exchanges stay
+  if (rc /= 0 .and. rc /= -1) then                               ! anything else (device memory, HIP) is an error of the run
+    error_status = 1
+    write(6,'(/''Error: pomgpu_set_wide_external failed'')')
+  end if
+end subroutine
+
+! end of a multi-rank run, before pomgpu_host_finalize: the mover leaves the context and gives its pinned buffers back
+subroutine pomgpu_host_disconnect_mpi
+  use pomgpu_iface
+  implicit none
+  include 'pom.h'
+  if (pomgpu_mpi_mover_remove(pom_ctx) /= 0) error_status = 1
 end subroutine
 
 subroutine sum0d_mpi(work, to)

@@ -123,6 +123,7 @@ program pom_gpu_mpi_main
     write(6,'(a,i4,a,i7,a,i7)') 'message rounds per step on rank 0: ', int(pomgpu_exchange_rounds(pom_ctx))/max(nsteps,1), &
                                  '  total ', int(pomgpu_exchange_rounds(pom_ctx)), '  on the second stream ', int(pomgpu_exchange_rounds_side(pom_ctx))
   end if
+  call pomgpu_host_disconnect_mpi
   call pomgpu_host_finalize
   call mpi_allreduce(mpi_in_place, error_status, 1, mpi_integer, mpi_max, pom_comm, ierr)
   if (my_task == 0) write(6,'(a,i6,a,i3,a,i3)') 'pom_gpu_mpi_main: steps ', nsteps, '  ranks ', nranks, '  error_status ', error_status

@@ -53,6 +53,9 @@ module pomgpu_iface
     integer(c_int) function pomgpu_mpi_mover_install(ctx, fcomm, neighbours8) bind(C, name='pomgpu_mpi_mover_install')
       import; type(c_ptr), value :: ctx; integer(c_int), value :: fcomm; integer(c_int) :: neighbours8(8)
     end function
+    integer(c_int) function pomgpu_mpi_mover_remove(ctx) bind(C, name='pomgpu_mpi_mover_remove')   ! before pomgpu_host_finalize: frees the pinned staging buffers
+      import; type(c_ptr), value :: ctx
+    end function
     integer(c_long) function pomgpu_exchange_rounds_side(ctx) bind(C, name='pomgpu_exchange_rounds_side')
       import; type(c_ptr), value :: ctx
     end function

@@ -73,6 +73,9 @@ _SIGS = {
     "pomgpu_rccl_init": (_I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.c_char_p]),
     "pomgpu_transport_side_capable": (_I, [_P]),
     "pomgpu_transport_side_agree": (_I, [_P, _I]),
+    "pomgpu_switch_digest": (ctypes.c_uint, [_P]),
+    "pomgpu_rccl_nranks": (_I, [_P]),
+    "pomgpu_debug_switch": (_I, [_P, ctypes.c_char_p, ctypes.c_char_p]),
     "pomgpu_exchange_rounds": (ctypes.c_long, [_P]),
     "pomgpu_exchange_rounds_side": (ctypes.c_long, [_P]),
     "pomgpu_set_wide_external": (_I, [_P, _I, _I, _I]),

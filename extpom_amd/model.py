@@ -135,8 +135,25 @@ class PomGpu:
         return int(self.L.pomgpu_transport_side_capable(self.h))
 
     def side_agree(self, agree):
-        """collective: agree(mine) must return the minimum of `mine` over all ranks of the decomposition"""
+        """collective: agree(mine) must return the minimum of `mine` over all ranks of the decomposition.  The ranks first
+        compare the digest of the switches that choose which message rounds exist (pomgpu.h): ranks started with different
+        POMGPU_* sets are all refused here instead of hanging in a later round."""
+        d = int(self.L.pomgpu_switch_digest(self.h))
+        lo, hi = int(agree(d)), -int(agree(-d))
+        if lo != hi:
+            raise PomGpuError("the ranks were created under different POMGPU_* switch sets (those that choose the message rounds): "
+                              "give every rank the same environment")
         self._chk(self.L.pomgpu_transport_side_agree(self.h, int(agree(self.side_capable()))), "transport_side_agree")
+
+    def switch(self, name: str, value=None):
+        """one developer switch of this live context (pomgpu_debug_switch): value None unsets it.  The library reads its
+        switches from the environment once, when the context is created."""
+        v = None if value is None else str(value).encode()
+        self._chk(self.L.pomgpu_debug_switch(self.h, name.encode(), v), "debug_switch")
+
+    def rccl_nranks(self) -> int:
+        """what ncclCommCount says about the transport's communicator (0: no RCCL transport)"""
+        return int(self.L.pomgpu_rccl_nranks(self.h))
 
     def rccl_init(self, tile, id128: bytes, rank: int, nranks: int, librccl: str | None = None):
         """production mover: grouped ncclSend / ncclRecv on the library's stream"""

@@ -163,14 +163,22 @@ int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, c
                      const char *librccl_path);
 /* Message rounds on the library's SECOND stream (the early part of the wide exchange, wr) are a decision every rank of
  * the decomposition must take alike: a rank that kept them on the first stream while its neighbours moved them would post
- * its rounds in another order on another communicator, and the job would hang.  pomgpu_rccl_init agrees on it itself
- * (one ncclAllReduce(min) over the ranks' own answers: second communicator split off, second stream created,
- * POMGPU_NO_OVERLAP / POMGPU_NO_SIDE_COMM / POMGPU_WR_MAIN not set -- all ranks or none).  With a callback mover the
- * library cannot reach the other ranks: side rounds stay OFF until the host has reduced pomgpu_transport_side_capable()
- * (1 / 0, this rank) to its minimum over ALL ranks and handed the result to pomgpu_transport_side_agree() on every rank,
- * after pomgpu_set_transport and before pomgpu_set_wide_external.  agreed = 0 is accepted with any transport. */
+ * its rounds in another order on another communicator, and the job would hang.  pomgpu_rccl_init agrees on it itself,
+ * BEFORE anything collective depends on a rank's own answer: one ncclAllReduce(min) over the first communicator of every
+ * rank's (a) willingness to split a second communicator off (ncclCommSplit present, second stream created, neither
+ * POMGPU_NO_OVERLAP nor POMGPU_NO_SIDE_COMM in the switches its context was created under), (b) POMGPU_WR_MAIN unset, and
+ * (c) a digest of the switches that choose which message rounds exist -- ranks started with different switch sets are all
+ * refused with a message (POMGPU_EHIP) instead of hanging later; only if ALL ranks are willing does any of them enter
+ * ncclCommSplit, and a second all-reduce settles whether every split succeeded.  With a callback mover the library cannot
+ * reach the other ranks: side rounds stay OFF until the host has reduced pomgpu_transport_side_capable() (this rank: 0 =
+ * cannot, 1 = can but wants wr on the main stream, 2 = can) to its minimum over ALL ranks and handed the result to
+ * pomgpu_transport_side_agree() on every rank, after pomgpu_set_transport and before pomgpu_set_wide_external.  agreed = 0
+ * is accepted with any transport.  pomgpu_switch_digest: the digest of (c), for such hosts to compare over their ranks. */
 int pomgpu_transport_side_capable(pomgpu_ctx *ctx);
 int pomgpu_transport_side_agree(pomgpu_ctx *ctx, int agreed);
+unsigned pomgpu_switch_digest(pomgpu_ctx *ctx);
+/* how many ranks RCCL itself reports for the communicator (ncclCommCount): 0 without the RCCL transport, -1 if unknown */
+int pomgpu_rccl_nranks(pomgpu_ctx *ctx);
 /* message rounds served by the transport since it was set (measurement) */
 long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
 /* ... of them on the library's second stream (the early part of the wide exchange, wr): beside kernels, not between them */
@@ -195,9 +203,21 @@ int pomgpu_set_wide_external(pomgpu_ctx *ctx, int on, int min_im, int min_jm);
 
 /* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
 int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
+/* With the wide-halo mode and side-stream rounds agreed, pomgpu_lateral_viscosity also starts the EARLY part of the wide
+ * exchange on the second stream, and pomgpu_mode_interaction then sends only the late part.  Between the two calls nothing
+ * may be called on ONE rank only that looks at the state (download, domain_stats, set_forcing_record ...): such a call joins
+ * the side stream, after which that rank would gather everything in one round while its neighbours post the late part --
+ * unequal message counts.  The reference's own sequence (advance.f:14-21) and pomgpu_advance satisfy this by construction. */
 int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */
 int pomgpu_mode_interaction(pomgpu_ctx *ctx);    /* advance.f:144-202 */
-int pomgpu_mode_external(pomgpu_ctx *ctx);       /* advance.f:205-353; uses blkcon.iext */
+/* advance.f:205-353; uses blkcon.iext.  One call per substep, as the reference makes them (advance.f:27-29).  PAIRING: on a
+ * tile large enough for the two-substeps-per-pass kernel an ODD substep is held back (the call returns POMGPU_OK with nothing
+ * launched) until the next call: if that is substep iext + 1 the two run as one pass and elf, uaf, vaf are stored for the
+ * SECOND substep only (nobody reads the first's: the reference overwrites them in the next call); any other entry point, a
+ * download or pomgpu_sync first runs the held substep alone (with its elf, uaf, vaf stored) under the scalars of the LAST
+ * pomgpu_set_con -- do not change blkcon between the two calls of a pair.  If the held substep fails when it finally runs,
+ * the context is marked failed: error_status = 1 and the next entry point / pomgpu_get_con reports it. */
+int pomgpu_mode_external(pomgpu_ctx *ctx);
 int pomgpu_mode_internal(pomgpu_ctx *ctx);       /* advance.f:356-537 */
 /* advance.f:611-641; any of the out pointers may be NULL.  Synchronises the stream. */
 int pomgpu_check_velocity(pomgpu_ctx *ctx, double *vamax, int *imax, int *jmax);
@@ -242,6 +262,9 @@ int pomgpu_advct(pomgpu_ctx *ctx);               /* solver.f:201-408 */
 int pomgpu_advq(pomgpu_ctx *ctx, const double *qb, const double *q, const double *qf);   /* :411-477 */
 int pomgpu_advt1(pomgpu_ctx *ctx, const double *fb, const double *f, const double *fclim, const double *ff); /* :480-574 */
 int pomgpu_advt2(pomgpu_ctx *ctx, const double *fb, const double *f, const double *fclim, const double *ff); /* :577-731 */
+/* smol_adif(xmassflux,ymassflux,zwflux,ff) (solver.f:1880-1967) is the ONE routine of SURVEY 8(b)'s export list without an
+ * entry point: its three flux arguments are automatic (stack) arrays of advt2 (solver.f:588-590), never COMMON arrays, so a
+ * host has nothing to pass by reference; it runs inside pomgpu_advt2 (nitera > 1: k_advt2_smol; nitera = 1: fused away). */
 int pomgpu_advu(pomgpu_ctx *ctx);                /* solver.f:734-788 */
 int pomgpu_advv(pomgpu_ctx *ctx);                /* solver.f:791-845 */
 int pomgpu_baropg(pomgpu_ctx *ctx);              /* solver.f:848-940 */
@@ -271,6 +294,9 @@ int pomgpu_prof_end(pomgpu_ctx *ctx);
 int pomgpu_prof_count(pomgpu_ctx *ctx);
 int pomgpu_prof_get(pomgpu_ctx *ctx, int k, const char **name, long *launches, double *total_ms);
 
+/* developer switches are read from the environment ONCE, at pomgpu_create; this changes one of a live
+ * context afterwards (name with or without "POMGPU_", value NULL = unset).  Tools and tests only. */
+int pomgpu_debug_switch(pomgpu_ctx *ctx, const char *name, const char *value);
 const char *pomgpu_version(void);
 /* a digest of the sources this library was built from (measurement bookkeeping: profiles/traffic.json names the build its
  * counters were taken from) */

@@ -141,7 +141,7 @@ def test_fortran_mpi_driver_and_mover_build():
     (hot path, ranks, forcing, I/O) and leaves no reference routine of the hot path undefined"""
     exe = _build_mpi(34, 26, 4)
     out = subprocess.run(["nm", "-D", os.path.join(ROOT, "extpom_amd", "csrc", "libpomgpu_mpi.so")], capture_output=True, text=True).stdout
-    assert " T pomgpu_mpi_mover_install" in out
+    assert " T pomgpu_mpi_mover_install" in out and " T pomgpu_mpi_mover_remove" in out
     out = subprocess.run(["nm", exe], capture_output=True, text=True).stdout
     defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     for name in ("wind heat surface lateral_bc write_output_pnetcdf write_restart_pnetcdf sum0d_mpi bcast0d_mpi pomgpu_host_connect_mpi "

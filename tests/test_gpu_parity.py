@@ -567,12 +567,9 @@ def test_config4_2048x1536x50_full_size():
     # per wavefront ...) -- the same bits
     ga.run(20)
     general = {"POMGPU_EXT_NOPAIR": "1", "POMGPU_EXT_NOMARCH": "1", "POMGPU_PROFQ_ROWS2": "1", "POMGPU_PROFQ_NOPACE": "1", "POMGPU_COL_STRIP": "0"}
-    os.environ.update(general)
-    try:
-        gc.run(20)
-    finally:
-        for k in general:
-            os.environ.pop(k, None)
+    for k, v in general.items():                     # switches are read when a context is created: these change the live one
+        gc.switch(k, v)
+    gc.run(20)
     ga.download()
     gc.download()
     ga.close()

@@ -150,3 +150,53 @@ def test_host_libm_is_the_one_the_pow_clone_restates(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tools", "check_glibc_pow_clone.c"), "-o", str(exe), "-lm"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300).stdout
     assert "x**1.5: 0 mismatches" in out and "general x**y: 0 mismatches" in out, out
+
+
+def _bench_selftest(plan, gpus, extra=(), limit="10"):
+    """bench.py --gpus N with stand-in ranks (POM_BENCH_SELFTEST: no GPU; what the rank SUPERVISORS make of passes that
+    complete, hang or die is what runs here -- the real code path of the launcher, the supervisors and their rendezvous)"""
+    import json
+    env = dict(os.environ, POM_BENCH_REHEARSE="1", POM_BENCH_SELFTEST=json.dumps(plan), POM_BENCH_PASS_LIMIT=limit)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_multi_gpu_passes_survive_a_hang_and_a_dead_rank():
+    """north_star's multi-GPU line must not be losable: the ranks' supervisors run a pass with every round on one stream, a
+    pass with the second stream and communicator, and a pass on the alternate tile grid, each as fresh child processes.  A
+    pass whose rank hangs (here: rank 1 of the overlapped pass never posts) is ended at its limit and named, a pass whose rank
+    dies (rank 2 of the alternate-grid pass) ends at once on every rank -- and the line still carries the passes that completed,
+    ONE line, with the tile grids BASELINE names (2x4 beside 1x8 would be --gpus 8: four ranks here)."""
+    r, lines = _bench_selftest({"hang": [1, 1], "fail": [2, 2]}, 4, ["--workload", "basin2048"], limit="6")
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
+    out = lines[0]
+    ps = out["passes"]
+    assert [(p["tiles"], p["overlap"], p["ok"]) for p in ps] == [("1x4", False, True), ("1x4", True, False), ("2x2", False, False)], ps
+    assert out["config"]["tiles"] == "1x4" and out["config"]["tiles_primary"] == "1x4" and ps[0]["primary"]
+    assert out["config"]["no_overlap_env"] == "1"                       # pass 0 ran with POMGPU_NO_OVERLAP=1
+    assert "no result within" in ps[1]["failed"]["first"] and set(ps[1]["failed"]["phase_by_rank"].values()) == {"connect"}
+    assert ps[2]["failed"]["why_by_rank"]["2"] == "exit code 9" and ps[2]["wall_s"] < 6.0      # the dead rank ended the pass at once, not at the limit
+    # everything healthy: the faster pass (overlap on, in the stand-in's numbers) is the line's value, the alternate grid under it
+    r, lines = _bench_selftest({}, 2, ["--workload", "basin1024", "--tiles", "2x1"])
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
+    out = lines[0]
+    assert [(p["tiles"], p["overlap"], p["ok"]) for p in out["passes"]] == [("2x1", False, True), ("2x1", True, True), ("1x2", True, True)]
+    assert out["config"]["overlap"] is True and out["ms_per_step"] == 8.0 and out["passes"][1]["primary"]
+    # nothing completes: no line, non-zero exit
+    r, lines = _bench_selftest({"fail": [0, 0]}, 2, ["--only-pass", "0"])
+    assert r.returncode != 0 and not lines
+
+
+def test_bench_tile_grids_follow_baseline_configs():
+    """configs[2] names "2x4 tile decomposition on 8 GPUs" for 1024x1024x40; configs[3] (2048x1536x50) names none: whole rows
+    there.  The other grid is always measured beside the primary (parallel_mpi.f:54-65 leaves the split to im_local, jm_local)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.tile_grids("basin1024", 8) == ("2x4", "1x8")
+    assert bench.tile_grids("basin2048", 8) == ("1x8", "2x4")
+    assert bench.tile_grids("basin2048", 8, "2x4") == ("2x4", "1x8")
+    assert bench.tile_grids("basin2048", 4) == ("1x4", "2x2") and bench.tile_grids("basin2048", 2)[0] == "1x2"
+    with pytest.raises(SystemExit):
+        bench.tile_grids("basin2048", 8, "3x3")

@@ -133,7 +133,7 @@ OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
 
 
 def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None,
-              by_routine=False, records=False, dte=6.0, side_fail_rank=None, side_rounds=None):
+              by_routine=False, records=False, dte=6.0, side_fail_rank=None, side_rounds=None, rank_switches=None, errors=None):
     world = nx * ny
     IMg, JMg = grid or (IM, JM)
     iml, jml = decomp.local_size(IMg, JMg, nx, ny)
@@ -145,6 +145,8 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
             tile = tiles[r]
             st = make_case(case, IMg, JMg, KB, tile=tile, dte=dte, isplit=isplit, **nml)
             g = PomGpu(st, libpath=EMU)
+            for k, v in (rank_switches or {}).get(r, {}).items():   # as if this rank alone had been started with POMGPU_<k>=v
+                g.switch(k, v)
             count = [0]
 
             def hook(ptrs, nzs):
@@ -157,7 +159,7 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
             if library_exchange:                     # the library packs, moves and unpacks by itself
                 # side-stream rounds: the ranks' own answers reduced to their minimum (side_fail_rank: that rank says no)
                 g.set_transport(tile, lambda *a: transport(board, tile, *a),
-                                agree=lambda mine: board.allmin(r, 0 if r == side_fail_rank else mine))
+                                agree=lambda mine: board.allmin(r, 0 if (r == side_fail_rank and mine in (1, 2)) else mine))   # 1, 2: the capability answers (pomgpu.h); the switch digest passes unchanged
                 if wide:
                     assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
             else:
@@ -204,13 +206,17 @@ def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=Fals
                 side_rounds[r] = g.exchange_rounds_side()
         except Exception as e:                      # a dead rank must not leave the others at the barrier
             errs.append(e)
-            board.barrier.abort()
+            if "different POMGPU_* switch sets" not in str(e):    # that refusal every rank reaches by itself: nobody is left waiting
+                board.barrier.abort()
 
     threads = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    if errors is not None:
+        errors.extend(errs)
+        return out
     assert not errs, errs
     return out
 
@@ -298,6 +304,29 @@ def test_side_stream_rounds_are_a_collective_decision():
     assert set(side_all.values()) == {2 * STEPS}, side_all             # early gather + wr, every step, every rank
     for r in main_all:       # per step: 8 rounds between kernels + 2 beside them, or 9 between kernels (wr back, the gather one round instead of early + late)
         assert main_one[r] == main_all[r] + STEPS, (main_one, main_all, side_all)
+
+
+def test_ranks_with_different_switch_sets_are_refused_together():
+    """One rank of 2x2 was started with POMGPU_NO_SIDE_COMM (or any other switch that chooses which message rounds exist and
+    where they run): the ranks compare a digest of those switches before anything collective depends on them and ALL of them
+    refuse with a message -- nobody enters a round its neighbours will not post (transport.hip does the same over the RCCL
+    communicator before ncclCommSplit).  A switch that only picks a kernel shape may differ from rank to rank."""
+    from extpom_amd.lib import PomGpuError
+    errs = []
+    run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, rank_switches={1: {"POMGPU_NO_SIDE_COMM": "1"}}, errors=errs)
+    refused = [e for e in errs if isinstance(e, PomGpuError) and "different POMGPU_* switch sets" in str(e)]
+    assert len(refused) == 4, errs                                     # every rank, by itself, before the first step
+    side = {}
+    out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, rank_switches={1: {"PROFQ_ROWS2": "1", "NO_LIN": "1"}},
+                    side_rounds=side)
+    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10, ghosts=False)
+    assert set(side.values()) == {2 * STEPS}, side
+    # the same switch on EVERY rank is an agreement, not a difference: all of them keep their rounds on the main stream
+    side = {}
+    out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT,
+                    rank_switches={r: {"NO_SIDE_COMM": "1"} for r in range(4)}, side_rounds=side)
+    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=10, ghosts=False)
+    assert set(side.values()) == {0}, side
 
 
 def test_wide_halo_too_narrow_shows_up(monkeypatch):

@@ -32,7 +32,7 @@ for spec in args:
     env = dict(p.split("=", 1) for p in parts[1:])
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    if lib == "@":                  # same context as the previous variant: only the environment differs (switches read at launch time)
+    if lib == "@":                  # same context as the previous variant: only the switches differ (set on the live context per turn)
         g = variants[-1][2]
     elif lib.startswith("@"):       # the previous variant's context (its memory) driven by ANOTHER build of the library: the handle is a
         import copy                 # plain C struct of the same layout -- for variants that differ in kernel code only
@@ -40,7 +40,11 @@ for spec in args:
         g.L = _lib.load(os.path.join(ROOT, lib[1:]))
     else:
         g = PomGpu(st0, device=0, libpath=os.path.join(ROOT, lib) if lib else None)
+    for k, v in env.items():
+        if k.startswith("POMGPU_") and k != "POMGPU_LIBPATH": g.switch(k, v)
     g.run(2); g.sync()
+    for k in env:
+        if k.startswith("POMGPU_") and k != "POMGPU_LIBPATH": g.switch(k, None)
     for k, v in old.items():
         os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     variants.append((tag, env, g, {}))
@@ -50,7 +54,11 @@ for r in range(rounds):
     for tag, env, g, acc in variants:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
+        for k, v in env.items():            # the library reads its switches at pomgpu_create: a variant's are set on the live context for its turn
+            if k.startswith("POMGPU_") and k != "POMGPU_LIBPATH": g.switch(k, v)
         g.prof_begin(); g.run(1); prof = g.prof_end()
+        for k in env:
+            if k.startswith("POMGPU_") and k != "POMGPU_LIBPATH": g.switch(k, None)
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         prof.pop("msg_round", None)
