@@ -211,8 +211,10 @@ def cpu_baseline_sample(workload, reference):
     d = _child_json(["--cpu-sample", "--workload", workload] + (["--reference"] if reference else []), 240)
     who = ("the reference's own sources (solver.f advance.f bounds_forcing.f, AMD flang -O2; linked with input hooks for the PnetCDF "
            "readers this image lacks, oracle/ref_traps.c)") if reference else "the plain-C oracle (gcc -O2)"
+    _, im, jm, _, _ = WORKLOADS[workload]
     return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "reference" if reference else "port",
-            "sample": f"SAMPLE {d['what']} (1/64 of the bench grid's area), {d['n']} internal steps of {who}, {d['seconds']:.1f} s"}
+            "sample": f"SAMPLE {d['what']} (1/{round(im * jm / (sim * sjm))} of the bench grid's area: a working set that much friendlier to the caches), "
+                      f"{d['n']} internal steps of {who}, {d['seconds']:.1f} s"}
 
 
 def cpu_baseline_all_cores(workload):

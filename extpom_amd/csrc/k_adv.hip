@@ -292,10 +292,11 @@ __device__ __forceinline__ void c_advt1(const KP &P, const int i, const int j, c
   G3(ff, i, j, k) = (fbr * (h_(i, j) + F2(etb, i, j)) * art - P.dti2 * r) / ((h_(i, j) + F2(etf, i, j)) * art);
 }
 // f(:,:,kb) = f(:,:,kbm1)  (solver.f:495)
-__global__ void k_copy_kb(KP P, double *f) {
+__global__ void k_copy_kb(KP P, double *f, double *g) {
   const int i = TID_I, j = TID_J;
   if (i > P.iml || j > P.jml) return;
   G3(f, i, j, P.kb) = G3(f, i, j, P.kbm1);
+  if (g) G3(g, i, j, P.kb) = G3(g, i, j, P.kbm1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -872,9 +873,9 @@ void launch_q_filter_rim(pomgpu_ctx *c) {
 void launch_mask_q(pomgpu_ctx *c) { LAUNCH(c, k_mask_q, gridm(c->P), blk2(), c->P); }
 void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff) {
   LAUNCH(c, k_advt1, gridm(c->P), blk2(), c->P, (const double *)fb, (const double *)f, fclim, ff);
-  LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f);
+  LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f, (double *)NULL);
 }
-void launch_copy_kb(pomgpu_ctx *c, double *f) { LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f); }
+void launch_copy_kb(pomgpu_ctx *c, double *f, double *g) { LAUNCH(c, k_copy_kb, grid2(c->P), blk2(), c->P, f, g); }
 void launch_advt2_mass(pomgpu_ctx *c) { LAUNCH(c, k_advt2_mass, gridm(c->P), blk2(), c->P); }
 void launch_advt2_step(pomgpu_ctx *c, const double *fbmem, const double *f, const double *eta, double *ff, int itera) {
   LAUNCH(c, k_advt2_step, gridm(c->P), blk2(), c->P, fbmem, f, eta, ff, itera);

@@ -300,7 +300,17 @@ void launch_bcondorl3(pomgpu_ctx *c) {
 // ---- halo pack / unpack (parallel_mpi.f:154-351 pack loops) ----------------------------------------
 // One launch moves the edge columns (dir 0) or rows (dir 1) of up to 8 arrays.  grid.x covers the
 // edge length, grid.y the levels of the deepest array, grid.z the arrays.
-struct HaloArgs { double *ptr[8]; int nz[8]; size_t off[8]; int count; };
+// st[a]: array a lives in the storage type of the 3-D arrays (blk3d, the 3-D scratch arrays: fp32 in the fp32-storage
+// variant), else it is a 2-D array of doubles.  The staging buffers always carry doubles: a stored fp32 value is widened
+// on the way out and rounds back to itself on the way in, so one message may mix 2-D and 3-D arrays.
+struct HaloArgs { double *ptr[8]; int nz[8]; size_t off[8]; int count; unsigned char st[8]; };
+#ifdef POMGPU_STORE_F32
+#define HGET(p, i, j, k) (A.st[a] ? (double)G3(p, i, j, k) : (p)[IX3(i, j, k)])
+#define HPUT(p, i, j, k, v) do { if (A.st[a]) G3(p, i, j, k) = (v); else (p)[IX3(i, j, k)] = (v); } while (0)
+#else
+#define HGET(p, i, j, k) G3(p, i, j, k)
+#define HPUT(p, i, j, k, v) G3(p, i, j, k) = (v)
+#endif
 __global__ void k_halo_pack(KP P, HaloArgs A, int dir, double *to_lo, double *to_hi) {
   const int t = TID_I, k = (int)blockIdx.y + 1, a = (int)blockIdx.z;
   const int len = dir == 0 ? P.jm : P.im;
@@ -308,11 +318,11 @@ __global__ void k_halo_pack(KP P, HaloArgs A, int dir, double *to_lo, double *to
   const double *p = A.ptr[a];
   const size_t o = A.off[a] * (size_t)len + (size_t)(k - 1) * len + (size_t)(t - 1);
   if (dir == 0) {
-    if (to_lo) to_lo[o] = G3(p, 2, t, k);
-    if (to_hi) to_hi[o] = G3(p, P.imm1, t, k);
+    if (to_lo) to_lo[o] = HGET(p, 2, t, k);
+    if (to_hi) to_hi[o] = HGET(p, P.imm1, t, k);
   } else {
-    if (to_lo) to_lo[o] = G3(p, t, 2, k);
-    if (to_hi) to_hi[o] = G3(p, t, P.jmm1, k);
+    if (to_lo) to_lo[o] = HGET(p, t, 2, k);
+    if (to_hi) to_hi[o] = HGET(p, t, P.jmm1, k);
   }
 }
 __global__ void k_halo_unpack(KP P, HaloArgs A, int dir, const double *from_lo, const double *from_hi) {
@@ -322,11 +332,11 @@ __global__ void k_halo_unpack(KP P, HaloArgs A, int dir, const double *from_lo, 
   double *p = A.ptr[a];
   const size_t o = A.off[a] * (size_t)len + (size_t)(k - 1) * len + (size_t)(t - 1);
   if (dir == 0) {
-    if (from_lo) G3(p, 1, t, k) = from_lo[o];
-    if (from_hi) G3(p, P.im, t, k) = from_hi[o];
+    if (from_lo) HPUT(p, 1, t, k, from_lo[o]);
+    if (from_hi) HPUT(p, P.im, t, k, from_hi[o]);
   } else {
-    if (from_lo) G3(p, t, 1, k) = from_lo[o];
-    if (from_hi) G3(p, t, P.jm, k) = from_hi[o];
+    if (from_lo) HPUT(p, t, 1, k, from_lo[o]);
+    if (from_hi) HPUT(p, t, P.jm, k, from_hi[o]);
   }
 }
 // ---- single-phase exchange with up to eight neighbours -------------------------------------------------
@@ -345,20 +355,20 @@ __global__ void k_halo_pack8(KP P, HaloArgs A, Halo8 to) {
   const double *p = A.ptr[a];
   if (t <= P.jm) {
     const size_t o = A.off[a] * (size_t)P.jm + (size_t)(k - 1) * P.jm + (size_t)(t - 1);
-    if (to.b[0]) to.b[0][o] = G3(p, 2, t, k);
-    if (to.b[1]) to.b[1][o] = G3(p, P.imm1, t, k);
+    if (to.b[0]) to.b[0][o] = HGET(p, 2, t, k);
+    if (to.b[1]) to.b[1][o] = HGET(p, P.imm1, t, k);
   }
   if (t <= P.im) {
     const size_t o = A.off[a] * (size_t)P.im + (size_t)(k - 1) * P.im + (size_t)(t - 1);
-    if (to.b[2]) to.b[2][o] = G3(p, t, 2, k);
-    if (to.b[3]) to.b[3][o] = G3(p, t, P.jmm1, k);
+    if (to.b[2]) to.b[2][o] = HGET(p, t, 2, k);
+    if (to.b[3]) to.b[3][o] = HGET(p, t, P.jmm1, k);
   }
   if (t == 1) {
     const size_t o = A.off[a] + (size_t)(k - 1);
-    if (to.b[4]) to.b[4][o] = G3(p, 2, 2, k);
-    if (to.b[5]) to.b[5][o] = G3(p, P.imm1, 2, k);
-    if (to.b[6]) to.b[6][o] = G3(p, 2, P.jmm1, k);
-    if (to.b[7]) to.b[7][o] = G3(p, P.imm1, P.jmm1, k);
+    if (to.b[4]) to.b[4][o] = HGET(p, 2, 2, k);
+    if (to.b[5]) to.b[5][o] = HGET(p, P.imm1, 2, k);
+    if (to.b[6]) to.b[6][o] = HGET(p, 2, P.jmm1, k);
+    if (to.b[7]) to.b[7][o] = HGET(p, P.imm1, P.jmm1, k);
   }
 }
 __global__ void k_halo_unpack8(KP P, HaloArgs A, Halo8 from) {
@@ -368,20 +378,20 @@ __global__ void k_halo_unpack8(KP P, HaloArgs A, Halo8 from) {
   const int jlo = P.S ? 1 : 2, jhi = P.N ? P.jm : P.jmm1, ilo = P.W ? 1 : 2, ihi = P.E ? P.im : P.imm1;
   if (t >= jlo && t <= jhi) {
     const size_t o = A.off[a] * (size_t)P.jm + (size_t)(k - 1) * P.jm + (size_t)(t - 1);
-    if (from.b[0]) G3(p, 1, t, k) = from.b[0][o];
-    if (from.b[1]) G3(p, P.im, t, k) = from.b[1][o];
+    if (from.b[0]) HPUT(p, 1, t, k, from.b[0][o]);
+    if (from.b[1]) HPUT(p, P.im, t, k, from.b[1][o]);
   }
   if (t >= ilo && t <= ihi) {
     const size_t o = A.off[a] * (size_t)P.im + (size_t)(k - 1) * P.im + (size_t)(t - 1);
-    if (from.b[2]) G3(p, t, 1, k) = from.b[2][o];
-    if (from.b[3]) G3(p, t, P.jm, k) = from.b[3][o];
+    if (from.b[2]) HPUT(p, t, 1, k, from.b[2][o]);
+    if (from.b[3]) HPUT(p, t, P.jm, k, from.b[3][o]);
   }
   if (t == 1) {
     const size_t o = A.off[a] + (size_t)(k - 1);
-    if (from.b[4]) G3(p, 1, 1, k) = from.b[4][o];
-    if (from.b[5]) G3(p, P.im, 1, k) = from.b[5][o];
-    if (from.b[6]) G3(p, 1, P.jm, k) = from.b[6][o];
-    if (from.b[7]) G3(p, P.im, P.jm, k) = from.b[7][o];
+    if (from.b[4]) HPUT(p, 1, 1, k, from.b[4][o]);
+    if (from.b[5]) HPUT(p, P.im, 1, k, from.b[5][o]);
+    if (from.b[6]) HPUT(p, 1, P.jm, k, from.b[6][o]);
+    if (from.b[7]) HPUT(p, P.im, P.jm, k, from.b[7][o]);
   }
 }
 static int halo_args(pomgpu_ctx *c, double *const *dev, const int *nz, int count, HaloArgs &A, int &nzmax) {
@@ -389,10 +399,16 @@ static int halo_args(pomgpu_ctx *c, double *const *dev, const int *nz, int count
   size_t off = 0;
   nzmax = 0;
   A.count = count;
-  for (int n = 0; n < 8; n++) { A.ptr[n] = NULL; A.nz[n] = 0; A.off[n] = 0; }
+  for (int n = 0; n < 8; n++) { A.ptr[n] = NULL; A.nz[n] = 0; A.off[n] = 0; A.st[n] = 0; }
   for (int n = 0; n < count; n++) {
     if (!dev[n] || nz[n] < 1 || nz[n] > c->P.kb) return -1;
     A.ptr[n] = dev[n]; A.nz[n] = nz[n]; A.off[n] = off;
+    {                                                         // inside blk3d or a 3-D scratch array?
+      const KP &P = c->P;
+      bool st = !(c->flags & POMGPU_CTX_2D) && P.b3 && dev[n] >= P.b3 && dev[n] < P.b3 + (size_t)POM_NBLK3D * P.a3;
+      for (int q = 0; q < POMGPU_NSCR3 && !st; q++) st = P.s3[q] && dev[n] >= P.s3[q] && dev[n] < P.s3[q] + P.n3;
+      A.st[n] = st ? 1 : 0;
+    }
     off += (size_t)nz[n];
     if (nz[n] > nzmax) nzmax = nz[n];
   }

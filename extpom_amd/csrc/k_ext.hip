@@ -812,6 +812,13 @@ __device__ __forceinline__ double west_true(double x, double w, int lane) {
   return lane == 0 ? w : t;
 }
 #endif
+// AHEAD (small tiles: the extended tile of a 4- or 8-tile split): the 22 pointwise operands of row j + 1 are requested while row j is
+// worked on, like the stencil rows always were.  With as many wavefronts as the chip has SIMDs (the launcher picks the segment height
+// for that) nobody else hides a load, so a row whose operands are requested at its own top costs a memory round trip (~6 us measured
+// on such tiles, which is why the one-row kernel used to win there); one row ahead the iteration is bound by its ~610 instructions.
+// ~44 more registers: one wave per SIMD.  The arithmetic and its order are the same in both instantiations.
+struct ExtPW { double el, elb, art, vfl, ea, h, cor, adx2d, aru, drx2d, wusurf, wubot, ady2d, arv, dry2d, wvsurf, wvbot, etf, egf, utf, vtf; unsigned mk; };
+template <bool AHEAD>
 __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows, const int *areas, int use_areas) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;   // (the host emulation runs lanes as blocks of width 1)
   if (wg < rim_wgs) { ext_rim_cell(P, wg * 256 + (int)threadIdx.y * 64 + lane, store_f, 1); return; }
@@ -880,23 +887,42 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
   double es = 0., tps0 = 0., fv0 = 0., gvM = 0.;
   const bool fu_on = (i0 >= 2 && i0 <= P.imm1), w_on = (i0 >= 2 && i0 <= P.im);
   // one row; LIVE = false: the warm-up row -- only what the carried values need (no momentum, no stores, 9 of the 22 pointwise loads)
+  // the pointwise operands of one row; LIVE = false (the warm-up row): 9 of the 22
+  auto load_pw = [&](const int row, auto live_tag) {
+    constexpr bool LV = decltype(live_tag)::value;
+    ExtPW w;
+    const unsigned ro = RO(row);
+    w.el = bld2(XD(X2_el), vo, ro); w.elb = bld2(XD(X2_elb), vo, ro);
+    w.art = FLD(art, o_area, ro); w.vfl = FLD(vfluxf, vo, ro);
+    w.mk = P.m8[(size_t)WAVE_UNIFORM(row - 1) * (size_t)P.iml + (size_t)(i - 1)];
+    w.ea = FLD(e_atmos, vo, ro); w.h = FLD(h, vo, ro); w.cor = FLD(cor, vo, ro);
+    w.adx2d = w.aru = w.drx2d = w.wusurf = w.wubot = w.ady2d = w.arv = w.dry2d = w.wvsurf = w.wvbot = 0.;
+    w.etf = w.egf = w.utf = w.vtf = 0.;
+    if (LV) {
+      w.adx2d = FLD(adx2d, vo, ro); w.aru = FLD(aru, o_area, ro); w.drx2d = FLD(drx2d, vo, ro);
+      w.wusurf = FLD(wusurf, vo, ro); w.wubot = FLD(wubot, vo, ro);
+      w.ady2d = FLD(ady2d, vo, ro); w.arv = FLD(arv, o_area, ro); w.dry2d = FLD(dry2d, vo, ro);
+      w.wvsurf = FLD(wvsurf, vo, ro); w.wvbot = FLD(wvbot, vo, ro);
+      w.etf = FLD(etf, o_etf_ld, ro); w.egf = FLD(egf, o_acc_ld, ro); w.utf = FLD(utf, o_acc_ld, ro); w.vtf = FLD(vtf, o_acc_ld, ro);
+    }
+    return w;
+  };
+  ExtPW pw;                                                   // AHEAD: the current row's operands, requested an iteration ago
+  if (AHEAD) pw = load_pw(jw, std::false_type());
   auto row_step = [&](const int j, auto live_tag) {
     constexpr bool LIVE = decltype(live_tag)::value;
     const unsigned ro = RO(j);
-    // ---- requests: the pointwise operands of this row first (used below), then the stencil row of the next iteration
-    const double el_0 = bld2(XD(X2_el), vo, ro), elb_0 = bld2(XD(X2_elb), vo, ro);
-    const double art_l = FLD(art, o_area, ro), vfl_0 = FLD(vfluxf, vo, ro);
-    const unsigned mk_0 = P.m8[(size_t)WAVE_UNIFORM(j - 1) * (size_t)P.iml + (size_t)(i - 1)];
-    const double ea_0 = FLD(e_atmos, vo, ro), h_0 = FLD(h, vo, ro), cor_0 = FLD(cor, vo, ro);
-    double adx2d = 0., aru = 0., drx2d = 0., wusurf = 0., wubot = 0., ady2d = 0., arv = 0., dry2d = 0., wvsurf = 0., wvbot = 0.;
-    double etf_o = 0., egf_o = 0., utf_o = 0., vtf_o = 0.;
-    if (LIVE) {
-      adx2d = FLD(adx2d, vo, ro); aru = FLD(aru, o_area, ro); drx2d = FLD(drx2d, vo, ro);
-      wusurf = FLD(wusurf, vo, ro); wubot = FLD(wubot, vo, ro);
-      ady2d = FLD(ady2d, vo, ro); arv = FLD(arv, o_area, ro); dry2d = FLD(dry2d, vo, ro);
-      wvsurf = FLD(wvsurf, vo, ro); wvbot = FLD(wvbot, vo, ro);
-      etf_o = FLD(etf, o_etf_ld, ro); egf_o = FLD(egf, o_acc_ld, ro); utf_o = FLD(utf, o_acc_ld, ro); vtf_o = FLD(vtf, o_acc_ld, ro);
-    }
+    // ---- requests: the pointwise operands (of this row, used below -- or, AHEAD, of the next one), then the stencil row of the
+    // next iteration
+    ExtPW pwn;
+    if (AHEAD) pwn = load_pw(j + 1 <= P.jml ? j + 1 : P.jml, std::true_type());
+    else pw = load_pw(j, live_tag);
+    const double el_0 = pw.el, elb_0 = pw.elb, art_l = pw.art, vfl_0 = pw.vfl;
+    const unsigned mk_0 = pw.mk;
+    const double ea_0 = pw.ea, h_0 = pw.h, cor_0 = pw.cor;
+    const double adx2d = pw.adx2d, drx2d = pw.drx2d, wusurf = pw.wusurf, wubot = pw.wubot, ady2d = pw.ady2d, dry2d = pw.dry2d, wvsurf = pw.wvsurf, wvbot = pw.wvbot;
+    double aru = pw.aru, arv = pw.arv;
+    const double etf_o = pw.etf, egf_o = pw.egf, utf_o = pw.utf, vtf_o = pw.vtf;
     ExtRow rn = load_row(j + 2 <= P.jml ? j + 2 : P.jml);
     const double fsm_0 = (double)(mk_0 & 1u), dum_0 = (double)((mk_0 >> 1) & 1u), dvm_0 = (double)((mk_0 >> 2) & 1u);
     const unsigned o_st = out ? vo : BOFF_NONE;
@@ -990,6 +1016,7 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
     rm = rc; rc = rp;
     rn.dW = WTRUE(rn.d, rn.dW); rn.dyW = WTRUE(rn.dy, rn.dyW);
     rp = rn;
+    if (AHEAD) pw = pwn;
   };
   row_step(jw, std::false_type());
   for (int j = j0; j <= j1; j++) row_step(j, std::true_type());
@@ -1405,7 +1432,9 @@ __global__ void k_ext_step_rim(KP P, int store_f) {
   ext_rim_cell(P, (int)(blockIdx.x * blockDim.x + threadIdx.x), store_f, 0);
 }
 
-// mode_internal tail: rotate the 2-D time levels -- advance.f:525-531 (whole arrays)
+// mode_internal tail: rotate the 2-D time levels -- advance.f:525-531 (whole arrays) -- and, in the same pass, the derived
+// coefficients of the new dt (k_coef_dt, k_tile.hip: the same expressions; a neighbour's dt is formed here as h + etf, the sum
+// that cell's own thread stores -- the same bits)
 __global__ void k_int_tail(KP P) {
   const int i = TID_I, j = TID_J;
   if (i > P.iml || j > P.jml) return;
@@ -1413,10 +1442,18 @@ __global__ void k_int_tail(KP P) {
   F2(etb, i, j) = F2(et, i, j);
   const double etf = F2(etf, i, j);
   F2(et, i, j) = etf;
-  F2(dt, i, j) = F2(h, i, j) + etf;
+  const double dt = F2(h, i, j) + etf;
+  F2(dt, i, j) = dt;
   F2(utb, i, j) = F2(utf, i, j);
   F2(vtb, i, j) = F2(vtf, i, j);
   F2(vfluxb, i, j) = F2(vfluxf, i, j);
+  const int iw = i > 1 ? i - 1 : 1, js = j > 1 ? j - 1 : 1;
+  const double dtw = F2(h, iw, j) + F2(etf, iw, j), dts = F2(h, i, js) + F2(etf, i, js), dtws = F2(h, iw, js) + F2(etf, iw, js);
+  K2(CMX, i, j) = 0.25 * (F2(dy, iw, j) + F2(dy, i, j)) * (dtw + dt);
+  K2(CMY, i, j) = 0.25 * (F2(dx, i, js) + F2(dx, i, j)) * (dts + dt);
+  K2(DTSX, i, j) = dt + dtw;
+  K2(DTSY, i, j) = dt + dts;
+  K2(DT4, i, j) = dt + dtw + dts + dtws;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1477,11 +1514,31 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     int rows = (int)(wave_rows / 7400);
     rows = rows < 2 ? 2 : (rows > 7 ? 7 : rows);
     if (SW(c, EXT_ROWS)) rows = (int)SWV(c, EXT_ROWS);
-    const int nseg = rows > 0 ? (Q.jmm1 - 3 + 1 + rows - 1) / rows : 0, nbx = (int)g.x;
     const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
-    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (wave_rows >= 16500 || SW(c, EXT_MARCH))) {
+    const bool large = wave_rows >= 16500 || SW(c, EXT_MARCH);
+    bool ahead = false;
+    if (!large && !SW(c, EXT_NOAHEAD) && Q.im >= 8 && Q.jm >= 8) {
+      // small tiles (the extended tile of a 4- or 8-tile split; small grids): ONE wavefront per SIMD marching with every operand a row
+      // ahead (k_ext_march<true>) -- segments as tall as it takes for the wavefronts to fill the chip's SIMDs once
+#ifdef POMGPU_EMU
+      const int nsimd = 1024;
+#else
+      static int nsimd = 0;
+      if (!nsimd) {
+        hipDeviceProp_t pr;
+        nsimd = 4 * ((hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256);
+      }
+#endif
+      rows = (int)((wave_rows + nsimd - 1) / nsimd);
+      if (rows < 4) rows = 4;
+      if (SW(c, EXT_AHEAD_ROWS)) rows = (int)SWV(c, EXT_AHEAD_ROWS);
+      ahead = true;
+    }
+    const int nseg = rows > 0 ? (Q.jmm1 - 3 + 1 + rows - 1) / rows : 0, nbx = (int)g.x;
+    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (large || ahead)) {
       const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
-      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
+      if (ahead) LAUNCHN(c, "k_ext_step_adv", k_ext_march<true>, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
+      else LAUNCHN(c, "k_ext_step_adv", k_ext_march<false>, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
       return;
     }
   }

@@ -19,6 +19,8 @@ static ProfState *PS(pomgpu_ctx *c) { return (ProfState *)c->prof_state; }
 #define SLOT3(c, n) ((c)->P.b3 + (size_t)(n) * (c)->P.a3)
 #define D2(c, name) SLOT2(c, P2_##name)
 #define D3(c, name) SLOT3(c, P3_##name)
+// level lev + 1 of a 3-D array, as a handle: in the fp32-storage variant the levels are n2 FLOATS apart
+#define LEV3(c, p, lev) ((double *)((pomgpu_st *)(p) + (size_t)(lev) * (c)->P.n2))
 
 int pomgpu_fail(pomgpu_ctx *c, int code, const char *fmt, ...) {
   if (c && c->parent) c = c->parent;
@@ -570,6 +572,7 @@ extern "C" int pomgpu_download_3d(pomgpu_ctx *c, int s, double *h) {
 extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) {
   if (!c || s < 0 || s >= POM_NBLK2D) return NULL;
   ext_canonical(c);
+  c->areas_checked = 0;                                       // the caller may write through the address it gets
   return SLOT2(c, s);
 }
 extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) {
@@ -728,14 +731,14 @@ static void seq_advq(pomgpu_ctx *c, double *qb, double *q, double *qf, int pair,
 static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   // solver.f:1212-1538
   KP &P = c->P;
   launch_profq_bc(c);
-  double *ufkb = D3(c, uf) + (size_t)(P.kb - 1) * P.n2;
+  double *ufkb = LEV3(c, D3(c, uf), P.kb - 1);
   const int lines = c->exch && c->tp.on && !SW(c, PROD_FULL);   // tiles, the library's own exchange
   if (lines) {
     // the production term's lines (k_profq_prod_lines) depend on nothing profq_bc or the exchange below delivers:
     // :1289-1290, :1374 (and advance.f:400 for w) travel in ONE round
     launch_profq_prod(c, 1, c->rho_rt_pending);
-    if (with_w) xch(c, 4, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2, D3(c, w), P.kb);
-    else xch(c, 3, P.s2[4], 1, ufkb, 1, P.s3[0] + P.n2, P.kbm2);
+    if (with_w) xch(c, 4, P.s2[4], 1, ufkb, 1, LEV3(c, P.s3[0], 1), P.kbm2, D3(c, w), P.kb);
+    else xch(c, 3, P.s2[4], 1, ufkb, 1, LEV3(c, P.s3[0], 1), P.kbm2);
     launch_profq(c, 2, fuse_filter, c->rho_rt_pending);       // owned columns form prod inside the solve
     return;
   }
@@ -743,7 +746,7 @@ static void seq_profq(pomgpu_ctx *c, int fuse_filter = 0, int with_w = 0) {   //
   else xch(c, 2, P.s2[4], 1, ufkb, 1);                        // :1289-1290
   if (!c->exch) { launch_profq(c, 1, fuse_filter, c->rho_rt_pending); return; }  // one tile: prod is formed inside the solve kernel
   launch_profq_prod(c, 0, c->rho_rt_pending);
-  xch(c, 1, P.s3[0] + P.n2, P.kbm2);                          // :1374
+  xch(c, 1, LEV3(c, P.s3[0], 1), P.kbm2);                          // :1374
   launch_profq(c, 0, fuse_filter, c->rho_rt_pending);
 }
 static void seq_fb_fix(pomgpu_ctx *c, double *fb, const double *fclim) {
@@ -955,7 +958,7 @@ static int mode_external(pomgpu_ctx *c, int store_f) {        // advance.f:205-3
     for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = c->ext_parity ? P.b2 + (size_t)X2_SLOT[n] * P.n2 : c->alt2[n];
     // once per internal step (and after any upload): are art, aru, arv what initialize.f:361-367 makes of dx, dy?  Then
     // k_ext_march forms them in registers instead of reading three arrays per substep.  On the device, no host round trip.
-    if (fuse_adv && (P.iext == 1 || !c->areas_checked)) { launch_check_areas(c); c->areas_checked = 1; }
+    if (fuse_adv && !c->areas_checked) { launch_check_areas(c); c->areas_checked = 1; }   // dx, dy, art, aru, arv change with an upload only (refresh_coefs)
     if (c->parent && !SW(c, WIDE_FULL)) {
       // The extended tile of the wide-halo mode: its stale rim grows by one line per substep (see "How far stale cells spread"
       // below), so substep n need not compute the n - 1 outermost rows of an extended side at all -- they are wrong already and
@@ -1004,7 +1007,7 @@ static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
   }
   t->con.iext = iext; t->con.isplit = isplit;
   P.iext = iext;
-  if (iext == 1 || !t->areas_checked) { launch_check_areas(t); t->areas_checked = 1; }
+  if (!t->areas_checked) { launch_check_areas(t); t->areas_checked = 1; }
   KP Q = P;
   // Every launch moves the current generation to the other buffer set; the loop should end in the blk2d arrays (else ext_canonical
   // copies seven arrays back: 0.09 ms at 2048x1536).  If the launches still to come (pairs, and a last single substep of an odd
@@ -1082,7 +1085,6 @@ static int tp_install(pomgpu_ctx *c, const int *nbr8) {
 }
 extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_transport_fn fn, void *user) {
   NEED_HOT(c);
-  if (fn) { F32_REFUSE(c, "set_transport"); }
   wide_free(c);
   pomgpu_tp_free(c);
   if (!fn) {                                                  // no mover: back to the hooks / a single tile
@@ -1094,7 +1096,6 @@ extern "C" int pomgpu_set_transport(pomgpu_ctx *c, const int *nbr8, pomgpu_trans
 }
 extern "C" int pomgpu_rccl_init(pomgpu_ctx *c, const void *id128, int rank, int nranks, const int *nbr8, const char *librccl_path) {
   NEED_HOT(c);
-  F32_REFUSE(c, "rccl_init");
   wide_free(c);
   pomgpu_tp_free(c);
   int rc = pomgpu_tp_rccl(c, id128, rank, nranks, librccl_path);
@@ -1459,7 +1460,7 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     }
     const int qfuse = !SW(c, QFILTER_SPLIT);
     seq_profq(c, qfuse, lib_x);                               // with the interior's Asselin filter (:416-421) on its way up
-    xch(c, 2, D3(c, uf) + P.n2, P.kbm2, D3(c, vf) + P.n2, P.kbm2);   // :411-412
+    xch(c, 2, LEV3(c, D3(c, uf), 1), P.kbm2, LEV3(c, D3(c, vf), 1), P.kbm2);   // :411-412
     launch_bcond6_edges(c);                                   // :414
     if (qfuse) launch_q_filter_rim(c);                        // :416-421, edge lines
     else launch_q_filter(c, 1);
@@ -1468,15 +1469,13 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
         seq_advt1(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
       } else if (k.nadv == 2) {
-        if (P.nitera == 1 && !SW(c, ADVT2_SINGLE)) {   // T and S in one pass
-          launch_coef_eta(c);
+        if (P.nitera == 1 && !SW(c, ADVT2_SINGLE)) {   // T and S in one pass (HEA, HFA: launch_coef_eta above -- etb, etf have not changed since)
           launch_advt2x2_col(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf));
           // solver.f:728 exchanges T, then S; advance.f:436-437 below exchanges both again with nothing written
           // in between: the library's own exchange serves the three points in that one round
           if (!lib_x) xch(c, 1, D3(c, uf), P.kbm1);             // solver.f:728 (T)
-          launch_copy_kb(c, D3(c, tb));                         // :618
           if (!lib_x) xch(c, 1, D3(c, vf), P.kbm1);             // :728 (S)
-          launch_copy_kb(c, D3(c, sb));
+          launch_copy_kb(c, D3(c, tb), D3(c, sb));              // :618 for T and S in one launch (level kb of tb, sb: no exchange reads it)
         } else {
           seq_advt2(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf), true);
           seq_advt2(c, D3(c, sb), D3(c, s), D3(c, sclim), D3(c, vf), true);
@@ -1513,14 +1512,13 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
       // column is their level kb (profu / profv write it on owned columns only).  ub, vb are needed in full: the filter
       // (:469-509) runs on ghost columns too, but from a u whose western / southern ghost cells missed the depth-mean
       // correction (:365-393 starts at i = 2, j = 2 and is not followed by an exchange).  2 x kb + 4 planes instead of 6 x kb.
-      const size_t top = (size_t)(P.kb - 1) * P.n2;
-      xch(c, 6, D3(c, ub), P.kb, D3(c, vb), P.kb, D3(c, u) + top, 1, D3(c, uf) + top, 1, D3(c, v) + top, 1, D3(c, vf) + top, 1);
+      const int top = P.kb - 1;
+      xch(c, 6, D3(c, ub), P.kb, D3(c, vb), P.kb, LEV3(c, D3(c, u), top), 1, LEV3(c, D3(c, uf), top), 1, LEV3(c, D3(c, v), top), 1, LEV3(c, D3(c, vf), top), 1);
     } else {
       xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
     }
   }
-  launch_int_tail(c);                                         // :525-531
-  launch_coef_dt(c);                                          // dt changed: refresh the derived coefficients
+  launch_int_tail(c);                                         // :525-531, and the derived coefficients of the new dt (k_coef_dt's) in the same pass
   launch_realvertvl(c);                                       // :534
   if (c->tp.on && c->exch && c->wide.split && c->tp.wr_side) {     // wr_side: no rank asked for POMGPU_WR_MAIN (agreed with side_agreed)
     // solver.f:2055 on the side stream: nobody on the hot path reads wr's ghost cells (a diagnostic for the output

@@ -445,7 +445,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EXT_NOCHAIN) X(EDGE_SPLIT)
+  X(EXT_NOAHEAD) X(EXT_AHEAD_ROWS) X(EDGE_SPLIT)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
@@ -706,7 +706,7 @@ void launch_q_filter(pomgpu_ctx *c, int mask);
 void launch_q_filter_rim(pomgpu_ctx *c);
 void launch_mask_q(pomgpu_ctx *c);
 void launch_advt1(pomgpu_ctx *c, double *fb, double *f, const double *fclim, double *ff);
-void launch_copy_kb(pomgpu_ctx *c, double *f);
+void launch_copy_kb(pomgpu_ctx *c, double *f, double *g = NULL);   // level kb = level kbm1, of one or two arrays
 void launch_advt2_mass(pomgpu_ctx *c);
 void launch_advt2_step(pomgpu_ctx *c, const double *fbmem, const double *f, const double *eta, double *ff, int itera);
 void launch_mask3(pomgpu_ctx *c, double *a, const double *m2);

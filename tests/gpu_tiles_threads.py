@@ -1,0 +1,156 @@
+"""Launched by tests/test_gpu_multitile.py: decomposition invariance AT FULL SIZE, GPU against GPU, in one process.
+
+The reference guarantees that a run does not depend on how the domain is cut into tiles (its only
+regression check).  Here the bench grid (default 2048x1536x50, the grid north_star's targets are stated on) runs once as ONE
+tile and once as 1 x N whole-row tiles -- bench.py's default split -- all on GPU 0: every tile a context of its own on a
+stream of its own, driven by a host thread, the library's exchange (pomgpu_set_transport) with a mover that copies the
+staging buffers device to device between the contexts, the wide-halo external mode with its two rounds on the second
+stream.  After STEPS internal steps every cell a tile OWNS must hold the bits of the single-tile run, in every COMMON array
+that is not pure scratch.  The single-tile path itself is pinned to the oracle at this size for steps 1-3
+(test_config4_2048x1536x50_full_size); this carries that pin over STEPS steps and over the multi-tile code path.
+
+    python tests/gpu_tiles_threads.py [IMxJMxKB] [N] [STEPS] [f32]
+"""
+import ctypes
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from extpom_amd import decomp
+from extpom_amd import lib as _lib
+from extpom_amd.cases import finish_initial, make_case
+from extpom_amd.halo import _DevPtr
+from extpom_amd.layout import BLK2D, BLK3D
+from extpom_amd.lib import OPP
+from extpom_amd.model import PomGpu
+
+SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
+T0 = time.time()
+
+
+def beat(msg):                                       # the GPU box's watchdog looks for signs of life under gpurun_out/
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/tiles_threads_progress.log", "a") as f:
+        f.write(f"{time.time() - T0:7.1f} s  {msg}\n")
+
+
+class Board:
+    def __init__(self, world):
+        self.box = {}
+        self.barrier = threading.Barrier(world)
+
+    def allmin(self, me, value):
+        self.box[("min", me)] = int(value)
+        self.barrier.wait()
+        m = min(v for k, v in self.box.items() if k[0] == "min")
+        self.barrier.wait()
+        return m
+
+
+def gpu_finish(st, g):
+    def dens(s, a, b, c):
+        g.upload(s); g.call("dens", a, b, c); g.download(s)
+
+    def baropg(s):
+        g.upload(s); g.call("baropg_mcc" if int(s.npg) == 2 else "baropg"); g.download(s)
+
+    finish_initial(st, dens, baropg)
+    g.upload(st)
+
+
+def main():
+    grid = sys.argv[1] if len(sys.argv) > 1 else "2048x1536x50"
+    world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    libpath = _lib.LIBPATH_F32 if "f32" in sys.argv[4:] else None
+    im, jm, kb = (int(v) for v in grid.split("x"))
+    nml = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
+    dev = torch.device("cuda", 0)
+    # ---- one tile ----------------------------------------------------------------------------------------------------
+    a = make_case("basin", im, jm, kb, **nml)
+    ga = PomGpu(a, device=0, libpath=libpath)
+    gpu_finish(a, ga)
+    ga.run(steps)
+    ga.download()
+    ga.close()
+    assert a.error_status == 0
+    beat(f"single tile: {steps} steps done")
+    # ---- 1 x world whole-row tiles, one host thread each -------------------------------------------------------------
+    iml, jml = decomp.local_size(im, jm, 1, world)
+    tiles = [decomp.make_tile(r, im, jm, iml, jml, n_proc=world) for r in range(world)]
+    board, errs, bad, info = Board(world), [], [], {}
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(0)
+            tile = tiles[r]
+            st = make_case("basin", im, jm, kb, tile=tile, **nml)
+            ts = torch.cuda.Stream()
+            torch.cuda.set_stream(ts)                 # thread-local: this thread's torch work goes to its context's stream
+            g = PomGpu(st, device=0, stream=ts.cuda_stream, libpath=libpath)
+            nb = PomGpu.neighbours8(tile)
+            w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
+
+            def mover(send, scount, recv, rcount):
+                ts.synchronize()                      # what the library packed is in the staging buffers
+                for d in range(8):
+                    if nb[d] >= 0 and scount[d]:
+                        board.box[(r, nb[d], d)] = (send[d], scount[d])
+                board.barrier.wait()
+                for d in range(8):
+                    if nb[d] >= 0 and rcount[d]:
+                        p, n = board.box[(nb[d], r, OPP[d])]
+                        assert n == rcount[d], (r, d, n, rcount[d])
+                        w(recv[d], n).copy_(w(p, n))
+                ts.synchronize()
+                board.barrier.wait()                  # nobody repacks a buffer a neighbour is still reading
+
+            g.set_transport(tile, mover, agree=lambda mine: board.allmin(r, mine))
+            assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
+            gpu_finish(st, g)
+            board.barrier.wait()
+            g.run(steps)
+            g.download()
+            info[r] = (g.exchange_rounds(), g.exchange_rounds_side())
+            g.close()
+            assert st.error_status == 0
+            io, jo, ti, tj = tile.i_off, tile.j_off, tile.im, tile.jm
+            sl_j = slice(0 if jo == 0 else 1, tj if jo + tj == jm else tj - 1)
+            sl_i = slice(0 if io == 0 else 1, ti if io + ti == im else ti - 1)
+            for n in BLK2D + BLK3D:
+                if n in SCRATCH:
+                    continue
+                ref = np.ascontiguousarray(a.field(n)[..., jo:jo + tj, io:io + ti][..., sl_j, sl_i])
+                got = np.ascontiguousarray(st.field(n)[..., :tj, :ti][..., sl_j, sl_i])
+                if not np.array_equal(ref.view(np.int64), got.view(np.int64)):     # the bits, the sign of a zero included
+                    bad.append((r, n, float(np.abs(ref - got).max())))
+            beat(f"tile {r} compared")
+        except Exception as e:                        # noqa: BLE001 -- a dead rank must not leave the others at the barrier
+            import traceback
+            errs.append(traceback.format_exc())
+            board.barrier.abort()
+
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        print("ERROR", errs[0])
+        sys.exit(2)
+    print(f"message rounds per step and tile: {[round(v[0] / steps, 2) for v in info.values()]} between kernels, "
+          f"{[round(v[1] / steps, 2) for v in info.values()]} on the second stream")
+    if bad:
+        print("MISMATCH", bad[:20])
+        sys.exit(1)
+    print(f"TILES-THREADS-OK {grid} 1x{world} {steps} steps")
+
+
+if __name__ == "__main__":
+    main()

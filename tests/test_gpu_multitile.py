@@ -64,6 +64,18 @@ def test_whole_row_tiles_the_default_split(args):
 
 
 @pytest.mark.gpu
+def test_full_size_decomposition_invariance_whole_row_tiles():
+    """The property the reference itself guarantees, at the size north_star is stated on: 2048x1536x50 as ONE
+    tile and as 1 x 4 whole-row tiles (bench.py's default split; library exchange, wide-halo external mode, two rounds per step
+    on the second stream), GPU against GPU on one device, 50 internal steps: every owned cell of every COMMON array that is not
+    scratch carries the same bits.  With steps 1-3 of the single-tile run pinned to the oracle at this size
+    (test_config4_2048x1536x50_full_size) this is what carries the pin beyond a few steps, and over the multi-tile path."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_threads.py"), "2048x1536x50", "4", "50"], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0 and "TILES-THREADS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["x", "rccl"], ["xy", "rccl"], ["y", "npg2", "rccl"]])
 def test_rccl_between_distinct_ranks_one_gpu_each(args):
     """bench.py's N > 1 path as a parity test: rank r on GPU r, the library's RCCL transport (main and side stream, both

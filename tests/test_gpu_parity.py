@@ -377,7 +377,7 @@ def test_restart_and_determinism_properties_1024x1024x40():
     """config 3's grid on one GPU, size-independent properties: (i) two runs give identical bits,
     (ii) run(2n) == run(n) + download/upload + run(n) (the restart property), (iii) land stays
     masked, nothing non-finite, (iv) closed basin conserves volume: the area integral of et does
-    not drift, (v) steps 1 AND 2 equal the oracle's on every field: at iint = 1 with time0 = 0 mode_internal skips its 3-D
+    not drift, (v) steps 1, 2 AND 3 equal the oracle's on every field (3 = the first with every branch warm): at iint = 1 with time0 = 0 mode_internal skips its 3-D
     body (advance.f:362), so step 2 is the first one in which advq / profq / advt2 / proft / advu / advv / profu / profv and
     the filters run, on the default (fast) kernel shapes of this grid."""
     OracleTile, oracle_finish_initial = _oracle()
@@ -409,12 +409,12 @@ def test_restart_and_determinism_properties_1024x1024x40():
     oracle_finish_initial(e)
     ge = _gpu(e)
     oc = OracleTile(c)
-    for step in (1, 2):
+    for step in (1, 2, 3):
         oc.run(1)
         ge.run(1)
         ge.download()
         assert not diff(c, e), f"step {step} differs from the oracle: {diff(c, e)}"
-    assert c.iint == 2 and e.iint == 2                # step 2: the 3-D body of mode_internal has run on both sides
+    assert c.iint == 3 and e.iint == 3                # steps 2, 3: the 3-D body of mode_internal has run on both sides; 3 = every branch warm
     ge.close()
 
 
@@ -528,10 +528,10 @@ def test_100_internal_steps_256x192x50_within_1e_10():
 
 def test_config4_2048x1536x50_full_size():
     """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU, default (fast) kernel shapes:
-    (i) steps 1 AND 2, every field array_equal to the oracle.  Step 1 (iint = 1, time0 = 0) skips mode_internal's 3-D body
+    (i) steps 1, 2 AND 3, every field equal to the oracle bit for bit (step 3: the first with every branch warm).  Step 1 (iint = 1, time0 = 0) skips mode_internal's 3-D body
     (advance.f:362); step 2 is the first in which k_profq<1,1,8>, k_advt2_col<2>, k_advq_col<2>, k_advct_col, k_advuv_col in
     strip order, k_ts_update and the <50> register kernels run AT THE BENCHMARKED LAUNCH GEOMETRY -- it is compared with the
-    oracle directly (about two minutes of one CPU core for the two oracle steps); (ii) two contexts fed the same state produce the same bits over 20 more steps, one on
+    oracle directly (about three minutes of one CPU core for the oracle steps); (ii) two contexts fed the same state produce the same bits over 20 more steps, one on
     the large-grid kernel shapes and one on the general ones; (iii) land stays masked, nothing non-finite.
     ~50 GB per host copy of the state."""
     import os
@@ -550,7 +550,7 @@ def test_config4_2048x1536x50_full_size():
     c = a.copy()
     ga = _gpu(a)
     oc = OracleTile(c)
-    for step in (1, 2):
+    for step in (1, 2, 3):                           # step 3: the first with every branch warm (leapfrog levels, filters, restore records)
         ga.run(1)
         ga.download()
         beat(f"device step {step} downloaded")
@@ -559,9 +559,9 @@ def test_config4_2048x1536x50_full_size():
         bad = diff(a, c)
         assert not bad, f"step {step} differs from the oracle: {bad}"
         beat(f"step {step} compared")
-    assert a.iint == 2 and c.iint == 2               # the 3-D body ran on both sides (advance.f:362)
+    assert a.iint == 3 and c.iint == 3               # the 3-D body ran on both sides (advance.f:362), twice
     del oc
-    gc = _gpu(c)                                     # the oracle's state after two steps, uploaded
+    gc = _gpu(c)                                     # the oracle's state after three steps, uploaded
     # 20 more steps: one context on the large-grid fast paths (two external substeps per pass marching down the rows, k_profq in 8
     # paced rows with its vectors in LDS, strip order), the other on the shapes small grids use (one substep per launch, one row
     # per wavefront ...) -- the same bits
@@ -576,7 +576,7 @@ def test_config4_2048x1536x50_full_size():
     gc.close()
     bad = diff(a, c)
     assert not bad, f"two contexts, same state, fast against general kernels, different bits after 20 steps: {bad}"
-    beat("steps 3-22 compared")
+    beat("steps 4-23 compared")
     for f in PROGNOSTIC + ["q2", "km", "rho", "w"]:
         assert np.isfinite(a.field(f)).all(), f
     for f in ("t", "s", "el", "et"):
@@ -621,8 +621,8 @@ def test_fp32_storage_variant_tracks_the_fp64_path_within_its_stated_drift():
     """BASELINE configs[4]'s study variant (libpomgpu_f32.so: the same sources with -DPOMGPU_STORE_F32 -- 3-D arrays stored
     as fp32, arithmetic and the 2-D external mode fp64).  It is NOT a parity path: the flow amplifies rounding-level
     differences (profiles/round2_fp32_storage_study_gpu.txt: 1.5e-8 in u after one step, 2.7e-4 after 10, 5e-2 after 100).
-    Asserted: it runs, it is the variant, and it stays inside that envelope for 1 and 10 steps; tiles and the output
-    writer are refused there."""
+    Asserted: it runs, it is the variant, and it stays inside that envelope for 1 and 10 steps; the output writer is
+    refused there (tiles: test_fp32_storage_variant_on_tiles)."""
     from extpom_amd import lib as L
     from extpom_amd.lib import PomGpuError
     from extpom_amd.model import PomGpu, gpu_finish_initial
@@ -641,6 +641,44 @@ def test_fp32_storage_variant_tracks_the_fp64_path_within_its_stated_drift():
     with pytest.raises(PomGpuError):
         g32.write_file("output", "/tmp/should_not_exist.nc")
     g64.close(); g32.close()
+
+
+@pytest.mark.gpu
+def test_fp32_storage_variant_at_the_benchmarks_level_count():
+    """the drift envelope of the fp32-storage variant at kb = 50 (256x192x50, the bench's level count and the <50> register
+    kernels): after 1 internal step the prognostic fields sit at fp32 rounding level of the fp64 path, after 10 steps inside
+    the envelope the 65x49x21 study found (the flow amplifies rounding-level differences: DESIGN.md section 8)"""
+    from extpom_amd import lib as L
+    from extpom_amd.model import PomGpu, gpu_finish_initial
+    a = make_case("basin", 256, 192, 50, dte=6.0, isplit=30)
+    gpu_finish_initial(a, device=0)
+    b = a.copy()
+    g64, g32 = PomGpu(a, device=0), PomGpu(b, device=0, libpath=L.LIBPATH_F32)
+    seen = {}
+    for steps, bound in ((2, 5e-6), (10, 5e-3)):     # step 1 skips the 3-D body (advance.f:362): 2 is the first step that stores fp32
+        g64.run(steps - (0 if steps == 2 else 2)); g32.run(steps - (0 if steps == 2 else 2))
+        g64.download(); g32.download()
+        r = reldiff(a, b, PROGNOSTIC)
+        seen[steps] = max(r.values())
+        assert 0 < max(r.values()) <= bound, (steps, r)
+        assert a.error_status == b.error_status == 0
+    print("fp32-storage drift at 256x192x50:", seen)
+    g64.close(); g32.close()
+
+
+@pytest.mark.gpu
+def test_fp32_storage_variant_on_tiles():
+    """configs[4]'s other half: the fp32-storage variant under the library's exchange and the wide-halo external mode (its
+    halos travel as doubles: a stored fp32 value widens exactly and rounds back to itself).  1 x 4 whole-row tiles of
+    256x192x50 against the single tile, both in fp32 storage, GPU against GPU: the owned cells carry the same bits -- the
+    variant is decomposition-invariant like the product."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiles_threads.py"), "256x192x50", "4", "6", "f32"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "TILES-THREADS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 @pytest.mark.gpu
