@@ -132,7 +132,8 @@ def _sample_dims(workload):
 
 def _cpu_run(workload, full, seconds=12.0, reference=False):
     """ONE host core.  full=True: the bench's OWN grid and state (identical inputs: same case, namelist, im x jm x kb), internal
-    steps 1-3, of which 2 and 3 are timed (step 1 skips the 3-D body, advance.f:362); full=False: a bounded sample on a
+    steps 1-2, of which step 2 is timed (step 1 skips the 3-D body, advance.f:362; one full-grid step is ~40 s of one core, and
+    the default run has to stay within minutes); full=False: a bounded sample on a
     1/8 x 1/8 horizontal grid for `seconds`.  reference=False: the plain-C oracle; True: the flang build of the reference's own
     sources (oracle/_ref, present only where /root/reference was at build time), driven in the order of its own `advance`."""
     from extpom_amd.cases import make_case
@@ -160,7 +161,7 @@ def _cpu_run(workload, full, seconds=12.0, reference=False):
         step()
     t0 = time.perf_counter()
     n = 0
-    while (n < 2) if full else (n < 4 or (time.perf_counter() - t0 < seconds and n < 400)):
+    while (n < 1) if full else (n < 4 or (time.perf_counter() - t0 < seconds and n < 400)):
         step()
         n += 1
     dt = time.perf_counter() - t0
@@ -197,7 +198,7 @@ def cpu_baseline(workload):
     (a second copy of the 50 GB state: freed when the child ends)."""
     d = _child_json(["--cpu-sample", "--full-grid", "--workload", workload], 900)
     return {"value": d["value"], "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{d['what']} = the bench's own grid and initial state (identical inputs), internal steps 2-3 of the plain-C oracle "
+            "sample": f"{d['what']} = the bench's own grid and initial state (identical inputs), internal step 2 of the plain-C oracle "
                       f"(gcc -O2, one core; step 1 untimed: it skips the 3-D body, advance.f:362), {d['seconds']:.1f} s"}
 
 
@@ -280,7 +281,7 @@ def _cpu_tiles_worker(workload):
     finish_initial(st, lambda s, a, b, c: ot.call("dens", ot.a3(a), ot.a3(b), ot.a3(c)),
                    lambda s: ot.call("baropg_mcc" if int(s.npg) == 2 else "baropg"))
     ot.run(1)
-    dist.barrier()
+    pdist.cpu_barrier()                                          # not dist.barrier(): that one opens the GPU (extpom_amd/dist.py)
     c0 = halo.count
     t0 = time.perf_counter()
     n = 0
@@ -291,7 +292,7 @@ def _cpu_tiles_worker(workload):
         dist.broadcast(flag, 0)                                  # rank 0's clock decides for everybody whether another step follows
         if n >= 6 or (n >= 2 and flag.item() == 0.0):
             break
-    dist.barrier()
+    pdist.cpu_barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"value": im * jm * kb * n / dt, "what": f"{case} {im}x{jm}x{kb}", "n": n, "seconds": dt,
@@ -529,7 +530,8 @@ def supervise(args):
             print(json.dumps(out), flush=True)
     cbox = [code]
     dist.broadcast_object_list(cbox, src=0)                     # every supervisor leaves with rank 0's verdict
-    dist.barrier()
+    from extpom_amd.dist import cpu_barrier
+    cpu_barrier()                                               # (dist.barrier() would open the GPU in a supervisor)
     dist.destroy_process_group()
     return cbox[0]
 
@@ -587,13 +589,13 @@ def _selftest_rank(args, this_pass, plan):
         sys.exit(9)
     if plan.get("hang") == [k, rank]:
         time.sleep(3600)
-    torch.distributed.barrier()
+    pdist.cpu_barrier()
     if rank == 0:
         ms = 10.0 + k - (3.0 if this_pass["overlap"] else 0.0)
         print(json.dumps({"metric": "SELFTEST -- not a measurement", "value": 1.0 / ms, "ms_per_step": ms, "n_gpus": world, "steps": args.steps,
                           "config": {"tiles": os.environ.get("POM_TILE_GRID"), "overlap": this_pass["overlap"], "rccl_nranks": 0,
                                      "no_overlap_env": os.environ.get("POMGPU_NO_OVERLAP")}}), flush=True)
-    torch.distributed.barrier()
+    pdist.cpu_barrier()
     torch.distributed.destroy_process_group()
 
 

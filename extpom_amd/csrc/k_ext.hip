@@ -812,13 +812,6 @@ __device__ __forceinline__ double west_true(double x, double w, int lane) {
   return lane == 0 ? w : t;
 }
 #endif
-// AHEAD (small tiles: the extended tile of a 4- or 8-tile split): the 22 pointwise operands of row j + 1 are requested while row j is
-// worked on, like the stencil rows always were.  With as many wavefronts as the chip has SIMDs (the launcher picks the segment height
-// for that) nobody else hides a load, so a row whose operands are requested at its own top costs a memory round trip (~6 us measured
-// on such tiles, which is why the one-row kernel used to win there); one row ahead the iteration is bound by its ~610 instructions.
-// ~44 more registers: one wave per SIMD.  The arithmetic and its order are the same in both instantiations.
-struct ExtPW { double el, elb, art, vfl, ea, h, cor, adx2d, aru, drx2d, wusurf, wubot, ady2d, arv, dry2d, wvsurf, wvbot, etf, egf, utf, vtf; unsigned mk; };
-template <bool AHEAD>
 __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wgs, int rows, const int *areas, int use_areas) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;   // (the host emulation runs lanes as blocks of width 1)
   if (wg < rim_wgs) { ext_rim_cell(P, wg * 256 + (int)threadIdx.y * 64 + lane, store_f, 1); return; }
@@ -887,42 +880,23 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
   double es = 0., tps0 = 0., fv0 = 0., gvM = 0.;
   const bool fu_on = (i0 >= 2 && i0 <= P.imm1), w_on = (i0 >= 2 && i0 <= P.im);
   // one row; LIVE = false: the warm-up row -- only what the carried values need (no momentum, no stores, 9 of the 22 pointwise loads)
-  // the pointwise operands of one row; LIVE = false (the warm-up row): 9 of the 22
-  auto load_pw = [&](const int row, auto live_tag) {
-    constexpr bool LV = decltype(live_tag)::value;
-    ExtPW w;
-    const unsigned ro = RO(row);
-    w.el = bld2(XD(X2_el), vo, ro); w.elb = bld2(XD(X2_elb), vo, ro);
-    w.art = FLD(art, o_area, ro); w.vfl = FLD(vfluxf, vo, ro);
-    w.mk = P.m8[(size_t)WAVE_UNIFORM(row - 1) * (size_t)P.iml + (size_t)(i - 1)];
-    w.ea = FLD(e_atmos, vo, ro); w.h = FLD(h, vo, ro); w.cor = FLD(cor, vo, ro);
-    w.adx2d = w.aru = w.drx2d = w.wusurf = w.wubot = w.ady2d = w.arv = w.dry2d = w.wvsurf = w.wvbot = 0.;
-    w.etf = w.egf = w.utf = w.vtf = 0.;
-    if (LV) {
-      w.adx2d = FLD(adx2d, vo, ro); w.aru = FLD(aru, o_area, ro); w.drx2d = FLD(drx2d, vo, ro);
-      w.wusurf = FLD(wusurf, vo, ro); w.wubot = FLD(wubot, vo, ro);
-      w.ady2d = FLD(ady2d, vo, ro); w.arv = FLD(arv, o_area, ro); w.dry2d = FLD(dry2d, vo, ro);
-      w.wvsurf = FLD(wvsurf, vo, ro); w.wvbot = FLD(wvbot, vo, ro);
-      w.etf = FLD(etf, o_etf_ld, ro); w.egf = FLD(egf, o_acc_ld, ro); w.utf = FLD(utf, o_acc_ld, ro); w.vtf = FLD(vtf, o_acc_ld, ro);
-    }
-    return w;
-  };
-  ExtPW pw;                                                   // AHEAD: the current row's operands, requested an iteration ago
-  if (AHEAD) pw = load_pw(jw, std::false_type());
   auto row_step = [&](const int j, auto live_tag) {
     constexpr bool LIVE = decltype(live_tag)::value;
     const unsigned ro = RO(j);
-    // ---- requests: the pointwise operands (of this row, used below -- or, AHEAD, of the next one), then the stencil row of the
-    // next iteration
-    ExtPW pwn;
-    if (AHEAD) pwn = load_pw(j + 1 <= P.jml ? j + 1 : P.jml, std::true_type());
-    else pw = load_pw(j, live_tag);
-    const double el_0 = pw.el, elb_0 = pw.elb, art_l = pw.art, vfl_0 = pw.vfl;
-    const unsigned mk_0 = pw.mk;
-    const double ea_0 = pw.ea, h_0 = pw.h, cor_0 = pw.cor;
-    const double adx2d = pw.adx2d, drx2d = pw.drx2d, wusurf = pw.wusurf, wubot = pw.wubot, ady2d = pw.ady2d, dry2d = pw.dry2d, wvsurf = pw.wvsurf, wvbot = pw.wvbot;
-    double aru = pw.aru, arv = pw.arv;
-    const double etf_o = pw.etf, egf_o = pw.egf, utf_o = pw.utf, vtf_o = pw.vtf;
+    // ---- requests: the pointwise operands of this row first (used below), then the stencil row of the next iteration
+    const double el_0 = bld2(XD(X2_el), vo, ro), elb_0 = bld2(XD(X2_elb), vo, ro);
+    const double art_l = FLD(art, o_area, ro), vfl_0 = FLD(vfluxf, vo, ro);
+    const unsigned mk_0 = P.m8[(size_t)WAVE_UNIFORM(j - 1) * (size_t)P.iml + (size_t)(i - 1)];
+    const double ea_0 = FLD(e_atmos, vo, ro), h_0 = FLD(h, vo, ro), cor_0 = FLD(cor, vo, ro);
+    double adx2d = 0., aru = 0., drx2d = 0., wusurf = 0., wubot = 0., ady2d = 0., arv = 0., dry2d = 0., wvsurf = 0., wvbot = 0.;
+    double etf_o = 0., egf_o = 0., utf_o = 0., vtf_o = 0.;
+    if (LIVE) {
+      adx2d = FLD(adx2d, vo, ro); aru = FLD(aru, o_area, ro); drx2d = FLD(drx2d, vo, ro);
+      wusurf = FLD(wusurf, vo, ro); wubot = FLD(wubot, vo, ro);
+      ady2d = FLD(ady2d, vo, ro); arv = FLD(arv, o_area, ro); dry2d = FLD(dry2d, vo, ro);
+      wvsurf = FLD(wvsurf, vo, ro); wvbot = FLD(wvbot, vo, ro);
+      etf_o = FLD(etf, o_etf_ld, ro); egf_o = FLD(egf, o_acc_ld, ro); utf_o = FLD(utf, o_acc_ld, ro); vtf_o = FLD(vtf, o_acc_ld, ro);
+    }
     ExtRow rn = load_row(j + 2 <= P.jml ? j + 2 : P.jml);
     const double fsm_0 = (double)(mk_0 & 1u), dum_0 = (double)((mk_0 >> 1) & 1u), dvm_0 = (double)((mk_0 >> 2) & 1u);
     const unsigned o_st = out ? vo : BOFF_NONE;
@@ -1016,7 +990,6 @@ __global__ void __launch_bounds__(256) k_ext_march(KP P, int store_f, int rim_wg
     rm = rc; rc = rp;
     rn.dW = WTRUE(rn.d, rn.dW); rn.dyW = WTRUE(rn.dy, rn.dyW);
     rp = rn;
-    if (AHEAD) pw = pwn;
   };
   row_step(jw, std::false_type());
   for (int j = j0; j <= j1; j++) row_step(j, std::true_type());
@@ -1167,16 +1140,21 @@ struct EAcc { double egf, utf, vtf, etf; };
 #define RING_HI 2
 // P.iext = n (the first substep of the pair), P.x2 = generation X, P.y2 = generation Z; T: generation Y next to the ring, for
 // the ring's second substep
-__global__ void __launch_bounds__(256) k_ext_march2(KP P, Gen7 T, GenD GX, GenD GZ, GenD GT, int store_f2, int ring_wgs, int rows, const int *areas, int use_areas) {
+__global__ void __launch_bounds__(256) k_ext_march2(KP P, Gen7 T, GenD GX, GenD GZ, GenD GT, int store_f2, int ring_wgs, int rows, const int *areas, int use_areas, int ring_first) {
   const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), lane = gx & 63, wg = gx >> 6;
-  if (wg < ring_wgs) {                                       // the ring's FIRST substep (X -> T), beside the marching workgroups
+  // The ring's FIRST substep (X -> T) beside the marching workgroups -- as the LAST workgroups of the grid.  The marching grid is one
+  // round of workgroups that each need a whole CU (one wave per SIMD, ~400 registers): dispatched first, the ring's small workgroups
+  // landed on ~50 CUs whose marching workgroup then started a ring-workgroup's lifetime (~10 us) late, and the launch ended that much
+  // later; dispatched last they share the few CUs the march leaves free (the launcher keeps some).
+  const int nmw = (int)gridDim.x - ring_wgs;
+  if (ring_first ? wg < ring_wgs : wg >= nmw) {
     KP R = P;
 #pragma unroll
     for (int g = 0; g < POMGPU_NGEN; g++) R.y2[g] = T.p[g];
-    ext_ring_cell(R, wg * 256 + (int)threadIdx.y * 64 + lane, 0, RING_LO, RING_HI);
+    ext_ring_cell(R, (ring_first ? wg : wg - nmw) * 256 + (int)threadIdx.y * 64 + lane, 0, RING_LO, RING_HI);
     return;
   }
-  const int L = wg - ring_wgs;
+  const int L = ring_first ? wg - ring_wgs : wg;
   // A workgroup = four ADJACENT wavefronts of one segment (not four segments of one column block as in k_ext_march): the segments
   // are tall here (one round of workgroups: ~55 rows at 2048x1536), and four wavefronts a megabyte apart in each of ~30 arrays
   // cycle through more 2-MiB pages than a CU's first-level TLB holds (k_profq's lesson, profiles/round2_tlb_profq.txt) -- side by
@@ -1514,31 +1492,11 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
     int rows = (int)(wave_rows / 7400);
     rows = rows < 2 ? 2 : (rows > 7 ? 7 : rows);
     if (SW(c, EXT_ROWS)) rows = (int)SWV(c, EXT_ROWS);
-    const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
-    const bool large = wave_rows >= 16500 || SW(c, EXT_MARCH);
-    bool ahead = false;
-    if (!large && !SW(c, EXT_NOAHEAD) && Q.im >= 8 && Q.jm >= 8) {
-      // small tiles (the extended tile of a 4- or 8-tile split; small grids): ONE wavefront per SIMD marching with every operand a row
-      // ahead (k_ext_march<true>) -- segments as tall as it takes for the wavefronts to fill the chip's SIMDs once
-#ifdef POMGPU_EMU
-      const int nsimd = 1024;
-#else
-      static int nsimd = 0;
-      if (!nsimd) {
-        hipDeviceProp_t pr;
-        nsimd = 4 * ((hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256);
-      }
-#endif
-      rows = (int)((wave_rows + nsimd - 1) / nsimd);
-      if (rows < 4) rows = 4;
-      if (SW(c, EXT_AHEAD_ROWS)) rows = (int)SWV(c, EXT_AHEAD_ROWS);
-      ahead = true;
-    }
     const int nseg = rows > 0 ? (Q.jmm1 - 3 + 1 + rows - 1) / rows : 0, nbx = (int)g.x;
-    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (large || ahead)) {
+    const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);       // blk2d through one 32-bit buffer descriptor
+    if (fits && rows >= 2 && rows <= 256 && Q.jmm1 >= 3 && (wave_rows >= 16500 || SW(c, EXT_MARCH))) {
       const int rim_wgs = ((n + 255) / 256 + 7) / 8 * 8, gpx = ((nseg + 3) / 4 + 7) / 8;
-      if (ahead) LAUNCHN(c, "k_ext_step_adv", k_ext_march<true>, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
-      else LAUNCHN(c, "k_ext_step_adv", k_ext_march<false>, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
+      LAUNCHN(c, "k_ext_step_adv", k_ext_march, dim3((unsigned)(rim_wgs + 8 * gpx * nbx), 1, 1), blk2(), Q, store_f, rim_wgs, rows, (const int *)c->d_areas, SW(c, EXT_AREAS_LOAD) ? 0 : 1);
       return;
     }
   }
@@ -1551,6 +1509,9 @@ void launch_ext_step(pomgpu_ctx *c, const KP &Q, int store_f, int fuse_adv) {
 // generation read, y2 = the generation written (the other buffer set); T: a third set for the rim's / the band's intermediate
 // generation.  Returns 1 when launched, 0 when the tile is not one for this path (the caller takes the substeps one by one).
 // is the tile one for that path?  (without launching: pomgpu_mode_external decides with it whether an odd substep may wait for its partner)
+#ifndef POMGPU_EXT_PAIR_MIN_WAVE_ROWS
+#define POMGPU_EXT_PAIR_MIN_WAVE_ROWS 6000
+#endif
 int launch_ext_pair_ok(const pomgpu_switches &sw, const KP &Q) {
 #ifdef POMGPU_EMU
   (void)Q; (void)sw;
@@ -1559,10 +1520,12 @@ int launch_ext_pair_ok(const pomgpu_switches &sw, const KP &Q) {
   if (sw.on[SW_EXT_NOPAIR]) return 0;
   const bool fits = (size_t)POM_NBLK2D * Q.n2 * 8 < ((size_t)1 << 32);         // blk2d through one 32-bit buffer descriptor
   if (!fits || Q.im < 16 || Q.jm < 16) return 0;
-  // small tiles keep the one-substep kernels unless asked (tests): the ring's ~20 us of dependent latency per pair and the few
-  // wavefronts of a small tile eat the gain (profiles/round3_ext_pair.txt: the extended tile of an 8-tile split)
+  // small grids keep the one-substep kernels unless asked (tests): the ring's ~16 us of dependent latency per pair eats the gain
+  // there.  The extended tile of a 4- or 8-tile split of 2048x1536 (33 x 452 / 33 x 260 wavefront-rows) gains since it shrinks as
+  // it goes stale (round 4: 1.17 -> 1.07 / 1.99 -> 1.92 ms per step before the window reached this path).  Decided on the WHOLE
+  // tile: the windows of later pairs are smaller.
   const long wave_rows = (long)grid2_halo(Q).x * (Q.jmm1 - 2);
-  if (wave_rows < 16500 && !sw.on[SW_EXT_PAIR]) return 0;
+  if (wave_rows < POMGPU_EXT_PAIR_MIN_WAVE_ROWS && !sw.on[SW_EXT_PAIR]) return 0;
   return 1;
 #endif
 }
@@ -1571,7 +1534,7 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   (void)c; (void)Q; (void)T; (void)store_f2;
   return 0;
 #else
-  if (!launch_ext_pair_ok(c->sw, Q)) return 0;
+  if (Q.im < 16 || Q.jm < 16) return 0;                      // (the caller has asked launch_ext_pair_ok about the whole tile; Q may be a window of it)
   static int ncu = 0;
   if (!ncu) {
     hipDeviceProp_t pr;
@@ -1583,10 +1546,11 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   int rows = 0;
   double best = 1e30;
   const int ncg = (nbx + 3) / 4;
+  const int ncu_m = ncu > 16 ? ncu - 4 : ncu;                 // a few CUs stay free for the ring's workgroups (the last ones of the grid)
   for (int r = 6; r <= 96; r++) {
     const int nseg = (nrow + r - 1) / r;
     const long nwg = (long)ncg * nseg;
-    const double cost = (double)((nwg + ncu - 1) / ncu) * (r + 4.5);
+    const double cost = (double)((nwg + ncu_m - 1) / ncu_m) * (r + 4.5);
     if (cost < best) { best = cost; rows = r; }
   }
   if (SW(c, EXT_ROWS2)) rows = (int)SWV(c, EXT_ROWS2);
@@ -1612,7 +1576,7 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   if (!gen_of(Q.x2, GX) || !gen_of(Q.y2, GZ) || !gen_of(T, GT)) return 0;
   // launch 1: the ring's first substep (X -> T) as the first workgroups, the marching workgroups beside them (X -> Z, band of Y -> T)
   LAUNCHN(c, "k_ext_pair", k_ext_march2, dim3((unsigned)(ring_wgs + nseg * ncg), 1, 1), blk2(), Q, Tg, GX, GZ, GT, store_f2, ring_wgs, rows, (const int *)c->d_areas,
-          SW(c, EXT_AREAS_LOAD) ? 0 : 1);
+          SW(c, EXT_AREAS_LOAD) ? 0 : 1, SW(c, EXT_RING_FIRST) ? 1 : 0);
   // launch 2: the ring's second substep (T -> Z)
   KP R2 = Q;
   for (int g = 0; g < POMGPU_NGEN; g++) R2.x2[g] = T[g];

@@ -477,6 +477,10 @@ __global__ void k_profq_prod_lines(KP P, int rho_rt) {
   else { if (t > P.im) return; i = t; j = line == 4 ? 1 : (line == 5 ? 2 : (line == 6 ? P.jmm1 : P.jm)); }
   double *prod = P.s3[0];
   double p = 0.;
+  // a line of owned cells (i = 2, imm1; j = 2, jmm1) is only READ by the pack kernel of the exchange that follows: it is evaluated
+  // where that side has a neighbour (whole-row tiles: two lines of the eight); the ghost lines hold 0 until the exchange fills them
+  const bool wanted = line == 1 ? !P.W : (line == 2 ? !P.E : (line == 5 ? !P.S : (line == 6 ? !P.N : true)));
+  if (!wanted) return;
   if (k >= 2 && k <= P.kbm1 && i >= 2 && i <= P.imm1 && j >= 2 && j <= P.jmm1) {
     const double dh = h_(i, j) + F2(etf, i, j);
     const double sef = 1., shiw = 0.;

@@ -1018,7 +1018,21 @@ static int ext_pair(pomgpu_ctx *c, int iext, int store_f = 0) {
   double *canon[POMGPU_NGEN];
   for (int n = 0; n < POMGPU_NGEN; n++) canon[n] = P.b2 + (size_t)X2_SLOT[n] * P.n2;
   for (int n = 0; n < POMGPU_NGEN; n++) Q.y2[n] = stay ? t->alt3[n] : t->ext_parity ? canon[n] : t->alt2[n];
-  if (!launch_ext_pair(t, Q, stay ? canon : t->alt3, store_f || iext + 1 == isplit)) return 0;
+  double *third[POMGPU_NGEN];
+  for (int n = 0; n < POMGPU_NGEN; n++) third[n] = stay ? canon[n] : t->alt3[n];
+  if (t->parent && !SW(c, WIDE_FULL)) {
+    // the extended tile shrinks as it goes stale (mode_external above): both substeps of the pair run on the window of the FIRST one
+    // (the second one's is a row smaller on every extended side: a subset)
+    const pomgpu_wide &Wd = t->parent->wide;
+    int cut = iext - 1 < Wd.w - 5 ? iext - 1 : Wd.w - 5;
+    if (cut < 0) cut = 0;
+    const int lo = Wd.oy > 0 ? cut : 0, hi = P.jm - t->parent->P.jm - Wd.oy > 0 ? cut : 0;
+    if (lo + hi > 0 && P.jm - lo - hi >= 16) {
+      Q = row_window(Q, lo, hi);
+      for (int n = 0; n < POMGPU_NGEN; n++) third[n] += (size_t)lo * P.iml;
+    }
+  }
+  if (!launch_ext_pair(t, Q, third, store_f || iext + 1 == isplit)) return 0;
   if (stay) for (int n = 0; n < POMGPU_NGEN; n++) { double *x = t->alt2[n]; t->alt2[n] = t->alt3[n]; t->alt3[n] = x; }
   else t->ext_parity ^= 1;                                    // two substeps, one change of buffer sets
   ext_buffers(t);
@@ -1388,6 +1402,7 @@ static int wide_begin(pomgpu_ctx *c) {
 static void wide_flush(pomgpu_ctx *c) {
   pomgpu_wide &Wd = c->wide;
   if (!Wd.on || !Wd.pending) return;
+  side_join(c);                                               // a deferred realvertvl on the side stream reads the etf this scatter rewrites
   ext_canonical(Wd.x);
   table_run(c, Wd.scatter);
   Wd.pending = 0;
@@ -1426,7 +1441,31 @@ extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {
   if ((iext & 1) && ext_pair_ok(c, iext)) { c->ext_deferred = iext; return POMGPU_OK; }
   return mode_external(c, 1);
 }
-extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-537
+// wr (solver.f:2024-2067) and its exchange (:2055) on the side stream: nobody on the hot path reads wr (a diagnostic for the
+// output file), so realvertvl itself may run there as well (with_kernel: beside the NEXT step's external substeps, below)
+static int wr_on_side(pomgpu_ctx *c, int with_kernel) {
+  const KP &P = c->P;
+  side_join(c);                                               // at most one piece of side work outstanding per event
+  side_begin(c);
+  if (with_kernel) launch_realvertvl(c);
+  double *arr[1] = {D3(c, wr)};
+  const int nz[1] = {P.kbm1};
+  const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
+  size_t cnt[8];
+  for (int d = 0; d < 8; d++) cnt[d] = c->tp.nbr[d] >= 0 ? (size_t)P.kbm1 * len[d] : 0;
+  int rcw = launch_halo_pack8(c, arr, nz, 1, c->tp.send2) ? fail(c, POMGPU_EINVAL, "wr exchange: bad array list") : POMGPU_OK;
+  if (!rcw) rcw = pomgpu_tp_move_side(c, cnt, cnt);
+  if (!rcw) (void)launch_halo_unpack8(c, arr, nz, 1, (const double *const *)c->tp.recv2);
+  side_end(c, c->ev_side);
+  c->side_pending = 1;
+  return rcw;                                                 // a failed round is the step's failure (error_status is set)
+}
+// defer_wr (pomgpu_run, every step but the last of the call): realvertvl and wr's exchange are left to the next step, which runs
+// them on the side stream beside its external substeps (wr_deferred) -- on a tile those are ~30 small dependent launches on the
+// extended tile's own arrays that leave most of the chip idle, while realvertvl is a plain pass over five 3-D arrays.  Its
+// operands (w, u, v, dt, et, etb, etf of the tile) are written next by the scatter that ends the external mode (wide_flush: etf)
+// and by the 3-D part of mode_internal: wide_flush joins the side stream first.
+static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-537
   NEED_HOT(c);
   KP &P = c->P;
   const pom_blkcon &k = c->con;
@@ -1519,29 +1558,19 @@ extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) {          // advance.f:356-5
     }
   }
   launch_int_tail(c);                                         // :525-531, and the derived coefficients of the new dt (k_coef_dt's) in the same pass
-  launch_realvertvl(c);                                       // :534
-  if (c->tp.on && c->exch && c->wide.split && c->tp.wr_side) {     // wr_side: no rank asked for POMGPU_WR_MAIN (agreed with side_agreed)
-    // solver.f:2055 on the side stream: nobody on the hot path reads wr's ghost cells (a diagnostic for the output
-    // file), so the round runs beside check_velocity and the next step's lateral_viscosity; the next step's early gather
-    // follows it on the same stream, and whoever looks at the state waits for it (side_join)
-    side_join(c);                                             // at most one piece of side work outstanding per event
-    side_begin(c);
-    double *arr[1] = {D3(c, wr)};
-    const int nz[1] = {P.kbm1};
-    const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
-    size_t cnt[8];
-    for (int d = 0; d < 8; d++) cnt[d] = c->tp.nbr[d] >= 0 ? (size_t)P.kbm1 * len[d] : 0;
-    int rcw = launch_halo_pack8(c, arr, nz, 1, c->tp.send2) ? fail(c, POMGPU_EINVAL, "wr exchange: bad array list") : POMGPU_OK;
-    if (!rcw) rcw = pomgpu_tp_move_side(c, cnt, cnt);
-    if (!rcw) (void)launch_halo_unpack8(c, arr, nz, 1, (const double *const *)c->tp.recv2);
-    side_end(c, c->ev_side);
-    c->side_pending = 1;
-    if (rcw) return rcw;                                      // a failed round is the step's failure (error_status is set)
-  } else {
-    xch(c, 1, D3(c, wr), P.kbm1);                             // solver.f:2055
+  const bool side_wr = c->tp.on && c->exch && c->wide.split && c->tp.wr_side;   // wr_side: no rank asked for POMGPU_WR_MAIN (agreed with side_agreed)
+  if (side_wr && defer_wr && c->wide.on && !SW(c, WR_NODEFER)) {
+    c->wr_deferred = 1;                                       // :534 and solver.f:2055 beside the next step's external substeps
+    return POMGPU_OK;
   }
+  launch_realvertvl(c);                                       // :534
+  // solver.f:2055 on the side stream: the round runs beside check_velocity and the next step's lateral_viscosity; the next
+  // step's early gather follows it on the same stream, and whoever looks at the state waits for it (side_join)
+  if (side_wr) return wr_on_side(c, 0);
+  xch(c, 1, D3(c, wr), P.kbm1);                               // solver.f:2055
   return POMGPU_OK;
 }
+extern "C" int pomgpu_mode_internal(pomgpu_ctx *c) { return mode_internal(c, 0); }
 extern "C" int pomgpu_check_velocity(pomgpu_ctx *c, double *vamax, int *imax, int *jmax) {   // advance.f:611-641
   NEED(c);
   launch_check_velocity(c);
@@ -1679,7 +1708,9 @@ extern "C" int pomgpu_domain_stats(pomgpu_ctx *c, double *out, int sums_only) { 
   out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; out[3] = s[3]; out[4] = tavg; out[5] = savg; out[6] = eavg; out[7] = s[6];
   return POMGPU_OK;
 }
-extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
+static int advance(pomgpu_ctx *c, int more_steps_follow);
+extern "C" int pomgpu_advance(pomgpu_ctx *c) { return advance(c, 0); }
+static int advance(pomgpu_ctx *c, int more_steps_follow) {    // advance.f:6-59
   NEED_HOT(c);
   int rc;
   if ((rc = pomgpu_get_time(c))) return rc;
@@ -1698,6 +1729,10 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   const int defer_rt = k0.mode == 3 && (k0.iint != 1 || k0.time0 != 0.) && !SW(c, RHO_ROUNDTRIP);   // rho's readers before dens: k_profq, k_profq_prod(_lines)
   if ((rc = lateral_viscosity(c, sum2d, defer_rt))) return rc;
   if ((rc = mode_interaction(c, sum2d))) return rc;           // with the wide-halo mode: on the extended tile from here ...
+  if (c->wr_deferred) {                                       // the previous step's realvertvl + wr exchange, beside this step's external substeps
+    c->wr_deferred = 0;
+    if ((rc = wr_on_side(c, 1))) return rc;
+  }
   const int ph_ext = prof_phase_open(c);                      // "phase_external": the isplit substeps of mode_external (advance.f:27-29)
   if (!ext_loop_all(c))
   for (int iext = 1; iext <= c->con.isplit; iext++) {
@@ -1707,16 +1742,17 @@ extern "C" int pomgpu_advance(pomgpu_ctx *c) {                // advance.f:6-59
   }
   prof_phase_close(c, ph_ext, "phase_external");
   c->con.iext = c->con.isplit + 1;
-  if ((rc = pomgpu_mode_internal(c))) return rc;
+  if ((rc = mode_internal(c, more_steps_follow))) return rc;
   launch_check_velocity(c);   // result stays on the device; error flag is merged at the next get_con
   prof_phase_close(c, ph_step, "phase_step");
   return POMGPU_OK;
 }
 extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
   NEED_HOT(c);
+  c->wr_deferred = 0;                                         // (a step that failed half way may have left it)
   for (int n = 0; n < nsteps; n++) {
     c->con.iint += 1;
-    int rc = pomgpu_advance(c);
+    int rc = advance(c, n + 1 < nsteps);                      // the last step of the call leaves nothing to a next one
     if (rc) return rc;
   }
   return POMGPU_OK;

@@ -24,6 +24,15 @@ def init(backend: str | None = None):
     return rank, world, local
 
 
+def cpu_barrier(group=None):
+    """A barrier for processes that must not touch the GPU (rank supervisors, the CPU-baseline workers of bench.py):
+    torch.distributed.barrier() on a gloo group initialises the GPU runtime in this torch build (measured on the GPU box,
+    tools/diag/kfd_open.py: /dev/kfd opens at the first barrier, whatever *_VISIBLE_DEVICES says) -- a reduction of a CPU
+    tensor does not."""
+    t = torch.zeros(1)
+    dist.all_reduce(t, group=group)
+
+
 def tile_for_rank(rank: int, world: int, im_global: int, jm_global: int):
     nx, ny = choose_tile_grid(world, im_global, jm_global)
     if os.environ.get("POM_TILE_GRID"):          # developer switch: "2x4" forces nproc_x x nproc_y

@@ -31,6 +31,9 @@ from extpom_amd.lib import OPP
 from extpom_amd.model import PomGpu
 
 SCRATCH = {"tps", "fluxua", "fluxva", "zflux"}
+# fp32-storage variant on tiles: the envelope of its difference to the single tile after a few steps (fp32 rounding is 6e-8; the
+# temperature and salinity fields carry it directly, the elevation through the pressure gradient)
+F32_BOUND = {"t": 1e-5, "s": 1e-5, "tb": 1e-5, "sb": 1e-5, "rho": 1e-4}
 T0 = time.time()
 
 
@@ -84,7 +87,7 @@ def main():
     # ---- 1 x world whole-row tiles, one host thread each -------------------------------------------------------------
     iml, jml = decomp.local_size(im, jm, 1, world)
     tiles = [decomp.make_tile(r, im, jm, iml, jml, n_proc=world) for r in range(world)]
-    board, errs, bad, info = Board(world), [], [], {}
+    board, errs, bad, info, worst = Board(world), [], [], {}, {}
 
     def rank(r):
         try:
@@ -128,8 +131,17 @@ def main():
                     continue
                 ref = np.ascontiguousarray(a.field(n)[..., jo:jo + tj, io:io + ti][..., sl_j, sl_i])
                 got = np.ascontiguousarray(st.field(n)[..., :tj, :ti][..., sl_j, sl_i])
-                if not np.array_equal(ref.view(np.int64), got.view(np.int64)):     # the bits, the sign of a zero included
-                    bad.append((r, n, float(np.abs(ref - got).max())))
+                if libpath is None:
+                    if not np.array_equal(ref.view(np.int64), got.view(np.int64)):     # the bits, the sign of a zero included
+                        bad.append((r, n, float(np.abs(ref - got).max())))
+                else:
+                    # the fp32-storage study variant is NOT decomposition-invariant bit for bit: a fused kernel integrates the values it has
+                    # in registers (fp64) where the tile path's edge-line kernels re-read them from memory (rounded to fp32) -- storage
+                    # rounding enters at other places, and the flow amplifies it like any other fp32-level difference
+                    rel = float(np.abs(ref - got).max() / max(float(np.abs(a.field(n)).max()), 1e-300))
+                    worst[n] = max(worst.get(n, 0.0), rel)
+                    if n in F32_BOUND and rel > F32_BOUND[n]:
+                        bad.append((r, n, rel))
             beat(f"tile {r} compared")
         except Exception as e:                        # noqa: BLE001 -- a dead rank must not leave the others at the barrier
             import traceback
@@ -146,6 +158,9 @@ def main():
         sys.exit(2)
     print(f"message rounds per step and tile: {[round(v[0] / steps, 2) for v in info.values()]} between kernels, "
           f"{[round(v[1] / steps, 2) for v in info.values()]} on the second stream")
+    if worst:
+        print("fp32-storage variant, tiles against one tile, largest difference relative to the field's largest magnitude:",
+              {k: float(f"{v:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]})
     if bad:
         print("MISMATCH", bad[:20])
         sys.exit(1)

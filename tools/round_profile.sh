@@ -1,21 +1,30 @@
 #!/bin/bash
 # round-end measurement on a GPU box: bench lines, rocprofv3 kernel stats and HBM-traffic counters
-# (separate --pmc passes, never mixed with trace domains other than --kernel-trace)
-TAG=${1:-r2}
+# (separate --pmc passes, never mixed with trace domains other than --kernel-trace).  Two parts, one gpurun call each:
+#   tools/round_profile.sh r4 A   the bench lines, kernel stats, counters, traffic.json of THIS build and the line that quotes it
+#   tools/round_profile.sh r4 B   one tile of the 2 / 4 / 8-tile split, the multi-rank rehearsals on one GPU, the fp32-storage study lines
+TAG=${1:-r4}
+PART=${2:-A}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-python bench.py --side-config > $O/bench_basin2048_with_config1.json 2> $O/bench_basin2048.err; tail -c 300 $O/bench_basin2048_with_config1.json; echo
-python bench.py --workload seamount256 --steps 20 > $O/bench_seamount256.json 2>/dev/null
-python bench.py --workload basin1024 --steps 5 > $O/bench_basin1024.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
-for set in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$set -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$set.log 2>&1
-done
-python3 tools/pmc_summarise.py $O > $O/pmc_summary.csv 2>&1 || true
-# profiles/traffic.json of THIS build (bench.py quotes roofline.traffic only when the build ids agree), then the line that carries it
-python3 tools/make_traffic_json.py $O/pmc_summary.csv > $O/traffic_make.log 2>&1 && cp profiles/traffic.json $O/traffic.json
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
-POM_BENCH_REHEARSE=1 timeout -k 10 400 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 > $O/rehearse2.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
-POM_BENCH_REHEARSE=1 timeout -k 10 400 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 > $O/rehearse4.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
-find $O -name "*kernel_stats.csv" | head -3
+if [ $PART = A ]; then
+  timeout -k 10 700 python bench.py --steps 20 --warmup 5 > $O/bench_basin2048.json 2> $O/bench_basin2048.err; echo "bench rc=$?"; tail -c 300 $O/bench_basin2048.json; echo
+  python bench.py --workload seamount256 --steps 40 --no-cpu-baseline > $O/bench_seamount256.json 2>/dev/null
+  python bench.py --workload basin1024 --steps 10 --no-cpu-baseline > $O/bench_basin1024.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_line_under_rocprofv3_kernel_trace.json 2> $O/stats.err
+  for set in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$set -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$set.log 2>&1
+  done
+  python3 tools/pmc_summarise.py $O > $O/pmc_summary.csv 2>&1 || true
+  # profiles/traffic.json of THIS build (bench.py quotes roofline.traffic only when the build ids agree), then the line that carries it
+  python3 tools/make_traffic_json.py $O/pmc_summary.csv > $O/traffic_make.log 2>&1 && cp profiles/traffic.json $O/traffic.json
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
+  find $O -name "*kernel_stats.csv" | head -3
+else
+  for n in 8 4 2; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_2ranks_one_gpu_basin1024.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
+  POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin1024.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
+  timeout -k 10 300 python bench.py --storage f32 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_f32_storage_study.json 2> $O/f32.err; echo "f32 rc=$?"
+  POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --storage f32 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline --no-alternate > $O/rehearsal_2ranks_one_gpu_basin1024_f32_storage.json 2> $O/rehearse2f32.err; echo "rehearse2 f32 rc=$?"
+fi
 ls $O
