@@ -1574,9 +1574,15 @@ int launch_ext_pair(pomgpu_ctx *c, const KP &Q, double *const *T, int store_f2) 
   };
   GenD GX, GZ, GT;
   if (!gen_of(Q.x2, GX) || !gen_of(Q.y2, GZ) || !gen_of(T, GT)) return 0;
-  // launch 1: the ring's first substep (X -> T) as the first workgroups, the marching workgroups beside them (X -> Z, band of Y -> T)
+  // launch 1: the ring's first substep (X -> T) beside the marching workgroups (X -> Z, band of Y -> T), as the grid's LAST workgroups
+  // where the march is long, as its FIRST ones where it is short.  The ring's workgroups are workgroups of this kernel -- one wave
+  // per SIMD like the marching ones -- so each takes a CU for its ~10 us.  Measured in one process each (round 4, ms per step for the
+  // 15 pairs): 2048x1536 (57-row segments) first 4.04, last 3.52; extended tile of a 4-tile split (16 rows) 1.49 / 1.40; of an 8-tile
+  // split (10 rows) 0.85 / 1.03 -- behind a short march the ring's dependent loads queue up behind the march's opening burst and
+  // the launch ends with them.  POMGPU_EXT_RING_FIRST = 1 / 2 forces first / last.
+  const int ring_first = SW(c, EXT_RING_FIRST) ? ((int)SWV(c, EXT_RING_FIRST) == 1) : (rows <= 12);
   LAUNCHN(c, "k_ext_pair", k_ext_march2, dim3((unsigned)(ring_wgs + nseg * ncg), 1, 1), blk2(), Q, Tg, GX, GZ, GT, store_f2, ring_wgs, rows, (const int *)c->d_areas,
-          SW(c, EXT_AREAS_LOAD) ? 0 : 1, SW(c, EXT_RING_FIRST) ? 1 : 0);
+          SW(c, EXT_AREAS_LOAD) ? 0 : 1, ring_first);
   // launch 2: the ring's second substep (T -> Z)
   KP R2 = Q;
   for (int g = 0; g < POMGPU_NGEN; g++) R2.x2[g] = T[g];

@@ -5,6 +5,7 @@
 // eleven full 3-D temporaries the reference streams through memory (solver.f:1224-1230,1552-1554).
 #include <type_traits>
 #include "pomgpu_internal.hpp"
+#include "dd_exp.h"
 
 #define dt_(i, j) F2(dt, i, j)
 #define dx_(i, j) F2(dx, i, j)
@@ -1016,9 +1017,9 @@ __global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsu
   const bool sw_ = (nbc == 2 || nbc == 4);
   const double r = r_[P.ntp - 1], ad1 = ad1_[P.ntp - 1], ad2 = ad2_[P.ntp - 1];
   const double swr = sw_ ? F2(swrad, i, j) : 0.;
-  // penetrative radiation at level k (0 at kb); the reference evaluates the exponentials in
-  // REAL(16) and rounds once (:1608-1611) -- here plain fp64 exp, see DESIGN.md (tolerance)
-#define RAD(k) ((sw_ && (k) <= kbm1) ? swr * (r * exp(F1(z, k) * dh / ad1) + (1. - r) * exp(F1(z, k) * dh / ad2)) : 0.)
+  // penetrative radiation at level k (0 at kb); the reference evaluates the expression in REAL(16) and rounds once (:1608-1611):
+  // proft_rad_q (dd_exp.h) returns that double from double-double arithmetic
+#define RAD(k) ((sw_ && (k) <= kbm1) ? proft_rad_q(swr, r, 1. - r, F1(z, k) * dh / ad1, F1(z, k) * dh / ad2) : 0.)
 #define ACOEF(k) (((k) <= kbm2) ? -P.dti2 * (F3(kh, i, j, (k) + 1) + P.umol) / (F1(dz, k) * F1(dzz, k) * dh * dh) : 0.)
 #define CCOEF(k) (-P.dti2 * (F3(kh, i, j, k) + P.umol) / (F1(dz, k) * F1(dzz, (k)-1) * dh * dh))
   const double a1 = ACOEF(1);
@@ -1096,7 +1097,7 @@ __global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg(KP P, double *f, 
   SCHED_FENCE();
   // ---- phase B: forward elimination
   const double r = r_[P.ntp - 1], ad1 = ad1_[P.ntp - 1], ad2 = ad2_[P.ntp - 1];
-#define RAD(k) ((SW && (k) <= kbm1) ? swr * (r * exp(F1(z, KC(k)) * dh / ad1) + (1. - r) * exp(F1(z, KC(k)) * dh / ad2)) : 0.)
+#define RAD(k) ((SW && (k) <= kbm1) ? proft_rad_q(swr, r, 1. - r, F1(z, KC(k)) * dh / ad1, F1(z, KC(k)) * dh / ad2) : 0.)
 #define ACOEF(k, khn) (-P.dti2 * ((khn) + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC(k)) * dh * dh))       /* khn = kh(k+1) */
 #define CCOEF(k, khk) (-P.dti2 * ((khk) + P.umol) / (F1(dz, KC(k)) * F1(dzz, KC((k)-1)) * dh * dh))   /* khk = kh(k)   */
   const double a1 = ACOEF(1, ee[1]);

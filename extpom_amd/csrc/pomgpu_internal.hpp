@@ -476,7 +476,7 @@ static inline void pomgpu_switches_read(pomgpu_switches &s) {
 // rounds exist and on which stream / communicator they run): the ranks compare it before any collective depends on it
 static inline unsigned pomgpu_switches_collective_digest(const pomgpu_switches &s) {
   static const int coll[] = {SW_ADVCT_SPLIT, SW_ADVQ_EXCHANGE, SW_PROD_FULL, SW_QFILTER_SPLIT, SW_UV_FULL_EXCHANGE, SW_NO_OVERLAP,
-                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT};
+                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT, SW_WR_NODEFER};
   unsigned h = 2166136261u;
   for (size_t n = 0; n < sizeof coll / sizeof coll[0]; n++) {
     h = (h ^ (unsigned)(s.on[coll[n]] ? 1 + coll[n] : 0)) * 16777619u;

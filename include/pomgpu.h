@@ -253,7 +253,11 @@ int pomgpu_write_restart(pomgpu_ctx *ctx, const char *path, const pomgpu_file_me
  * mode_interaction, isplit x mode_external, mode_internal, check_velocity (advance.f:6-59 minus print and
  * output, which stay on the host).  Does not synchronise. */
 int pomgpu_advance(pomgpu_ctx *ctx);
-/* nsteps x { iint = iint+1; advance }  (pom.f:17-19).  Does not synchronise. */
+/* nsteps x { iint = iint+1; advance }  (pom.f:17-19).  Does not synchronise.  On several tiles with the second stream agreed
+ * (pomgpu_rccl_init / pomgpu_transport_side_agree) every step but the last of the call leaves realvertvl (solver.f:2024-2067) and the
+ * exchange of wr (:2055) to the step that follows: they run on the second stream beside that step's external substeps -- wr has
+ * no reader on the hot path.  The last step of the call does both at once, so after the call the state is complete.  Like every
+ * call that posts message rounds, every rank makes it with the same nsteps. */
 int pomgpu_run(pomgpu_ctx *ctx, int nsteps);
 
 /* ---- the hot path: kernels (solver.f, bounds_forcing.f), device-resident ---------------- */

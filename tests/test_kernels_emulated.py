@@ -53,6 +53,24 @@ def test_steps_bit_identical(case, nml, steps):
     assert g.check_velocity() == ot.vamax
 
 
+@pytest.mark.parametrize("nbct,kb", [(2, 21), (4, 21), (2, 70)])
+def test_short_wave_penetration_bit_identical(nbct, kb):
+    """proft with nbc = 2 / 4 and swrad != 0: the reference evaluates the radiation term in REAL(16) and rounds once
+    (solver.f:1608-1611; the oracle with libquadmath), the kernels in double-double arithmetic (csrc/dd_exp.h) -- the same double.
+    kb = 70 takes the kernel with work vectors (k_proft), kb = 21 the register-resident one (k_proft_reg<24, 1>)."""
+    a = make_case("seamount", 65, 49, kb, dte=6.0, isplit=30, nbct=nbct)
+    a.swrad[...] = -5.0e-5 * a.fsm
+    oracle_finish_initial(a)
+    b = a.copy()
+    ot = OracleTile(a)
+    g = PomGpu(b, libpath=EMU)
+    for n in range(1, 7):
+        ot.run(1)
+        g.run(1)
+        g.download()
+        assert not diff(a, b), f"step {n}: {diff(a, b)}"
+
+
 @pytest.mark.parametrize("case,im,jm", [("seamount", 66, 50), ("island", 128, 12)])
 def test_even_leading_dimension_steps(case, im, jm):
     """an even im_local selects the two-columns-per-lane kernels (16-byte loads)"""

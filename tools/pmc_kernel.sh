@@ -1,13 +1,13 @@
 #!/bin/bash
 # developer tool (GPU box): HBM-side traffic and L2 counters of selected kernels for one library variant
-# usage: tools/pmc_kernel.sh <tag> <kernel-regex> [lib]
+# usage: tools/pmc_kernel.sh <tag> <kernel-regex> [lib]        (PMC_CMD="tools/tile_probe.py --tiles 8 --rank 4 --steps 1": another program than the bench)
 export TMPDIR=/tmp
 TAG=$1; PAT=$2; LIB=$3
 O=gpurun_out/pmc_$TAG; mkdir -p $O
 [ -n "$LIB" ] && export POMGPU_LIBPATH=$PWD/$LIB
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-30)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/$tag -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/$tag -- python3 ${PMC_CMD:-bench.py --steps 1 --warmup 1 --no-cpu-baseline} > $O/$tag.log 2>&1
 done
 python3 tools/pmc_summarise.py $O > $O/summary.csv 2>&1
 python3 - "$O/summary.csv" "$PAT" <<'PY'
