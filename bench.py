@@ -297,6 +297,16 @@ def _cpu_tiles_worker(workload):
     if rank == 0:
         print(json.dumps({"value": im * jm * kb * n / dt, "what": f"{case} {im}x{jm}x{kb}", "n": n, "seconds": dt,
                           "rounds_per_step": (halo.count - c0) / n}))
+    if os.environ.get("POM_BENCH_REPORT_DEVICE_FDS"):            # tests: a CPU worker must never have opened the GPU (the box's process guard counts them)
+        fds = set()
+        for f in os.listdir("/proc/self/fd"):
+            try:
+                t = os.readlink(f"/proc/self/fd/{f}")
+            except OSError:
+                continue
+            if "kfd" in t or "/dri/" in t:
+                fds.add(t)
+        print(f"DEVICE-FDS rank {rank}: {sorted(fds)}", flush=True)
     dist.destroy_process_group()
 
 

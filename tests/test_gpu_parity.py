@@ -777,3 +777,30 @@ def test_reference_call_sequence_pairs_its_external_substeps(monkeypatch):
     g.close()
     assert prof.get("k_ext_pair", (0, 0))[0] == 3 * (isplit // 2) - 1, {k: v[0] for k, v in prof.items() if "ext" in k}
     assert not diff(a, b), diff(a, b)
+
+
+@pytest.mark.gpu
+def test_bench_cpu_workers_never_open_the_gpu():
+    """bench.py's all-cores CPU leg starts one oracle process per core; the GPU boxes end a job in which more than a handful of
+    processes hold the device open (round 4: the default bench died of it -- torch.distributed.barrier() on a gloo group
+    initialises the GPU runtime; tools/diag/kfd_open.py).  Two workers of the smallest workload, on a box that HAS a GPU: neither
+    may have /dev/kfd or a render node open when it is done."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   POM_TILE_GRID="1x2", POM_BENCH_REPORT_DEVICE_FDS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--cpu-tiles-worker", "--workload", "seamount65"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for r, o in enumerate(outs):
+        assert f"DEVICE-FDS rank {r}: []" in o, o[-2000:]
+
