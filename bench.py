@@ -458,6 +458,12 @@ def supervise(args):
         rd.start()
         failkey = f"pass{k}_failed"
         limit = float(os.environ.get("POM_BENCH_PASS_LIMIT", 420.0 + 4.0 * (args.steps + args.warmup)))
+        # once a pass has completed, the others are the same work on the same machine: a pass that takes many times as long is hung, and
+        # the line -- which already has its number -- should not wait minutes for it (every supervisor computes the same limit: wall_s of
+        # a completed pass is broadcast below)
+        done_ok = [r["wall_s"] for r in results if r["ok"]]
+        if done_ok and "POM_BENCH_PASS_LIMIT" not in os.environ:
+            limit = min(limit, max(90.0, 8.0 * max(done_ok)))
         why = None
         while True:
             rc = child.poll()
@@ -508,9 +514,9 @@ def supervise(args):
         if ok and rank != 0:
             res.update(ms_per_step=0.0, value=0.0)
         results.append(res)
-        msbox = [res.get("ms_per_step")]
+        msbox = [res.get("ms_per_step"), res["wall_s"]]
         dist.broadcast_object_list(msbox, src=0)                # every supervisor plans the next pass from the same numbers
-        res["ms_per_step"] = msbox[0]
+        res["ms_per_step"], res["wall_s"] = msbox
     code = 0
     if rank == 0:
         good = [r for r in results if r["ok"]]
