@@ -477,6 +477,9 @@ struct LevCa { double c[5], h[ROWSHARE_SLOTS(5)]; };
 __global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
   constexpr int NS = 5, NH = ROWSHARE_SLOTS(NS), U = 0, V = 1, UB = 2, VB = 3, AM = 4;
   HALO_XCD_DECODE_R(LDS_ROWS)                                           // i0: 1-based column of this lane (0 for the very first halo lane)
+#ifdef POMGPU_WGTIME                                        // developer build (tools/wg_times.py): when does each workgroup run, and where?
+  const unsigned long long wgt0 = wall_clock64();
+#endif
   const int r = WAVE_UNIFORM((int)threadIdx.y), j0w = j - r;
   const bool jvalid = j <= P.jml;                           // rows beyond the tile shadow row jml and store nothing
   const int jc = jvalid ? j : P.jml;
@@ -635,6 +638,15 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
     }
     if (sum2d) { F2(adx2d, i, jc) = jrow ? ax2 : 0.; F2(ady2d, i, jc) = jrow ? ay2 : 0.; }
   }
+#ifdef POMGPU_WGTIME
+  __syncthreads();
+  if (threadIdx.y == 0 && lane == 0) {                      // four doubles per workgroup into wr (a diagnostic array nothing reads here)
+    double *rec = (double *)(P.b3 + (size_t)P3_wr * P.a3) + 4 * (size_t)L__;
+    rec[0] = (double)wgt0; rec[1] = (double)wall_clock64();
+    rec[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID: wave, simd, pipe, cu, sh, se ...
+    rec[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+  }
+#endif
 }
 
 // ---- advu + advv in one pass -- solver.f:734-788, :791-845 --------------------------------------------
