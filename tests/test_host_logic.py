@@ -200,3 +200,16 @@ def test_bench_tile_grids_follow_baseline_configs():
     assert bench.tile_grids("basin2048", 4) == ("1x4", "2x2") and bench.tile_grids("basin2048", 2)[0] == "1x2"
     with pytest.raises(SystemExit):
         bench.tile_grids("basin2048", 8, "3x3")
+
+
+def test_short_wave_term_in_double_double_equals_the_quad_evaluation(tmp_path):
+    """csrc/dd_exp.h (what the proft kernels evaluate for solver.f:1608-1611) against the REAL(16) expression as libquadmath
+    evaluates it, on arguments of proft's ranges (tools/check_dd_exp.cpp; 2e7 arguments there, 3e5 here): no result may differ."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "check_dd_exp")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_dd_exp.cpp"), "-lquadmath"])
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 results differ" in r.stdout, r.stdout[-500:]
