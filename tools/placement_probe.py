@@ -49,9 +49,42 @@ def hold(n):
         g.close()
 
 
+def pads(values):
+    """ONE region (a context created again in one process gets the same memory back: experiment A), another distance between the
+    arrays of blk3d each time (POMGPU_PAD3, 4-KiB pages): does the layout inside the region move a kernel?"""
+    from extpom_amd.model import PomGpu
+    case, im, jm, kb, desc = bench.WORKLOADS["basin2048"]
+    st = bench.build_state("basin2048", pdist.tile_for_rank(0, 1, im, jm))
+    g = bench.gpu_initialise(st, 0, None)
+    init = st.copy()
+    g.close()
+    print(f"{'PAD3':>10s} {'ms/step':>8s} " + " ".join(f"{k[2:12]:>10s}" for k in KERNELS), flush=True)
+    for v in values:
+        if v:
+            os.environ["POMGPU_PAD3"] = str(v)
+        else:
+            os.environ.pop("POMGPU_PAD3", None)
+        g = PomGpu(init.copy(), device=0)
+        g.run(3)
+        g.sync()
+        g.prof_begin()
+        g.run(3)
+        prof = g.prof_end()
+        t0 = time.perf_counter()
+        g.run(10)
+        g.sync()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        print(f"{v:10d} {ms:8.2f} " + " ".join(f"{prof.get(k, (0, 0.0))[1] / 3:10.3f}" for k in KERNELS), flush=True)
+        g.close()
+        del g
+        torch.cuda.empty_cache()
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "hold":
         return hold(int(sys.argv[2]))
+    if len(sys.argv) > 1 and sys.argv[1] == "pads":
+        return pads([int(a) for a in sys.argv[2:]] or [0, 1, 3, 16, 64, 257, 512, 1031, 4099, 0])
     sizes = [int(a) for a in sys.argv[1:]] or [0, 0, 512, 512, 3072, 3072, 9216, 9216, 0]
     case, im, jm, kb, desc = bench.WORKLOADS["basin2048"]
     st0 = bench.build_state("basin2048", pdist.tile_for_rank(0, 1, im, jm))
