@@ -6,8 +6,8 @@ lateral_viscosity, mode_interaction, isplit external substeps, mode_internal, ch
 
 N=1 runs in this process.  N>1: one rank per GPU, the global grid split into N tiles (strong scaling: the
 global grid is fixed) -- started by the caller under torch.distributed.run (WORLD_SIZE set), or, when
-`python bench.py --gpus N` is called plainly, by this script itself (`python -m torch.distributed.run --nproc-per-node N
-bench.py <same arguments>` as a CHILD process; reference launch shape: pom.sh:1 `mpiexec -n 8`, parallel_mpi.f:6-20).
+`python bench.py --gpus N` is called plainly, by this script itself (N child processes with the environment
+torch.distributed.run would give them; reference launch shape: pom.sh:1 `mpiexec -n 8`, parallel_mpi.f:6-20).
 Either way a rank's process is only a SUPERVISOR: it never touches the GPU.  It runs the measurement as a sequence of
 PASSES, each a fresh child process per rank with a rendezvous of its own and deadlines of its own:
   1. the primary tile grid, every message round on the kernels' stream (one stream, one communicator: POMGPU_NO_OVERLAP=1);
@@ -330,11 +330,14 @@ def side_config(workload, device, stream, steps=40, warmup=5):
 
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N rank supervisors as a child torch.distributed.run (one
-    per GPU, rendezvous on 127.0.0.1), pass its output through and return its exit code.  This process never initialises
-    the GPU, and nothing is re-executed in place."""
+    """`python bench.py --gpus N` without a launcher: start the N rank supervisors as child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1), pass rank 0's line through and return the worst
+    exit code.  This process never initialises the GPU, nothing is re-executed in place -- and no torch.distributed.run stands
+    between them: its elastic agent holds the GPU open (tools/diag/ancestors_kfd.py), one process more than the ranks on boxes
+    that count them.  (Under the driver's own torch.distributed.run the supervisors are its ranks: bench.supervise either way.)"""
     import socket
     import subprocess
+    import threading
     if os.environ.get("POM_BENCH_REHEARSE") != "1":
         import torch
         have = torch.cuda.device_count()                       # counting devices does not initialise the GPU in this process
@@ -344,20 +347,42 @@ def launch_ranks(n):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this pool
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    # the ranks' stdout is passed on line by line: the JSON line to stdout, anything a library wrote there (gloo's
-    # "[Gloo] Rank ..." banners in a rehearsal) to stderr, so that stdout holds the one line the contract asks for
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-    for line in child.stdout:
-        t = line.strip()
-        is_json = t.startswith("{") and t.endswith("}")
-        (sys.stdout if is_json else sys.stderr).write(line)
-        (sys.stdout if is_json else sys.stderr).flush()
-    return child.wait()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def pump(p):
+        # the ranks' stdout line by line: the JSON line to stdout, anything a library wrote there (gloo's "[Gloo] Rank ..." banners in
+        # a rehearsal) to stderr, so that stdout holds the one line the contract asks for
+        for line in p.stdout:
+            t = line.strip()
+            is_json = t.startswith("{") and t.endswith("}")
+            (sys.stdout if is_json else sys.stderr).write(line)
+            (sys.stdout if is_json else sys.stderr).flush()
+
+    readers = [threading.Thread(target=pump, args=(p,), daemon=True) for p in procs]
+    for t in readers:
+        t.start()
+    code, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc not in (None, 0) and failed_at is None:
+                failed_at = time.perf_counter()                 # a supervisor that died cannot tell the others: give them a moment, then end them
+        if failed_at is not None and time.perf_counter() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                    # exactly the processes this launcher started
+        time.sleep(0.25)
+    for t in readers:
+        t.join(timeout=5)
+    for p in procs:
+        code = max(code, abs(p.returncode or 0))
+    return code
 
 
 # ---- tile grids ----------------------------------------------------------------------------------------------------
@@ -870,6 +895,9 @@ def measure(args):
         print(json.dumps(out), flush=True)
     if g is not None:
         g.close()
+    if os.environ.get("POM_BENCH_REPORT_ANCESTORS") and rank == 0:   # developer: which of launcher / elastic agent / supervisor hold the GPU open?
+        import runpy
+        runpy.run_path(os.path.join(ROOT, "tools", "diag", "ancestors_kfd.py"))
     if world > 1:
         torch.distributed.barrier()
         deadline("done", 0)
