@@ -588,6 +588,7 @@ def main():
     ap.add_argument("--no-alternate", action="store_true", help="N > 1: skip the pass on the alternate tile grid")
     ap.add_argument("--only-pass", type=int, default=None, help="N > 1, developer: run only pass 0 (overlap off), 1 (overlap on) or 2 (alternate grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune-placement", action="store_true", help="N = 1: leave the 3-D arrays where the allocator put them (pomgpu_tune_placement is not called)")
     ap.add_argument("--side-config", action="store_true",
                     help="N=1: also time BASELINE configs[1] (seamount 256x256x30) in the same run; off by default so that a profile "
                          "of the default command holds the headline workload's kernels only")
@@ -676,6 +677,16 @@ def measure(args):
     f32 = args.storage == "f32"
     from extpom_amd import lib as _L
     g = gpu_initialise(st, local, stream, _L.LIBPATH_F32 if f32 else None)
+    # N = 1: where in HBM the 3-D arrays start is measured, not taken as it comes (pomgpu_tune_placement, include/pomgpu.h: up to 6 % per
+    # kernel, different from process to process, reproducible inside one): a few start offsets inside one allocation, three real steps
+    # each, the fastest kept -- before the warm-up; the line says what was tried (config.placement).  --no-tune-placement skips it.
+    placement = None
+    if world == 1 and not args.no_tune_placement:
+        try:
+            g.run(2)                                                # (the model's first step skips its 3-D part, advance.f:362: not a step to time)
+            placement = g.tune_placement(3, 8)
+        except Exception as e:                                     # noqa: BLE001 -- the measurement does not depend on it
+            print(f"bench: placement not tuned ({e})", file=sys.stderr)
     build_id = g.L.pomgpu_build_id().decode()
     exchange = "none"
     rccl_nranks = 0
@@ -841,6 +852,7 @@ def measure(args):
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
                        "overlap": (("second stream + second communicator for the early part of the wide exchange and wr" if overlap_on
                                     else "off: every message round on the kernels' stream (POMGPU_NO_OVERLAP)") if world > 1 else None),
+                       "placement": placement,                      # N = 1: start offsets of blk3d inside its allocation that were tried (MiB), ms per step of each, which was kept
                        "rccl_nranks": rccl_nranks,                  # what ncclCommCount reports for the library's communicator (0: no RCCL transport)
                        "message_rounds_ms_rank0": round(msg_ms, 3),
                        "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0,

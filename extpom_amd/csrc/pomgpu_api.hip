@@ -368,6 +368,11 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   pomgpu_tp_free(c);
   KP &P = c->P;
   (void)hipFree(P.r1);
+  if (c->tune_block) {                                        // pomgpu_tune_placement: blk3d and the scratch arrays are pieces of one allocation
+    (void)hipFree(c->tune_block);
+    c->tune_block = NULL; P.b3 = NULL;
+    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = NULL;
+  }
   (void)hipFree(P.b1); (void)hipFree(P.b2); (void)hipFree(P.b3); (void)hipFree(P.bd);
   for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
   for (int n = 0; n < POMGPU_NSCR2; n++) (void)hipFree(P.s2[n]);
@@ -1756,6 +1761,109 @@ extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
     if (rc) return rc;
   }
   return POMGPU_OK;
+}
+
+// ---- where in memory the 3-D arrays live ------------------------------------------------------------------------------------------
+// The same kernels on the same bytes run up to 6 % faster or slower with WHERE in the 288 GB their arrays lie (round 4,
+// profiles/round4_placement_probe.txt: blk3d starting 7200 MiB into its allocation instead of 0: the step 37.7 -> 36.3 ms in four
+// processes out of four on one box, k_profq 7.55 -> 7.2, k_advuv_col 2.99 -> 2.67; 8400-19200 MiB into it on another box: 39.0).
+// Which offsets are good differs from box to box and from process to process -- physical addresses and the memory system's
+// interleave are not visible to a user process -- but inside one process it is reproducible to 0.1 %.  So the placement is
+// MEASURED: blk3d and the 3-D scratch arrays move into ONE allocation with room in front, and a few start offsets (multiples
+// of two arrays, so that the move never overlaps itself inside a chunk) are tried with `steps` internal steps each -- real steps
+// of the model, timed with events on the kernels' stream; results do not depend on where an array lives -- and the fastest
+// is kept.  Costs one extra allocation of the arrays' size plus the room while it moves in, ~25 ms per move at 2048x1536x50,
+// and advances the model by ntried x (steps + 1) internal steps (one untimed step after every move).  Tiles below 64 MiB per array
+// are left alone (ntried = 0).
+static int range_move(pomgpu_ctx *c, double *dst, const double *src, size_t total, size_t chunk) {   // ranges may overlap; chunk <= |dst - src|
+  if (dst == src || !total) return POMGPU_OK;
+  const size_t nch = (total + chunk - 1) / chunk;
+  for (size_t q = 0; q < nch; q++) {
+    const size_t m = dst > src ? nch - 1 - q : q;             // moving up: from the end
+    const size_t o = m * chunk, len = (o + chunk <= total ? chunk : total - o);
+    HIPCHK(c, hipMemcpyAsync(dst + o, src + o, len * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, double *ms_out, long *front_mib_out, int *ntried, int *kept) {
+  NEED(c);
+  if (ntried) *ntried = 0;
+  if (kept) *kept = 0;
+#ifdef POMGPU_EMU
+  (void)steps; (void)max_try; (void)ms_out; (void)front_mib_out;
+  return POMGPU_OK;
+#else
+  KP &P = c->P;
+  if ((c->flags & POMGPU_CTX_2D) || !P.b3 || steps < 1 || max_try < 1) return fail(c, POMGPU_EINVAL, "tune_placement: a context with 3-D arrays, steps >= 1, max_try >= 1");
+  if (c->tp.on) return POMGPU_OK;                             // tiles: every rank would have to try alike (message rounds); their arrays are small
+  const size_t arr = P.a3 > P.n3 ? P.a3 : P.n3;
+  if (arr * sizeof(double) < ((size_t)64 << 20) && !SW(c, TUNE_FORCE)) return POMGPU_OK;
+  const size_t total = (size_t)POM_NBLK3D * P.a3 + (size_t)POMGPU_NSCR3 * P.n3, unit = 2 * arr;
+  static const int KS[16] = {0, 3, 10, 5, 2, 1, 7, 4, 15, 20, 12, 25, 30, 8, 6, 14};   // in units of two arrays, in the order they are tried
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
+  if (!c->tune_block) {
+    size_t fre = 0, tot = 0;
+    HIPCHK(c, hipMemGetInfo(&fre, &tot));
+    int kmax = max_try > 8 ? 30 : 10;                         // the room in front: 10 units (24 GB at 2048x1536x50) unless more trials are asked for
+    while (kmax > 0 && (total + (size_t)kmax * unit) * sizeof(double) + ((size_t)2 << 30) > fre) kmax--;
+    if (kmax < 1) return POMGPU_OK;                           // no room to move: the placement stays what it is
+    double *blk = NULL;
+    if (hipMalloc((void **)&blk, (total + (size_t)kmax * unit) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return POMGPU_OK; }
+    HIPCHK(c, hipMemcpyAsync(blk, P.b3, (size_t)POM_NBLK3D * P.a3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    for (int n = 0; n < POMGPU_NSCR3; n++)
+      HIPCHK(c, hipMemcpyAsync(blk + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3, P.s3[n], P.n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(P.b3);
+    for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
+    c->tune_block = blk;
+    c->tune_front = 0;
+    c->tune_kmax = kmax;
+    P.b3 = blk;
+    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = blk + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3;
+  }
+  auto rebase = [&](size_t front) -> int {
+    const int rc = range_move(c, c->tune_block + front, c->tune_block + c->tune_front, total, arr);
+    if (rc) return rc;
+    c->tune_front = front;
+    P.b3 = c->tune_block + front;
+    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = P.b3 + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3;
+    return POMGPU_OK;
+  };
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  int n = 0, best = 0, rc = POMGPU_OK;
+  size_t fronts[16];
+  double ms[16];
+  for (int q = 0; q < 16 && n < max_try && !rc; q++) {
+    if (KS[q] > c->tune_kmax) continue;
+    fronts[n] = (size_t)KS[q] * unit;
+    if ((rc = rebase(fronts[n]))) break;
+    if ((rc = pomgpu_run(c, 1))) break;                       // untimed: the first step after a move (and the model's very first step, which skips its 3-D part)
+    (void)hipEventRecord(e0, c->stream);
+    if ((rc = pomgpu_run(c, steps))) break;
+    side_join(c);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    ms[n] = (double)t / steps;
+    if (ms[n] < ms[best]) best = n;
+    n++;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (n && (rc = rebase(fronts[best]))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int q = 0; q < n; q++) {
+    if (ms_out) ms_out[q] = ms[q];
+    if (front_mib_out) front_mib_out[q] = (long)(fronts[q] * sizeof(double) >> 20);
+  }
+  if (ntried) *ntried = n;
+  if (kept) *kept = best;
+  return POMGPU_OK;
+#endif
 }
 
 // ---- stand-alone kernels (device-resident), reference names ------------------------------------

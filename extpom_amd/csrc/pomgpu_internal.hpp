@@ -445,7 +445,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST)
+  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
@@ -542,6 +542,9 @@ struct pomgpu_ctx {
   hipStream_t cur, side;
   hipEvent_t ev_fork, ev_early, ev_side;
   int early_started;         // this step's early part of the wide exchange is in flight on the side stream (ev_early ends it)
+  double *tune_block;        // pomgpu_tune_placement: blk3d and the 3-D scratch arrays live in ONE allocation with room in front ...
+  size_t tune_front;         // ... and start this many doubles into it
+  int tune_kmax;             // the room in front: this many units of two arrays
   int wr_deferred;           // pomgpu_run: the last step's realvertvl + wr exchange are still to come (beside the next step's external substeps)
   int side_pending;          // work on the side stream that the main stream has not waited for yet (ev_side ends it)
   pom_blkcon con;            // host copy of blkcon (iint, iext, error_status live here)

@@ -39,6 +39,16 @@ class PomGpu:
     def _p(a):
         return ctypes.c_void_p(a.ctypes.data)
 
+    def tune_placement(self, steps: int = 3, max_try: int = 6):
+        """pomgpu_tune_placement: try a few start offsets of the 3-D arrays inside one allocation, keep the fastest (the model
+        advances by tried x (steps + 1) internal steps).  Returns {"tried": n, "front_mib": [...], "ms_per_step": [...], "kept": k}."""
+        ms = (ctypes.c_double * max_try)()
+        fr = (ctypes.c_long * max_try)()
+        n, k = ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(self.L.pomgpu_tune_placement(self.h, steps, max_try, ms, fr, ctypes.byref(n), ctypes.byref(k)), "tune_placement")
+        return {"tried": n.value, "front_mib": [int(fr[q]) for q in range(n.value)], "ms_per_step": [round(float(ms[q]), 3) for q in range(n.value)],
+                "kept": k.value}
+
     def close(self):
         if getattr(self, "h", None):
             self.L.pomgpu_destroy(self.h)

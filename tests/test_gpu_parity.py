@@ -804,3 +804,30 @@ def test_bench_cpu_workers_never_open_the_gpu():
     for r, o in enumerate(outs):
         assert f"DEVICE-FDS rank {r}: []" in o, o[-2000:]
 
+
+
+@pytest.mark.gpu
+def test_tune_placement_moves_the_arrays_and_keeps_the_bits(monkeypatch):
+    """pomgpu_tune_placement (include/pomgpu.h): blk3d and the 3-D scratch arrays move into one allocation and are tried at several
+    start offsets with real steps in between.  Where an array lives must not show in any result: after two steps, the trials (forced
+    on this small grid: POMGPU_TUNE_FORCE) and three more steps every field equals the oracle's after as many steps, bit for bit;
+    a second call re-uses the allocation."""
+    OracleTile, oracle_finish_initial = _oracle()
+    monkeypatch.setenv("POMGPU_TUNE_FORCE", "1")
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    oa, g = OracleTile(a), _gpu(b)
+    g.run(2)
+    r = g.tune_placement(2, 5)
+    assert r["tried"] == 5 and len(set(r["front_mib"])) >= 1 and 0 <= r["kept"] < 5, r
+    g.run(1)
+    r2 = g.tune_placement(1, 3)
+    assert r2["tried"] == 3, r2
+    g.run(2)
+    g.download()
+    oa.run(2 + 5 * (2 + 1) + 1 + 3 * (1 + 1) + 2)                # every trial: one untimed step after the move, then the timed ones
+    bad = diff(a, b)
+    assert not bad, bad
+    assert a.iint == b.iint
+    g.close()

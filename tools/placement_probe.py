@@ -49,7 +49,7 @@ def hold(n):
         g.close()
 
 
-def pads(values):
+def pads(values, var="POMGPU_PAD3"):
     """ONE region (a context created again in one process gets the same memory back: experiment A), another distance between the
     arrays of blk3d each time (POMGPU_PAD3, 4-KiB pages): does the layout inside the region move a kernel?"""
     from extpom_amd.model import PomGpu
@@ -58,12 +58,12 @@ def pads(values):
     g = bench.gpu_initialise(st, 0, None)
     init = st.copy()
     g.close()
-    print(f"{'PAD3':>10s} {'ms/step':>8s} " + " ".join(f"{k[2:12]:>10s}" for k in KERNELS), flush=True)
+    print(f"{var[7:]:>10s} {'ms/step':>8s} " + " ".join(f"{k[2:12]:>10s}" for k in KERNELS), flush=True)
     for v in values:
         if v:
-            os.environ["POMGPU_PAD3"] = str(v)
+            os.environ[var] = str(v)
         else:
-            os.environ.pop("POMGPU_PAD3", None)
+            os.environ.pop(var, None)
         g = PomGpu(init.copy(), device=0)
         g.run(3)
         g.sync()
@@ -83,6 +83,21 @@ def pads(values):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "hold":
         return hold(int(sys.argv[2]))
+    if len(sys.argv) > 1 and sys.argv[1] == "tune":            # the library's own tuner with many candidates: the landscape of one process
+        case, im, jm, kb, desc = bench.WORKLOADS["basin2048"]
+        st = bench.build_state("basin2048", pdist.tile_for_rank(0, 1, im, jm))
+        g = bench.gpu_initialise(st, 0, None)
+        g.run(2)
+        for rep in range(2):
+            r = g.tune_placement(3, 16)
+            print("tune:", sorted(zip(r["front_mib"], r["ms_per_step"])), "kept", r["front_mib"][r["kept"]], flush=True)
+        g.close()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "front":           # a -DPOMGPU_ALLOC_EXPERIMENT build: one block, blk3d POMGPU_FRONT MiB into it
+        os.environ["POMGPU_ALLOC"] = "4"
+        return pads([int(a) for a in sys.argv[2:]] or [0, 16, 64, 256, 1024, 1200, 2400, 4096, 4800, 9600, 0, 9600], "POMGPU_FRONT")
+    if len(sys.argv) > 1 and sys.argv[1] == "alloc":           # a -DPOMGPU_ALLOC_EXPERIMENT build: 1 scratch arrays first, 2 one block, 3 one block, scratch in front
+        return pads([int(a) for a in sys.argv[2:]] or [0, 1, 2, 3, 0, 2], "POMGPU_ALLOC")
     if len(sys.argv) > 1 and sys.argv[1] == "pads":
         return pads([int(a) for a in sys.argv[2:]] or [0, 1, 3, 16, 64, 257, 512, 1031, 4099, 0])
     sizes = [int(a) for a in sys.argv[1:]] or [0, 0, 512, 512, 3072, 3072, 9216, 9216, 0]
