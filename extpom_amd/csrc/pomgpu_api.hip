@@ -1795,7 +1795,7 @@ extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, doub
 #else
   KP &P = c->P;
   if ((c->flags & POMGPU_CTX_2D) || !P.b3 || steps < 1 || max_try < 1) return fail(c, POMGPU_EINVAL, "tune_placement: a context with 3-D arrays, steps >= 1, max_try >= 1");
-  if (c->tp.on) return POMGPU_OK;                             // tiles: every rank would have to try alike (message rounds); their arrays are small
+  // several tiles: the trial steps post message rounds -- every rank calls this alike (same steps, same max_try), each keeps its own best
   const size_t arr = P.a3 > P.n3 ? P.a3 : P.n3;
   if (arr * sizeof(double) < ((size_t)64 << 20) && !SW(c, TUNE_FORCE)) return POMGPU_OK;
   const size_t total = (size_t)POM_NBLK3D * P.a3 + (size_t)POMGPU_NSCR3 * P.n3, unit = 2 * arr;

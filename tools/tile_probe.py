@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--workload", default="basin2048")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-wide", action="store_true")
+    ap.add_argument("--tune", action="store_true", help="pomgpu_tune_placement before the measurement")
     a = ap.parse_args()
     import torch
     import bench
@@ -58,6 +59,7 @@ def main():
         tiles = [pdist.tile_for_rank(r, a.tiles, im, jm) for r in range(a.tiles)]
         wide = g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
     g.run(2)
+    tuned = g.tune_placement(3, 8) if a.tune else None
     g.sync()
     g.prof_begin()
     g.run(1)
@@ -73,7 +75,7 @@ def main():
     msg_side = prof.pop("msg_round_side", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
     print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
-                      "wide": bool(wide), "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
+                      "wide": bool(wide), "placement": tuned, "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
                       "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
                       "message_rounds_on_side_stream_per_step": g.exchange_rounds_side() / (a.steps + 3), "stand_in_mover_side_ms": round(msg_side[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
