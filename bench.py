@@ -684,7 +684,7 @@ def measure(args):
     if world == 1 and not args.no_tune_placement:
         try:
             g.run(2)                                                # (the model's first step skips its 3-D part, advance.f:362: not a step to time)
-            placement = g.tune_placement(3, 8)
+            placement = g.tune_placement(3, 10)
         except Exception as e:                                     # noqa: BLE001 -- the measurement does not depend on it
             print(f"bench: placement not tuned ({e})", file=sys.stderr)
     build_id = g.L.pomgpu_build_id().decode()

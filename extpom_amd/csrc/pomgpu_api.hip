@@ -1770,76 +1770,113 @@ extern "C" int pomgpu_run(pomgpu_ctx *c, int nsteps) {        // pom.f:17-19
 // Which offsets are good differs from box to box and from process to process -- physical addresses and the memory system's
 // interleave are not visible to a user process -- but inside one process it is reproducible to 0.1 %.  So the placement is
 // MEASURED: blk3d and the 3-D scratch arrays move into ONE allocation with room in front, and a few start offsets (multiples
-// of two arrays, so that the move never overlaps itself inside a chunk) are tried with `steps` internal steps each -- real steps
+// of two arrays), each with the arrays at their own distance or 256 MiB further apart, are tried with `steps` internal steps each -- real steps
 // of the model, timed with events on the kernels' stream; results do not depend on where an array lives -- and the fastest
 // is kept.  Costs one extra allocation of the arrays' size plus the room while it moves in, ~25 ms per move at 2048x1536x50,
 // and advances the model by ntried x (steps + 1) internal steps (one untimed step after every move).  Tiles below 64 MiB per array
 // are left alone (ntried = 0).
-static int range_move(pomgpu_ctx *c, double *dst, const double *src, size_t total, size_t chunk) {   // ranges may overlap; chunk <= |dst - src|
-  if (dst == src || !total) return POMGPU_OK;
-  const size_t nch = (total + chunk - 1) / chunk;
+// one array of n doubles from src to dst inside one allocation; the ranges may overlap (chunks no longer than the shift, in the safe order)
+static int piece_move(pomgpu_ctx *c, double *dst, const double *src, size_t n) {
+  if (dst == src || !n) return POMGPU_OK;
+  const size_t shift = dst > src ? (size_t)(dst - src) : (size_t)(src - dst), chunk = shift < n ? shift : n;
+  const size_t nch = (n + chunk - 1) / chunk;
   for (size_t q = 0; q < nch; q++) {
     const size_t m = dst > src ? nch - 1 - q : q;             // moving up: from the end
-    const size_t o = m * chunk, len = (o + chunk <= total ? chunk : total - o);
+    const size_t o = m * chunk, len = (o + chunk <= n ? chunk : n - o);
     HIPCHK(c, hipMemcpyAsync(dst + o, src + o, len * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
   return POMGPU_OK;
 }
-extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, double *ms_out, long *front_mib_out, int *ntried, int *kept) {
+// a layout of the tuner's allocation: blk3d starts `f` doubles into it, its arrays are `a` doubles apart, the scratch arrays follow
+struct TuneLay { size_t f, a; };
+static double *tune_piece(const pomgpu_ctx *c, const TuneLay &L, int i) {   // piece i: the blk3d arrays, then the 3-D scratch arrays
+  return c->tune_block + L.f + (i < POM_NBLK3D ? (size_t)i * L.a : (size_t)POM_NBLK3D * L.a + (size_t)(i - POM_NBLK3D) * c->P.n3);
+}
+static int tune_relayout(pomgpu_ctx *c, TuneLay to) {
+  const int np = POM_NBLK3D + POMGPU_NSCR3;
+  auto one_way = [&](const TuneLay &from, const TuneLay &dst_) -> int {   // every piece moves up, or every piece moves down
+    const bool up = dst_.f >= from.f && dst_.a >= from.a;
+    for (int q = 0; q < np; q++) {
+      const int i = up ? np - 1 - q : q;                      // moving up: the last piece first
+      const int rc = piece_move(c, tune_piece(c, dst_, i), tune_piece(c, from, i), c->P.n3);
+      if (rc) return rc;
+    }
+    return POMGPU_OK;
+  };
+  const TuneLay cur = {c->tune_front, c->P.a3};
+  int rc = POMGPU_OK;
+  if ((to.f >= cur.f && to.a >= cur.a) || (to.f <= cur.f && to.a <= cur.a)) rc = one_way(cur, to);
+  else {                                                      // one grows, the other shrinks: by way of the layout that is at least both
+    const TuneLay mid = {to.f > cur.f ? to.f : cur.f, to.a > cur.a ? to.a : cur.a};
+    rc = one_way(cur, mid);
+    if (!rc) rc = one_way(mid, to);
+  }
+  if (rc) return rc;
+  KP &P = c->P;
+  c->tune_front = to.f;
+  P.a3 = to.a;
+  P.b3 = c->tune_block + to.f;
+  for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = P.b3 + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3;
+  return POMGPU_OK;
+}
+extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, double *ms_out, long *front_mib_out, long *pad_mib_out, int *ntried, int *kept) {
   NEED(c);
   if (ntried) *ntried = 0;
   if (kept) *kept = 0;
 #ifdef POMGPU_EMU
-  (void)steps; (void)max_try; (void)ms_out; (void)front_mib_out;
+  (void)steps; (void)max_try; (void)ms_out; (void)front_mib_out; (void)pad_mib_out;
   return POMGPU_OK;
 #else
   KP &P = c->P;
   if ((c->flags & POMGPU_CTX_2D) || !P.b3 || steps < 1 || max_try < 1) return fail(c, POMGPU_EINVAL, "tune_placement: a context with 3-D arrays, steps >= 1, max_try >= 1");
   // several tiles: the trial steps post message rounds -- every rank calls this alike (same steps, same max_try), each keeps its own best
-  const size_t arr = P.a3 > P.n3 ? P.a3 : P.n3;
-  if (arr * sizeof(double) < ((size_t)64 << 20) && !SW(c, TUNE_FORCE)) return POMGPU_OK;
-  const size_t total = (size_t)POM_NBLK3D * P.a3 + (size_t)POMGPU_NSCR3 * P.n3, unit = 2 * arr;
-  static const int KS[16] = {0, 3, 10, 5, 2, 1, 7, 4, 15, 20, 12, 25, 30, 8, 6, 14};   // in units of two arrays, in the order they are tried
+  if (P.n3 * sizeof(double) < ((size_t)64 << 20) && !SW(c, TUNE_FORCE)) return POMGPU_OK;
+  const size_t unit = 2 * P.n3;                               // start offsets: multiples of two arrays
+  // a second distance between the arrays: 256 MiB more (2048x1536x50: 1200 -> 1456 MiB; round 4: 37.4 -> 36.6 ms per step on one box),
+  // a quarter of an array on smaller tiles; always a multiple of 64 KiB (odd distances cost k_profq 4 %)
+  size_t pad1 = P.n3 * sizeof(double) >= ((size_t)512 << 20) ? ((size_t)256 << 20) / sizeof(double) : (P.n3 / 4 + 8191) / 8192 * 8192;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
   if (!c->tune_block) {
     size_t fre = 0, tot = 0;
     HIPCHK(c, hipMemGetInfo(&fre, &tot));
-    int kmax = max_try > 8 ? 30 : 10;                         // the room in front: 10 units (24 GB at 2048x1536x50) unless more trials are asked for
-    while (kmax > 0 && (total + (size_t)kmax * unit) * sizeof(double) + ((size_t)2 << 30) > fre) kmax--;
+    const size_t a0 = P.a3;
+    size_t amax = a0 + pad1;
+    auto need = [&](int kmax, size_t am) { return ((size_t)kmax * unit + (size_t)POM_NBLK3D * am + (size_t)POMGPU_NSCR3 * P.n3) * sizeof(double) + ((size_t)2 << 30); };
+    int kmax = max_try > 12 ? 30 : 10;                        // the room in front: 10 units (24 GB at 2048x1536x50) unless many trials are asked for
+    while (kmax > 0 && need(kmax, amax) > fre) kmax--;
+    if (kmax < 1) { amax = a0; kmax = 10; while (kmax > 0 && need(kmax, amax) > fre) kmax--; }   // no room for the wider distance: start offsets only
     if (kmax < 1) return POMGPU_OK;                           // no room to move: the placement stays what it is
     double *blk = NULL;
-    if (hipMalloc((void **)&blk, (total + (size_t)kmax * unit) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return POMGPU_OK; }
-    HIPCHK(c, hipMemcpyAsync(blk, P.b3, (size_t)POM_NBLK3D * P.a3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (hipMalloc((void **)&blk, need(kmax, amax) - ((size_t)2 << 30)) != hipSuccess) { (void)hipGetLastError(); return POMGPU_OK; }
+    for (int n = 0; n < POM_NBLK3D; n++)
+      HIPCHK(c, hipMemcpyAsync(blk + (size_t)n * a0, P.b3 + (size_t)n * a0, P.n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     for (int n = 0; n < POMGPU_NSCR3; n++)
-      HIPCHK(c, hipMemcpyAsync(blk + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3, P.s3[n], P.n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(blk + (size_t)POM_NBLK3D * a0 + (size_t)n * P.n3, P.s3[n], P.n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(P.b3);
     for (int n = 0; n < POMGPU_NSCR3; n++) (void)hipFree(P.s3[n]);
     c->tune_block = blk;
     c->tune_front = 0;
     c->tune_kmax = kmax;
+    c->tune_a0 = a0;
+    c->tune_amax = amax;
     P.b3 = blk;
-    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = blk + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3;
+    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = blk + (size_t)POM_NBLK3D * a0 + (size_t)n * P.n3;
   }
-  auto rebase = [&](size_t front) -> int {
-    const int rc = range_move(c, c->tune_block + front, c->tune_block + c->tune_front, total, arr);
-    if (rc) return rc;
-    c->tune_front = front;
-    P.b3 = c->tune_block + front;
-    for (int n = 0; n < POMGPU_NSCR3; n++) P.s3[n] = P.b3 + (size_t)POM_NBLK3D * P.a3 + (size_t)n * P.n3;
-    return POMGPU_OK;
-  };
+  // (start offset in units of two arrays, wider distance?) in the order they are tried
+  static const int KS[20][2] = {{0, 0}, {3, 0}, {10, 0}, {0, 1}, {3, 1}, {10, 1}, {5, 0}, {5, 1}, {2, 0}, {1, 0}, {7, 0}, {4, 0}, {7, 1}, {2, 1}, {15, 0}, {20, 0}, {25, 0}, {30, 0}, {15, 1}, {20, 1}};
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   int n = 0, best = 0, rc = POMGPU_OK;
-  size_t fronts[16];
-  double ms[16];
-  for (int q = 0; q < 16 && n < max_try && !rc; q++) {
-    if (KS[q] > c->tune_kmax) continue;
-    fronts[n] = (size_t)KS[q] * unit;
-    if ((rc = rebase(fronts[n]))) break;
+  TuneLay lay[20];
+  double ms[20];
+  for (int q = 0; q < 20 && n < max_try && !rc; q++) {
+    if (KS[q][0] > c->tune_kmax || (KS[q][1] && c->tune_amax == c->tune_a0)) continue;
+    lay[n].f = (size_t)KS[q][0] * unit;
+    lay[n].a = KS[q][1] ? c->tune_amax : c->tune_a0;
+    if ((rc = tune_relayout(c, lay[n]))) break;
     if ((rc = pomgpu_run(c, 1))) break;                       // untimed: the first step after a move (and the model's very first step, which skips its 3-D part)
     (void)hipEventRecord(e0, c->stream);
     if ((rc = pomgpu_run(c, steps))) break;
@@ -1854,11 +1891,12 @@ extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, doub
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (rc) return rc;
-  if (n && (rc = rebase(fronts[best]))) return rc;
+  if (n && (rc = tune_relayout(c, lay[best]))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int q = 0; q < n; q++) {
     if (ms_out) ms_out[q] = ms[q];
-    if (front_mib_out) front_mib_out[q] = (long)(fronts[q] * sizeof(double) >> 20);
+    if (front_mib_out) front_mib_out[q] = (long)(lay[q].f * sizeof(double) >> 20);
+    if (pad_mib_out) pad_mib_out[q] = (long)((lay[q].a - P.n3) * sizeof(double) >> 20);
   }
   if (ntried) *ntried = n;
   if (kept) *kept = best;

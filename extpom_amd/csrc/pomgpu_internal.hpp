@@ -545,6 +545,7 @@ struct pomgpu_ctx {
   double *tune_block;        // pomgpu_tune_placement: blk3d and the 3-D scratch arrays live in ONE allocation with room in front ...
   size_t tune_front;         // ... and start this many doubles into it
   int tune_kmax;             // the room in front: this many units of two arrays
+  size_t tune_a0, tune_amax; // the distance between the arrays of blk3d as it was, and the wider one the allocation has room for
   int wr_deferred;           // pomgpu_run: the last step's realvertvl + wr exchange are still to come (beside the next step's external substeps)
   int side_pending;          // work on the side stream that the main stream has not waited for yet (ev_side ends it)
   pom_blkcon con;            // host copy of blkcon (iint, iext, error_status live here)

@@ -62,8 +62,8 @@ module pomgpu_iface
     integer(c_long) function pomgpu_exchange_rounds(ctx) bind(C, name='pomgpu_exchange_rounds')
       import; type(c_ptr), value :: ctx
     end function
-    integer(c_int) function pomgpu_tune_placement(ctx, steps, max_try, ms_out, front_mib_out, ntried, kept) bind(C, name='pomgpu_tune_placement')
-      import; type(c_ptr), value :: ctx, ms_out, front_mib_out, ntried, kept; integer(c_int), value :: steps, max_try   ! the four outputs may be c_null_ptr
+    integer(c_int) function pomgpu_tune_placement(ctx, steps, max_try, ms_out, front_mib_out, pad_mib_out, ntried, kept) bind(C, name='pomgpu_tune_placement')
+      import; type(c_ptr), value :: ctx, ms_out, front_mib_out, pad_mib_out, ntried, kept; integer(c_int), value :: steps, max_try   ! the five outputs may be c_null_ptr
     end function
     integer(c_int) function pomgpu_sync(ctx) bind(C, name='pomgpu_sync')
       import; type(c_ptr), value :: ctx

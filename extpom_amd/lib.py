@@ -104,7 +104,7 @@ _SIGS = {
                              ctypes.POINTER(ctypes.c_double)]),
     "pomgpu_version": (ctypes.c_char_p, []),
     "pomgpu_build_id": (ctypes.c_char_p, []),
-    "pomgpu_tune_placement": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pomgpu_tune_placement": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
 }
 # argument-less hot-path entry points, same names as the reference subroutines
 NOARG = ["get_time", "lateral_viscosity", "mode_interaction", "mode_external", "mode_internal", "advance", "advave",

@@ -44,10 +44,11 @@ class PomGpu:
         advances by tried x (steps + 1) internal steps).  Returns {"tried": n, "front_mib": [...], "ms_per_step": [...], "kept": k}."""
         ms = (ctypes.c_double * max_try)()
         fr = (ctypes.c_long * max_try)()
+        pd = (ctypes.c_long * max_try)()
         n, k = ctypes.c_int(0), ctypes.c_int(0)
-        self._chk(self.L.pomgpu_tune_placement(self.h, steps, max_try, ms, fr, ctypes.byref(n), ctypes.byref(k)), "tune_placement")
-        return {"tried": n.value, "front_mib": [int(fr[q]) for q in range(n.value)], "ms_per_step": [round(float(ms[q]), 3) for q in range(n.value)],
-                "kept": k.value}
+        self._chk(self.L.pomgpu_tune_placement(self.h, steps, max_try, ms, fr, pd, ctypes.byref(n), ctypes.byref(k)), "tune_placement")
+        return {"tried": n.value, "front_mib": [int(fr[q]) for q in range(n.value)], "pad_mib": [int(pd[q]) for q in range(n.value)],
+                "ms_per_step": [round(float(ms[q]), 3) for q in range(n.value)], "kept": k.value}
 
     def close(self):
         if getattr(self, "h", None):

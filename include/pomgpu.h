@@ -263,14 +263,15 @@ int pomgpu_run(pomgpu_ctx *ctx, int nsteps);
 /* Where the 3-D arrays live (no counterpart in the reference; optional).  The same kernels on the same bytes run up to 6 %
  * faster or slower with where in HBM their arrays lie; which places are good differs from process to process and cannot be seen from
  * user space, but is reproducible inside one process.  This call MEASURES it: blk3d and the 3-D scratch arrays move into one
- * allocation with room in front, up to max_try start offsets are tried with one untimed and `steps` timed internal steps each (real
- * steps: the model advances by ntried x (steps + 1); results do not depend on where an array lives) and the fastest is kept.  ms_out / front_mib_out (max_try
- * entries each, may be NULL): what each trial took per step and how far into the allocation blk3d started; *ntried = 0 when nothing was
+ * allocation with room in front, up to max_try layouts (a start offset, and the arrays at their distance or 256 MiB further apart) are tried with one untimed and `steps` timed internal steps each (real
+ * steps: the model advances by ntried x (steps + 1); results do not depend on where an array lives) and the fastest is kept.  ms_out / front_mib_out /
+ * pad_mib_out (max_try entries each, may be NULL): what each trial took per step, how far into the allocation blk3d started and how much
+ * further apart than their size its arrays were; *ntried = 0 when nothing was
  * tried (arrays below 64 MiB, no memory for the move).  On several tiles the trial steps post message rounds: every rank makes the
  * call alike (same steps, same max_try) and keeps its own best.  Needs the arrays' size plus the room again while it moves in.
  * The placement survives pomgpu_upload: a host that wants its run to start from an untouched state tunes on the initial state
  * and uploads it again (state and blkcon) before its first step. */
-int pomgpu_tune_placement(pomgpu_ctx *ctx, int steps, int max_try, double *ms_out, long *front_mib_out, int *ntried, int *kept);
+int pomgpu_tune_placement(pomgpu_ctx *ctx, int steps, int max_try, double *ms_out, long *front_mib_out, long *pad_mib_out, int *ntried, int *kept);
 
 /* ---- the hot path: kernels (solver.f, bounds_forcing.f), device-resident ---------------- */
 int pomgpu_advave(pomgpu_ctx *ctx);              /* solver.f:6-198   */

@@ -59,7 +59,7 @@ def main():
         tiles = [pdist.tile_for_rank(r, a.tiles, im, jm) for r in range(a.tiles)]
         wide = g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
     g.run(2)
-    tuned = g.tune_placement(3, 8) if a.tune else None
+    tuned = g.tune_placement(3, 10) if a.tune else None
     g.sync()
     g.prof_begin()
     g.run(1)
