@@ -12,6 +12,8 @@ if [ $PART = A ]; then
   python bench.py --workload seamount256 --steps 40 --no-cpu-baseline > $O/bench_seamount256.json 2>/dev/null
   python bench.py --workload basin1024 --steps 10 --no-cpu-baseline > $O/bench_basin1024.json 2>/dev/null
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_line_under_rocprofv3_kernel_trace.json 2> $O/stats.err
+  # the same under rocprofv3 with the layout left as it comes: the CSV then holds ONE layout, and its average is the events' average
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_one_layout -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-tune-placement > $O/bench_line_under_rocprofv3_kernel_trace_one_layout.json 2> $O/stats1.err
   for set in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$set -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$set.log 2>&1
   done
