@@ -23,7 +23,7 @@ if [ $PART = A ]; then
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
   find $O -name "*kernel_stats.csv" | head -3
 else
-  for n in 8 4 2; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  for n in 8 4 2; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) --tune > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
   POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_2ranks_one_gpu_basin1024.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
   POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin1024.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
   timeout -k 10 300 python bench.py --storage f32 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_f32_storage_study.json 2> $O/f32.err; echo "f32 rc=$?"
