@@ -7,7 +7,10 @@ process CAN do is change what is allocated before the context.  This run creates
 time behind a dummy allocation of another size that stays alive meanwhile, and times the large kernels: do the times follow the dummy's
 size (then a context could try a few placements at creation and keep the best), repeat for the same size, or ignore it?
 
-    python tools/placement_probe.py [sizes in MiB ...]
+    python tools/placement_probe.py [sizes in MiB ...]     the context created again and again behind dummy allocations of these sizes
+    python tools/placement_probe.py hold 4                 four contexts alive at once, timed in turn
+    python tools/placement_probe.py pads 0 16 65536 ...    one region, POMGPU_PAD3 = these many 4-KiB pages between the arrays of blk3d
+    python tools/placement_probe.py tune                   the library's own pomgpu_tune_placement with 16 layouts, twice
 """
 import os
 import sys
@@ -93,11 +96,6 @@ def main():
             print("tune:", sorted(zip(r["front_mib"], r["ms_per_step"])), "kept", r["front_mib"][r["kept"]], flush=True)
         g.close()
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "front":           # a -DPOMGPU_ALLOC_EXPERIMENT build: one block, blk3d POMGPU_FRONT MiB into it
-        os.environ["POMGPU_ALLOC"] = "4"
-        return pads([int(a) for a in sys.argv[2:]] or [0, 16, 64, 256, 1024, 1200, 2400, 4096, 4800, 9600, 0, 9600], "POMGPU_FRONT")
-    if len(sys.argv) > 1 and sys.argv[1] == "alloc":           # a -DPOMGPU_ALLOC_EXPERIMENT build: 1 scratch arrays first, 2 one block, 3 one block, scratch in front
-        return pads([int(a) for a in sys.argv[2:]] or [0, 1, 2, 3, 0, 2], "POMGPU_ALLOC")
     if len(sys.argv) > 1 and sys.argv[1] == "pads":
         return pads([int(a) for a in sys.argv[2:]] or [0, 1, 3, 16, 64, 257, 512, 1031, 4099, 0])
     sizes = [int(a) for a in sys.argv[1:]] or [0, 0, 512, 512, 3072, 3072, 9216, 9216, 0]
