@@ -1078,7 +1078,7 @@ __global__ void k_proft(KP P, double *f, const double *wfsurf, const double *fsu
 // expression sequence as k_proft.  When SW = 0 the term dti2*(rad(k)-rad(k+1))/(dh*dz(k)) is +0
 // exactly (dti2 > 0, dh*dz > 0), written as "+ 0.".
 template <int KBT, int SW>
-__global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+static __device__ __forceinline__ void d_proft_reg(const KP &P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double r_[5] = {.58, .62, .67, .77, .78}, ad1_[5] = {.35, .60, 1.0, 1.5, 1.4}, ad2_[5] = {23., 20., 17., 14., 7.9};
@@ -1148,6 +1148,18 @@ __global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg(KP P, double *f, 
 #undef RAD
 #undef ACOEF
 #undef CCOEF
+}
+template <int KBT, int SW>
+__global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg(KP P, double *f, const double *wfsurf, const double *fsurf, int nbc) {
+  d_proft_reg<KBT, SW>(P, f, wfsurf, fsurf, nbc);
+}
+// T and S (advance.f:439-440: two calls that share nothing but kh) as ONE grid, the tracer on blockIdx.z: on a tile of an 8-GPU split a
+// launch is three to four rounds of workgroups whose last round is mostly empty -- one launch pays for that once, not twice
+struct ProftArgs { double *f; const double *wfsurf, *fsurf; int nbc; };
+template <int KBT, int SW>
+__global__ void __launch_bounds__(64 * ROWS_PROFT) k_proft_reg2(KP P, ProftArgs a0, ProftArgs a1) {
+  if (blockIdx.z == 0) d_proft_reg<KBT, SW>(P, a0.f, a0.wfsurf, a0.fsurf, a0.nbc);
+  else d_proft_reg<KBT, SW>(P, a1.f, a1.wfsurf, a1.fsurf, a1.nbc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1351,7 +1363,7 @@ __global__ void k_advv_profv(KP P, int do_adv, int do_prof) {
 // Phase A loads the whole column into the future ee/gg registers, phase B is the forward
 // elimination (solver.f:1712-1745 / :1810-1843), phase C the bottom value and back substitution.
 template <int KBT, int V>
-__global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg(KP P) {
+static __device__ __forceinline__ void d_profuv_reg(const KP &P, const bool store_tps) {
   const int j = TID_J;
   if (j > P.jm) return;
   int i0, lane = 1;
@@ -1451,10 +1463,20 @@ __global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg(KP P) {
     const double xn = (ee[ki - 1] * x + gg[ki - 1]) * m;
     if (ki <= kbm2) { x = xn; PLANE(f, ki, col) = x; }
   }
-  F2(tps, i, j) = tps;
+  if (store_tps) F2(tps, i, j) = tps;
 #undef KC
 #undef KCB
 #undef PLANE
+}
+template <int KBT, int V>
+__global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg(KP P) { d_profuv_reg<KBT, V>(P, true); }
+// profu and profv (advance.f:461-462) as ONE grid, the component on blockIdx.z (see k_proft_reg2); the grid is profu's (62 columns per
+// wavefront), profv's workgroups beyond its 64-column count find nothing to do.  tps is the reference's shared scratch:
+// only profv, whose value the reference leaves there, stores it.
+template <int KBT>
+__global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg2(KP P) {
+  if (blockIdx.z == 0) d_profuv_reg<KBT, 0>(P, false);
+  else d_profuv_reg<KBT, 1>(P, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1489,7 +1511,7 @@ __global__ void k_uv_filter(KP P) {
 // column once for the depth mean and again to correct it (4 reads + 2 writes for both components);
 // with the level loop unrolled for a template bound >= kb the column waits in registers: 1 read + 1 write.
 template <int KBT, int V>
-__global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg(KP P) {
+static __device__ __forceinline__ void d_int_uvmean_reg(const KP &P) {
   COL2
   double *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.a3;
   const int kbm1 = P.kbm1;
@@ -1513,6 +1535,13 @@ __global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg(KP P) {
   if (V) F2(tps, i, j) = s_;
 #undef KC
 }
+template <int KBT, int V>
+__global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg(KP P) { d_int_uvmean_reg<KBT, V>(P); }
+template <int KBT>
+__global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg2(KP P) {   // u and v as ONE grid, the component on blockIdx.z (see k_proft_reg2)
+  if (blockIdx.z == 0) d_int_uvmean_reg<KBT, 0>(P);
+  else d_int_uvmean_reg<KBT, 1>(P);
+}
 
 // uv_filter with the column in registers (one component per launch: V = 0 u, V = 1 v).  The scratch-free
 // kernel above sweeps the column twice and re-reads uf, ub, u for the second sweep (16 array passes for
@@ -1521,7 +1550,7 @@ __global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg(KP P) {
 // second sweep needs no memory: 3 reads + 2 writes per component.  u and ub of the whole column are
 // requested up front into their final registers; uf streams through two small chunk buffers.
 template <int KBT, int V>
-__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P) {
+static __device__ __forceinline__ void d_uv_filter_reg(const KP &P) {
   COL2
   if (i > P.im || j > P.jm) return;
   const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.a3;
@@ -1569,6 +1598,13 @@ __global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P) {
   if (V) F2(tps, i, j) = su;
 #undef KC
 }
+template <int KBT, int V>
+__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P) { d_uv_filter_reg<KBT, V>(P); }
+template <int KBT>
+__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg2(KP P) {   // u and v as ONE grid, the component on blockIdx.z (see k_proft_reg2)
+  if (blockIdx.z == 0) d_uv_filter_reg<KBT, 0>(P);
+  else d_uv_filter_reg<KBT, 1>(P);
+}
 
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 colblk() { return dim3(64, 2, 1); }
@@ -1588,7 +1624,9 @@ void launch_order_pack(pomgpu_ctx *c, double *send_e, double *send_n) {
   const int len = P.iml > P.jml ? P.iml : P.jml;
   LAUNCH(c, k_order_pack, dim3((len + 63) / 64, P.kb + 1, 1), dim3(64, 1, 1), c->P, send_e, send_n);
 }
+static inline dim3 twin(dim3 g) { g.z = 2; return g; }       // the two variants of a twin kernel on blockIdx.z
 template <int KBT> static void launch_int_uvmean_reg_t(pomgpu_ctx *c) {
+  if (!SW(c, NO_TWIN)) { LAUNCHN(c, "k_int_uvmean_reg2", (k_int_uvmean_reg2<KBT>), twin(rowgrid(c->P, ROWS_UVM)), rowblk(ROWS_UVM), c->P); return; }
   LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 0>), rowgrid(c->P, ROWS_UVM), rowblk(ROWS_UVM), c->P);
   LAUNCHN(c, "k_int_uvmean_reg", (k_int_uvmean_reg<KBT, 1>), rowgrid(c->P, ROWS_UVM), rowblk(ROWS_UVM), c->P);
 }
@@ -1650,10 +1688,34 @@ void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *
   else if (kb <= 56) launch_proft_reg<56>(c, f, wfsurf, fsurf, nbc);
   else launch_proft_reg<64>(c, f, wfsurf, fsurf, nbc);
 }
+// proft for T and S in one launch (advance.f:439-440); 0 = not applicable (no register kernel for this kb, or the two tracers' surface
+// conditions differ in whether the short-wave term is compiled in): the caller launches them one by one
+template <int KBT>
+static void launch_proft2_reg(pomgpu_ctx *c, const ProftArgs &a0, const ProftArgs &a1, int sw) {
+  if (sw) LAUNCHN(c, "k_proft_reg2", (k_proft_reg2<KBT, 1>), twin(rowgrid(c->P, ROWS_PROFT)), rowblk(ROWS_PROFT), c->P, a0, a1);
+  else LAUNCHN(c, "k_proft_reg2", (k_proft_reg2<KBT, 0>), twin(rowgrid(c->P, ROWS_PROFT)), rowblk(ROWS_PROFT), c->P, a0, a1);
+}
+int launch_proft2(pomgpu_ctx *c, double *f0, const double *wfsurf0, const double *fsurf0, int nbc0, double *f1, const double *wfsurf1, const double *fsurf1, int nbc1) {
+  const int kb = c->P.kb, sw0 = (nbc0 == 2 || nbc0 == 4), sw1 = (nbc1 == 2 || nbc1 == 4);
+  if (SW(c, NO_TWIN) || SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6 || sw0 != sw1) return 0;
+  const ProftArgs a0 = {f0, wfsurf0, fsurf0, nbc0}, a1 = {f1, wfsurf1, fsurf1, nbc1};
+  if (kb <= 24) launch_proft2_reg<24>(c, a0, a1, sw0);
+  else if (kb <= 32) launch_proft2_reg<32>(c, a0, a1, sw0);
+  else if (kb <= 40) launch_proft2_reg<40>(c, a0, a1, sw0);
+  else if (kb <= 44) launch_proft2_reg<44>(c, a0, a1, sw0);
+  else if (kb <= 50) launch_proft2_reg<50>(c, a0, a1, sw0);
+  else if (kb <= 56) launch_proft2_reg<56>(c, a0, a1, sw0);
+  else launch_proft2_reg<64>(c, a0, a1, sw0);
+  return 1;
+}
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advu_profu, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof) { LAUNCH(c, k_advv_profv, colgrid(c->P), colblk(), c->P, do_adv, do_prof); }
 template <int KBT> static void launch_profuv_reg_t(pomgpu_ctx *c) {
   const KP &P = c->P;
+  if (!SW(c, NO_TWIN)) {
+    LAUNCHN(c, "k_profuv_reg2", (k_profuv_reg2<KBT>), dim3((P.iml + 61) / 62, (P.jml + ROWS_PROFUV - 1) / ROWS_PROFUV, 2), rowblk(ROWS_PROFUV), c->P);
+    return;
+  }
   LAUNCHN(c, "k_profu_reg", (k_profuv_reg<KBT, 0>), dim3((P.iml + 61) / 62, (P.jml + ROWS_PROFUV - 1) / ROWS_PROFUV, 1), rowblk(ROWS_PROFUV), c->P);
   LAUNCHN(c, "k_profv_reg", (k_profuv_reg<KBT, 1>), rowgrid(P, ROWS_PROFUV), rowblk(ROWS_PROFUV), c->P);
 }
@@ -1670,6 +1732,7 @@ int launch_profuv_reg(pomgpu_ctx *c) {
   return 1;
 }
 template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c) {
+  if (!SW(c, NO_TWIN)) { LAUNCHN(c, "k_uv_filter_reg2", (k_uv_filter_reg2<KBT>), twin(rowgrid(c->P, ROWS_UVF)), rowblk(ROWS_UVF), c->P); return; }
   LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
   LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
 }

@@ -1528,8 +1528,10 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
         return fail(c, POMGPU_EINVAL, "Error: invalid value for nadv");
       }
       xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);        // :436-437
-      launch_proft(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct);   // :439-440
-      launch_proft(c, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs);
+      if (!launch_proft2(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs)) {   // :439-440, T and S in one launch
+        launch_proft(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct);
+        launch_proft(c, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs);
+      }
       launch_bcond4_edges(c);                                 // :442
       double fold, fnew;
       int rc = restore_prepare(c, &fold, &fnew);              // :452 (record handling)

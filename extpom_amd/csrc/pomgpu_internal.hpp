@@ -445,7 +445,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE)
+  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
@@ -738,6 +738,7 @@ void launch_profq_bc(pomgpu_ctx *c);
 void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt = 0);
 void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt = 0);
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
+int launch_proft2(pomgpu_ctx *c, double *f0, const double *wfsurf0, const double *fsurf0, int nbc0, double *f1, const double *wfsurf1, const double *fsurf1, int nbc1);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_uv_filter(pomgpu_ctx *c);

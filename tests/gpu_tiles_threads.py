@@ -2,14 +2,15 @@
 
 The reference guarantees that a run does not depend on how the domain is cut into tiles (its only
 regression check).  Here the bench grid (default 2048x1536x50, the grid north_star's targets are stated on) runs once as ONE
-tile and once as 1 x N whole-row tiles -- bench.py's default split -- all on GPU 0: every tile a context of its own on a
-stream of its own, driven by a host thread, the library's exchange (pomgpu_set_transport) with a mover that copies the
-staging buffers device to device between the contexts, the wide-halo external mode with its two rounds on the second
-stream.  After STEPS internal steps every cell a tile OWNS must hold the bits of the single-tile run, in every COMMON array
+tile and once as A x B tiles -- 1 x N whole rows (bench.py's default split) or the reference's own kind of 2-D split, e.g. the 2 x 4
+of BASELINE configs[2] / [3] with its trimmed north row of tiles and all eight neighbours (parallel_mpi.f:54-65,82-119,96-103) --
+all on GPU 0: every tile a context of its own on a stream of its own, driven by a host thread, the library's exchange
+(pomgpu_set_transport) with a mover that copies the staging buffers device to device between the contexts (corner messages
+included), the wide-halo external mode with its rounds on the second stream.  After STEPS internal steps every cell a tile OWNS must hold the bits of the single-tile run, in every COMMON array
 that is not pure scratch.  The single-tile path itself is pinned to the oracle at this size for steps 1-3
 (test_config4_2048x1536x50_full_size); this carries that pin over STEPS steps and over the multi-tile code path.
 
-    python tests/gpu_tiles_threads.py [IMxJMxKB] [N] [STEPS] [f32]
+    python tests/gpu_tiles_threads.py [IMxJMxKB] [N | AxB[,CxD...]] [STEPS] [f32]
 """
 import ctypes
 import os
@@ -69,7 +70,7 @@ def gpu_finish(st, g):
 
 def main():
     grid = sys.argv[1] if len(sys.argv) > 1 else "2048x1536x50"
-    world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    splits = [tuple(int(v) for v in sp.split("x")) if "x" in sp else (1, int(sp)) for sp in (sys.argv[2] if len(sys.argv) > 2 else "4").split(",")]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     libpath = _lib.LIBPATH_F32 if "f32" in sys.argv[4:] else None
     im, jm, kb = (int(v) for v in grid.split("x"))
@@ -84,9 +85,17 @@ def main():
     ga.close()
     assert a.error_status == 0
     beat(f"single tile: {steps} steps done")
-    # ---- 1 x world whole-row tiles, one host thread each -------------------------------------------------------------
-    iml, jml = decomp.local_size(im, jm, 1, world)
+    for nx, ny in splits:                             # every split against the same single-tile run
+        run_split(a, grid, im, jm, kb, nml, nx, ny, steps, libpath, dev)
+
+
+def run_split(a, grid, im, jm, kb, nml, nx, ny, steps, libpath, dev):
+    world = nx * ny
+    # ---- nx x ny tiles, one host thread each -------------------------------------------------------------------------
+    iml, jml = decomp.local_size(im, jm, nx, ny)
+    assert decomp.tile_grid(im, jm, iml, jml) == (nx, ny), (decomp.tile_grid(im, jm, iml, jml), nx, ny)
     tiles = [decomp.make_tile(r, im, jm, iml, jml, n_proc=world) for r in range(world)]
+    print("tiles (im x jm, neighbours W E S N SW SE NW NE):", [(t.im, t.jm, PomGpu.neighbours8(t)) for t in tiles])
     board, errs, bad, info, worst = Board(world), [], [], {}, {}
 
     def rank(r):
@@ -142,7 +151,7 @@ def main():
                     worst[n] = max(worst.get(n, 0.0), rel)
                     if n in F32_BOUND and rel > F32_BOUND[n]:
                         bad.append((r, n, rel))
-            beat(f"tile {r} compared")
+            beat(f"{nx}x{ny}: tile {r} compared")
         except Exception as e:                        # noqa: BLE001 -- a dead rank must not leave the others at the barrier
             import traceback
             errs.append(traceback.format_exc())
@@ -164,7 +173,7 @@ def main():
     if bad:
         print("MISMATCH", bad[:20])
         sys.exit(1)
-    print(f"TILES-THREADS-OK {grid} 1x{world} {steps} steps")
+    print(f"TILES-THREADS-OK {grid} {nx}x{ny} {steps} steps")
 
 
 if __name__ == "__main__":

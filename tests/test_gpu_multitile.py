@@ -64,15 +64,30 @@ def test_whole_row_tiles_the_default_split(args):
 
 
 @pytest.mark.gpu
-def test_full_size_decomposition_invariance_whole_row_tiles():
+def test_full_size_decomposition_invariance_whole_rows_and_baselines_2x4():
     """The property the reference itself guarantees, at the size north_star is stated on: 2048x1536x50 as ONE
-    tile and as 1 x 4 whole-row tiles (bench.py's default split; library exchange, wide-halo external mode, two rounds per step
-    on the second stream), GPU against GPU on one device, 50 internal steps: every owned cell of every COMMON array that is not
-    scratch carries the same bits.  With steps 1-3 of the single-tile run pinned to the oracle at this size
-    (test_config4_2048x1536x50_full_size) this is what carries the pin beyond a few steps, and over the multi-tile path."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_threads.py"), "2048x1536x50", "4", "50"], capture_output=True,
+    tile, as 1 x 4 whole-row tiles (bench.py's default split) and as the 2 x 4 tiles BASELINE configs[3] runs on 8 GPUs (1025 x 386,
+    the north row of tiles trimmed to 384 rows, every tile with three or five live neighbours incl. the diagonal ones:
+    parallel_mpi.f:54-65,82-119,96-103) -- library exchange with corner messages, wide-halo external mode, rounds on the second stream --
+    GPU against GPU on one device, 50 internal steps: every owned cell of every COMMON array that is not scratch carries the same
+    bits.  With steps 1-3 of the single-tile run pinned to the oracle at this size (test_config4_2048x1536x50_full_size) this is
+    what carries the pin beyond a few steps, and over the multi-tile path."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_threads.py"), "2048x1536x50", "1x4,2x4", "50"], capture_output=True,
                        text=True, timeout=1500)
-    assert r.returncode == 0 and "TILES-THREADS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "TILES-THREADS-OK 2048x1536x50 1x4 50" in r.stdout and "TILES-THREADS-OK 2048x1536x50 2x4 50" in r.stdout, \
+        r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_config2_grid_as_baselines_2x4_tiles():
+    """BASELINE configs[2] as it is worded: the closed basin 1024x1024x40 on a 2 x 4 tile decomposition (tiles 513 x 258, the north
+    row of tiles trimmed to jm = 256 of 258), eight contexts on one GPU, 20 internal steps against the single tile: every owned
+    cell of every COMMON array that is not scratch carries the same bits.  The single tile of this grid is pinned to the oracle
+    for steps 1-3 (test_restart_and_determinism_properties_1024x1024x40)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_tiles_threads.py"), "1024x1024x40", "2x4", "20"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "TILES-THREADS-OK 1024x1024x40 2x4 20" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "(513, 256," in r.stdout and "(513, 258," in r.stdout, r.stdout[-3000:]      # the trimmed north row of tiles did run
 
 
 @pytest.mark.gpu

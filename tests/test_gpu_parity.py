@@ -37,6 +37,27 @@ def diff(a, b):
     return [n for n in BLK2D + BLK3D if n not in SCRATCH and not same_bits(a.field(n), b.field(n))]
 
 
+def _against_background_oracle(st, bg, steps, beat=lambda msg: None):
+    """steps 1..steps of the HIP path from `st` against the oracle's, which a child process has been computing since the session
+    began (tests/oracle_bg.py, tests/conftest.py): per COMMON array that is not scratch one xxh3-128 digest of its 64-bit patterns
+    on either side -- equal digests, equal bits.  Step 0 shows that both sides start from identical inputs."""
+    from oracle_bg import digests
+    want = bg.step(0)
+    assert want["digests"] == digests(st), "the background oracle and this test did not start from the same state"
+    g = _gpu(st)
+    for step in range(1, steps + 1):
+        g.run(1)
+        g.download()
+        beat(f"device step {step} downloaded")
+        got = digests(st)
+        want = bg.step(step)
+        beat(f"oracle step {step} there (it took the child {want['seconds']} s from its start)")
+        bad = [n for n in got if got[n] != want["digests"][n]]
+        assert not bad, f"step {step} differs from the oracle: {bad}"
+        assert want["iint"] == step and st.iint == step
+    g.close()
+
+
 def reldiff(a, b, fields):
     return {f: float(np.abs(a.field(f) - b.field(f)).max() / max(np.abs(a.field(f)).max(), 1e-300)) for f in fields}
 
@@ -382,7 +403,8 @@ def test_kb_above_the_register_kernels_bound():
     assert not diff(a, b), diff(a, b)
 
 
-def test_restart_and_determinism_properties_1024x1024x40():
+@pytest.mark.bg_oracle("basin", 1024, 1024, 40, 3)
+def test_restart_and_determinism_properties_1024x1024x40(bg_oracle):
     """config 3's grid on one GPU, size-independent properties: (i) two runs give identical bits,
     (ii) run(2n) == run(n) + download/upload + run(n) (the restart property), (iii) land stays
     masked, nothing non-finite, (iv) closed basin conserves volume: the area integral of et does
@@ -392,7 +414,7 @@ def test_restart_and_determinism_properties_1024x1024x40():
     OracleTile, oracle_finish_initial = _oracle()
     a = make_case("basin", 1024, 1024, 40, dte=6.0, isplit=30)
     oracle_finish_initial(a)
-    b, c = a.copy(), a.copy()
+    b = a.copy()
     vol0 = float((a.et * a.art * a.fsm).sum())
     ga = _gpu(a)
     ga.run(6)
@@ -416,15 +438,7 @@ def test_restart_and_determinism_properties_1024x1024x40():
     assert abs(float((a.et * a.art * a.fsm).sum()) - vol0) / area < 1e-12
     e = make_case("basin", 1024, 1024, 40, dte=6.0, isplit=30)
     oracle_finish_initial(e)
-    ge = _gpu(e)
-    oc = OracleTile(c)
-    for step in (1, 2, 3):
-        oc.run(1)
-        ge.run(1)
-        ge.download()
-        assert not diff(c, e), f"step {step} differs from the oracle: {diff(c, e)}"
-    assert c.iint == 3 and e.iint == 3                # steps 2, 3: the 3-D body of mode_internal has run on both sides; 3 = every branch warm
-    ge.close()
+    _against_background_oracle(e, bg_oracle, 3)
 
 
 # ---- the instantiations bench.py runs: kb = 50 and 2048-wide rows ---------------------------------------------------
@@ -535,14 +549,17 @@ def test_100_internal_steps_256x192x50_within_1e_10():
     assert a.error_status == b.error_status == 0
 
 
-def test_config4_2048x1536x50_full_size():
+@pytest.mark.bg_oracle("basin", 2048, 1536, 50, 3)
+def test_config4_2048x1536x50_full_size(bg_oracle):
     """BASELINE configs[3]'s grid -- the one bench.py reports -- at full size on one GPU, default (fast) kernel shapes:
     (i) steps 1, 2 AND 3, every field equal to the oracle bit for bit (step 3: the first with every branch warm).  Step 1 (iint = 1, time0 = 0) skips mode_internal's 3-D body
     (advance.f:362); step 2 is the first in which k_profq<1,1,8>, k_advt2_col<2>, k_advq_col<2>, k_advct_col, k_advuv_col in
     strip order, k_ts_update and the <50> register kernels run AT THE BENCHMARKED LAUNCH GEOMETRY -- it is compared with the
-    oracle directly (about three minutes of one CPU core for the oracle steps); (ii) two contexts fed the same state produce the same bits over 20 more steps, one on
-    the large-grid kernel shapes and one on the general ones; (iii) land stays masked, nothing non-finite.
-    ~50 GB per host copy of the state."""
+    oracle directly.  The oracle's three steps (about three minutes of one CPU core) are computed by a child process from the
+    start of the session, beside the other tests (tests/oracle_bg.py); (ii) land stays masked, nothing non-finite.
+    (Fast against general kernel shapes over the whole horizon at this size: tools/fullsize_1000.py,
+    profiles/round4_fullsize_1000_steps_fast_against_general_kernels.txt; the multi-tile path over 50 steps:
+    test_full_size_decomposition_invariance_whole_rows_and_baselines_2x4.)  ~50 GB per host copy of the state."""
     import os
     import time
     OracleTile, oracle_finish_initial = _oracle()
@@ -556,42 +573,13 @@ def test_config4_2048x1536x50_full_size():
     a = make_case("basin", 2048, 1536, 50, dte=6.0, isplit=30)
     oracle_finish_initial(a)
     beat("case built")
-    c = a.copy()
-    ga = _gpu(a)
-    oc = OracleTile(c)
-    for step in (1, 2, 3):                           # step 3: the first with every branch warm (leapfrog levels, filters, restore records)
-        ga.run(1)
-        ga.download()
-        beat(f"device step {step} downloaded")
-        oc.run(1)
-        beat(f"oracle step {step} done")
-        bad = diff(a, c)
-        assert not bad, f"step {step} differs from the oracle: {bad}"
-        beat(f"step {step} compared")
-    assert a.iint == 3 and c.iint == 3               # the 3-D body ran on both sides (advance.f:362), twice
-    del oc
-    gc = _gpu(c)                                     # the oracle's state after three steps, uploaded
-    # 20 more steps: one context on the large-grid fast paths (two external substeps per pass marching down the rows, k_profq in 8
-    # paced rows with its vectors in LDS, strip order), the other on the shapes small grids use (one substep per launch, one row
-    # per wavefront ...) -- the same bits
-    ga.run(20)
-    general = {"POMGPU_EXT_NOPAIR": "1", "POMGPU_EXT_NOMARCH": "1", "POMGPU_PROFQ_ROWS2": "1", "POMGPU_PROFQ_NOPACE": "1", "POMGPU_COL_STRIP": "0"}
-    for k, v in general.items():                     # switches are read when a context is created: these change the live one
-        gc.switch(k, v)
-    gc.run(20)
-    ga.download()
-    gc.download()
-    ga.close()
-    gc.close()
-    bad = diff(a, c)
-    assert not bad, f"two contexts, same state, fast against general kernels, different bits after 20 steps: {bad}"
-    beat("steps 4-23 compared")
+    _against_background_oracle(a, bg_oracle, 3, beat)    # step 3: the first with every branch warm (leapfrog levels, filters, restore records)
     for f in PROGNOSTIC + ["q2", "km", "rho", "w"]:
         assert np.isfinite(a.field(f)).all(), f
     for f in ("t", "s", "el", "et"):
         x = a.field(f)
         assert not np.any((x if x.ndim == 2 else x[:49]) * (1.0 - a.fsm)), f
-    assert a.error_status == c.error_status == 0
+    assert a.error_status == 0
     beat("done")
 
 

@@ -213,3 +213,23 @@ def test_short_wave_term_in_double_double_equals_the_quad_evaluation(tmp_path):
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "check_dd_exp.cpp"), "-lquadmath"])
     r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and " 0 results differ" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.bg_oracle("seamount", 33, 29, 9, 2)
+def test_background_oracle_leaves_the_digests_of_an_in_process_run(bg_oracle):
+    """tests/oracle_bg.py + tests/conftest.py: the child process that computes the full-size oracle steps beside the GPU tests
+    (test_config4_2048x1536x50_full_size joins it) -- on a small grid its per-array digests after every step are those of the
+    same oracle run made here, and a changed bit (the sign of a zero) changes a digest"""
+    from oracle_bg import NML, digests
+    from extpom_amd.cases import make_case
+    from oracle.pyoracle import OracleTile, oracle_finish_initial
+    a = make_case("seamount", 33, 29, 9, **NML)
+    oracle_finish_initial(a)
+    assert bg_oracle.step(0)["digests"] == digests(a)
+    oc = OracleTile(a)
+    for n in (1, 2):
+        oc.run(1)
+        want = bg_oracle.step(n, timeout=120)
+        assert want["iint"] == n and want["digests"] == digests(a)
+    a.field("el")[0, 0] = -0.0 if a.field("el")[0, 0] == 0 else -a.field("el")[0, 0]
+    assert digests(a)["el"] != want["digests"]["el"]

@@ -288,6 +288,35 @@ def test_wide_halo_external_mode(nx, ny, case, nml):
             assert np.array_equal(wide[r][1].field(n)[:t.jm, :t.im], narrow[r][1].field(n)[:t.jm, :t.im]), (r, n)
 
 
+@pytest.mark.parametrize("nx,ny,grid,case,nml", [(2, 4, (43, 75), "island", {}), (2, 4, (43, 75), "seamount", dict(npg=2)), (3, 3, (59, 53), "seamount", {}),
+                                                 (3, 3, (59, 53), "island", dict(nadv=1))])
+def test_baselines_own_2x4_split_and_a_tile_with_eight_neighbours(nx, ny, grid, case, nml):
+    """BASELINE configs[2] / [3] name a 2 x 4 tile decomposition: (43, 75) splits into tiles of 23 x 21 whose north row is TRIMMED
+    (jm = 18 of jm_local = 21, parallel_mpi.f:96-103) and every tile has a diagonal neighbour; 3 x 3 has a centre tile with all EIGHT
+    neighbours live (parallel_mpi.f:111-119 reaches the diagonal ones through its two phases, the library sends them their corner
+    cells, and the extended tile of the wide-halo mode takes a (w+1) x (w+1) corner block from each).  The library exchange and
+    the wide-halo mode with its second-stream rounds against the single-tile oracle, owned cells bit for bit; and the two paths
+    against each other on every cell, ghost cells included."""
+    lib = run_tiles(nx, ny, nml, library_exchange=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
+    compare_with_single_tile(lib, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=50)
+    side = {}
+    wide = run_tiles(nx, ny, nml, library_exchange=True, wide=True, grid=grid, isplit=WIDE_ISPLIT, case=case, side_rounds=side)
+    compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=10)
+    assert set(side.values()) == {2 * STEPS}, side
+    tiles = [wide[r][0] for r in sorted(wide)]
+    if ny == 4:
+        assert {t.jm for t in tiles if t.py == 3} == {tiles[0].jm_local - 3} and all(t.jm == t.jm_local for t in tiles if t.py < 3)
+    else:
+        assert min(PomGpu.neighbours8(tiles[4])) >= 0                  # the centre tile: eight live neighbours
+    bad = []
+    for r in lib:
+        t = lib[r][0]
+        for n in BLK2D + BLK3D:
+            if n not in SCRATCH and not np.array_equal(lib[r][1].field(n)[..., :t.jm, :t.im], wide[r][1].field(n)[..., :t.jm, :t.im]):
+                bad.append((r, n))
+    assert not bad, bad[:10]
+
+
 def test_side_stream_rounds_are_a_collective_decision():
     """Rounds on the library's second stream (the early part of the wide exchange, wr) run on all ranks or on none: one rank of
     2x2 that reports it cannot serve them (a failed ncclCommSplit / hipStreamCreate in production) keeps EVERY rank on the
