@@ -305,9 +305,15 @@ __global__ void k_advave_m2b(KP P) {
 // mode_interaction, vertical integrals -- advance.f:152-168.  One thread per column, k in a
 // register loop; reads 5 3-D arrays once (coalesced planes), writes 5 2-D arrays.
 // only_aam: adx2d, ady2d, drx2d, dry2d were left by k_advct_col / k_baropg (sum2d) in this step
-__global__ void k_vint(KP P, int only_aam) {
+// ghost (with only_aam; pomgpu_api.hip "rim rounds"): +1 = every cell but the lines a neighbour tile owns -- their aam arrives with a message round that
+// runs beside this kernel --, -1 = those lines alone, on the side stream behind that round
+__global__ void k_vint(KP P, int only_aam, int ghost) {
   const int i = TID_I, j = TID_J;
   if (i > P.iml || j > P.jml) return;
+  if (ghost) {
+    const bool gl = (i == 1 && !P.W) || (i == P.im && !P.E) || (j == 1 && !P.S) || (j == P.jm && !P.N);
+    if ((ghost > 0) == gl) return;
+  }
   double ax = 0., ay = 0., rx = 0., ry = 0., am = 0.;
   if (only_aam) {
     if (i <= P.im && j <= P.jm)
@@ -1469,7 +1475,7 @@ void launch_advave_fused(pomgpu_ctx *c) {
 }
 void launch_advave_m2a(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2a, grid2(c->P), blk2(), c->P); }
 void launch_advave_m2b(pomgpu_ctx *c) { LAUNCH(c, k_advave_m2b, grid2(c->P), blk2(), c->P); }
-void launch_vint(pomgpu_ctx *c, int only_aam) { LAUNCH(c, k_vint, grid2(c->P), blk2(), c->P, only_aam); }
+void launch_vint(pomgpu_ctx *c, int only_aam, int ghost) { LAUNCH(c, k_vint, grid2(c->P), blk2(), c->P, only_aam, ghost); }
 void launch_modeint_tail(pomgpu_ctx *c) { LAUNCH(c, k_modeint_tail, grid2(c->P), blk2(), c->P); }
 void launch_ext_elf(pomgpu_ctx *c) { LAUNCH(c, k_ext_elf, grid2(c->P), blk2(), c->P); }
 void launch_ext_uvaf(pomgpu_ctx *c, int interior) { LAUNCH(c, k_ext_uvaf, grid2(c->P), blk2(), c->P, interior); }

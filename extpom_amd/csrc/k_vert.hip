@@ -1481,8 +1481,13 @@ __global__ void __launch_bounds__(64 * ROWS_PROFUV) k_profuv_reg2(KP P) {
 
 // ---------------------------------------------------------------------------------------------
 // column-mean-free Asselin filter of u,v and time rotation -- advance.f:469-514
-__global__ void k_uv_filter(KP P) {
+// own: leave the ghost lines alone (lines a neighbour tile owns).  There the reference's filter ends in u = uf, v = vf and in ub, vb that the
+// exchange of advance.f:516-521 replaces anyway: with the rounds of :466-467 and :516-521 on the side stream (pomgpu_api.hip, "rim rounds")
+// the ghost lines of u, v are filled from the message that brings uf, vf, and this kernel need not wait for it.
+#define UVF_GHOST(P, i, j) (((i) == 1 && !(P).W) || ((i) == (P).im && !(P).E) || ((j) == 1 && !(P).S) || ((j) == (P).jm && !(P).N))
+__global__ void k_uv_filter(KP P, int own) {
   COL2
+  if (own && UVF_GHOST(P, i, j)) return;
   const bool act = (i <= P.im && j <= P.jm);
   double su = 0., sv = 0.;
   if (act) {
@@ -1550,9 +1555,10 @@ __global__ void __launch_bounds__(64 * ROWS_UVM) k_int_uvmean_reg2(KP P) {   // 
 // second sweep needs no memory: 3 reads + 2 writes per component.  u and ub of the whole column are
 // requested up front into their final registers; uf streams through two small chunk buffers.
 template <int KBT, int V>
-static __device__ __forceinline__ void d_uv_filter_reg(const KP &P) {
+static __device__ __forceinline__ void d_uv_filter_reg(const KP &P, const int own) {
   COL2
   if (i > P.im || j > P.jm) return;
+  if (own && UVF_GHOST(P, i, j)) return;
   const double *f = P.b3 + (size_t)(V ? P3_vf : P3_uf) * P.a3;
   double *b = P.b3 + (size_t)(V ? P3_vb : P3_ub) * P.a3, *c = P.b3 + (size_t)(V ? P3_v : P3_u) * P.a3;
   const int kb = P.kb, kbm1 = P.kbm1;
@@ -1599,11 +1605,11 @@ static __device__ __forceinline__ void d_uv_filter_reg(const KP &P) {
 #undef KC
 }
 template <int KBT, int V>
-__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P) { d_uv_filter_reg<KBT, V>(P); }
+__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg(KP P, int own) { d_uv_filter_reg<KBT, V>(P, own); }
 template <int KBT>
-__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg2(KP P) {   // u and v as ONE grid, the component on blockIdx.z (see k_proft_reg2)
-  if (blockIdx.z == 0) d_uv_filter_reg<KBT, 0>(P);
-  else d_uv_filter_reg<KBT, 1>(P);
+__global__ void __launch_bounds__(64 * ROWS_UVF) k_uv_filter_reg2(KP P, int own) {   // u and v as ONE grid, the component on blockIdx.z (see k_proft_reg2)
+  if (blockIdx.z == 0) d_uv_filter_reg<KBT, 0>(P, own);
+  else d_uv_filter_reg<KBT, 1>(P, own);
 }
 
 // ---- launchers --------------------------------------------------------------------------------
@@ -1731,22 +1737,24 @@ int launch_profuv_reg(pomgpu_ctx *c) {
   else launch_profuv_reg_t<64>(c);
   return 1;
 }
-template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c) {
-  if (!SW(c, NO_TWIN)) { LAUNCHN(c, "k_uv_filter_reg2", (k_uv_filter_reg2<KBT>), twin(rowgrid(c->P, ROWS_UVF)), rowblk(ROWS_UVF), c->P); return; }
-  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
-  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P);
+template <int KBT> static void launch_uv_filter_reg_t(pomgpu_ctx *c, int own) {
+  if (!SW(c, NO_TWIN)) { LAUNCHN(c, "k_uv_filter_reg2", (k_uv_filter_reg2<KBT>), twin(rowgrid(c->P, ROWS_UVF)), rowblk(ROWS_UVF), c->P, own); return; }
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 0>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P, own);
+  LAUNCHN(c, "k_uv_filter_reg", (k_uv_filter_reg<KBT, 1>), rowgrid(c->P, ROWS_UVF), rowblk(ROWS_UVF), c->P, own);
 }
-static int launch_uv_filter_reg(pomgpu_ctx *c) {
+static int launch_uv_filter_reg(pomgpu_ctx *c, int own) {
   const int kb = c->P.kb;
   if (SW(c, THOMAS_SCRATCH) || kb > 64 || kb < 6) return 0;
-  if (kb <= 24) launch_uv_filter_reg_t<24>(c);
-  else if (kb <= 32) launch_uv_filter_reg_t<32>(c);
-  else if (kb <= 40) launch_uv_filter_reg_t<40>(c);
-  else if (kb <= 44) launch_uv_filter_reg_t<44>(c);
-  else if (kb <= 50) launch_uv_filter_reg_t<50>(c);
-  else if (kb <= 56) launch_uv_filter_reg_t<56>(c);
-  else launch_uv_filter_reg_t<64>(c);
+  if (kb <= 24) launch_uv_filter_reg_t<24>(c, own);
+  else if (kb <= 32) launch_uv_filter_reg_t<32>(c, own);
+  else if (kb <= 40) launch_uv_filter_reg_t<40>(c, own);
+  else if (kb <= 44) launch_uv_filter_reg_t<44>(c, own);
+  else if (kb <= 50) launch_uv_filter_reg_t<50>(c, own);
+  else if (kb <= 56) launch_uv_filter_reg_t<56>(c, own);
+  else launch_uv_filter_reg_t<64>(c, own);
   return 1;
 }
-void launch_uv_filter(pomgpu_ctx *c) {
-  if (launch_uv_filter_reg(c)) return; LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P); }
+void launch_uv_filter(pomgpu_ctx *c, int own) {
+  if (launch_uv_filter_reg(c, own)) return;
+  LAUNCH(c, k_uv_filter, colgrid(c->P), colblk(), c->P, own);
+}

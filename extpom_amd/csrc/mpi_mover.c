@@ -25,7 +25,7 @@ typedef struct mpi_mover {
   int nbr[8];
   double *hs[8], *hr[8];      /* pinned host staging, grown on demand */
   size_t cs[8], cr[8];
-  void *stream;               /* the library's stream (hipStream_t) */
+  pomgpu_ctx *ctx;            /* the context this mover serves: its key in the table below */
   long rounds;
 } mpi_mover;
 
@@ -43,8 +43,9 @@ static void mover_fn(void *user, const double *const *send, const size_t *scount
   MPI_Request req[16];
   MPI_Status sta[16];
   int nreq = 0, bad = 0;
-  /* ordered after everything the library has enqueued (rounds of its second stream arrive here already completed) */
-  if (hipStreamSynchronize((hipStream_t)m->stream) != hipSuccess) bad = 1;
+  /* ordered after everything the library has enqueued on the stream of THIS round (pomgpu_current_stream: the kernels' stream, or the
+   * library's second stream, whose rounds arrive here already completed -- the kernels' stream keeps running beside them) */
+  if (hipStreamSynchronize((hipStream_t)pomgpu_current_stream(m->ctx)) != hipSuccess) bad = 1;
   for (int d = 0; d < 8 && !bad; d++) {
     if (m->nbr[d] < 0) continue;
     if (rcount[d]) {
@@ -84,7 +85,7 @@ int pomgpu_mpi_mover_install(pomgpu_ctx *ctx, int fcomm, const int *neighbours8)
   if (!m) return POMGPU_ENOMEM;
   m->comm = MPI_Comm_f2c((MPI_Fint)fcomm);
   for (int d = 0; d < 8; d++) m->nbr[d] = neighbours8[d];
-  m->stream = pomgpu_stream(ctx);
+  m->ctx = ctx;
   int rc = pomgpu_set_transport(ctx, neighbours8, mover_fn, m);
   /* every rank reaches the reduction, whatever happened to it above */
   int mine = rc == POMGPU_OK ? pomgpu_transport_side_capable(ctx) : 0, all = 0, worst = 0, myrc = rc;
@@ -95,17 +96,24 @@ int pomgpu_mpi_mover_install(pomgpu_ctx *ctx, int fcomm, const int *neighbours8)
     mover_free(m);
     return rc != POMGPU_OK ? rc : POMGPU_EINVAL;
   }
-  for (int k = 0; k < 64; k++) if (!g_installed[k]) { g_installed[k] = m; break; }
+  int slot = -1;
+  for (int k = 0; k < 64 && slot < 0; k++) if (!g_installed[k]) slot = k;
+  if (slot < 0) {                                             /* nowhere to remember it: no mover rather than one nobody can free */
+    (void)pomgpu_set_transport(ctx, NULL, NULL, NULL);
+    mover_free(m);
+    fprintf(stderr, "pomgpu_mpi_mover_install: 64 movers are installed already in this process\n");
+    return POMGPU_ENOMEM;
+  }
+  g_installed[slot] = m;
   return pomgpu_transport_side_agree(ctx, all);
 }
 /* takes the mover off the context (back to a single tile's behaviour) and frees its pinned staging buffers; call it before
  * pomgpu_destroy, after the last step.  Not collective. */
 int pomgpu_mpi_mover_remove(pomgpu_ctx *ctx) {
   if (!ctx) return POMGPU_EINVAL;
-  void *stream = pomgpu_stream(ctx);
   const int rc = pomgpu_set_transport(ctx, NULL, NULL, NULL);  /* synchronises what the mover may still be part of */
-  for (int k = 0; k < 64; k++)
-    if (g_installed[k] && g_installed[k]->stream == stream) { mover_free(g_installed[k]); g_installed[k] = NULL; }
+  for (int k = 0; k < 64; k++)                                 /* the mover of THIS context (two contexts may share a caller-supplied stream) */
+    if (g_installed[k] && g_installed[k]->ctx == ctx) { mover_free(g_installed[k]); g_installed[k] = NULL; }
   return rc;
 }
 /* Fortran-callable without an interface block (by-reference arguments, trailing underscore) is not offered: the host

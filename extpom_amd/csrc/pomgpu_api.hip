@@ -231,6 +231,9 @@ static void rho_materialize(pomgpu_ctx *c) {
   launch_roundtrip(c, SLOT3(c, P3_rho), SLOT3(c, P3_rmean), 2);
 }
 static void side_join(pomgpu_ctx *c);
+static void side_begin(pomgpu_ctx *c);
+static void side_end(pomgpu_ctx *c, hipEvent_t ev);
+static int rim_side(pomgpu_ctx *c);
 static void early_invalidate(pomgpu_ctx *c);
 static void restore_materialize(pomgpu_ctx *c) {
   side_join(c);                                               // whoever asks for materialised state also waits for the side stream
@@ -392,6 +395,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   }
   if (c->side) {
     (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_early); (void)hipEventDestroy(c->ev_side);
+    (void)hipEventDestroy(c->ev_r1); (void)hipEventDestroy(c->ev_r2); (void)hipEventDestroy(c->ev_r8);
     (void)hipStreamDestroy(c->side);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -414,6 +418,7 @@ extern "C" int pomgpu_debug_switch(pomgpu_ctx *c, const char *name, const char *
 }
 extern "C" const char *pomgpu_last_error(const pomgpu_ctx *c) { return c ? c->err : "null context"; }
 extern "C" void *pomgpu_stream(pomgpu_ctx *c) { return c ? (void *)c->stream : NULL; }
+extern "C" void *pomgpu_current_stream(pomgpu_ctx *c) { return c ? (void *)c->cur : NULL; }
 
 static int pull_err(pomgpu_ctx *c) {
   if (c->launch_err) return POMGPU_EHIP;                      // message already in last_error
@@ -683,12 +688,20 @@ static void seq_advct(pomgpu_ctx *c, int sum2d = 0, int defer_xch = 0) {   // so
   if (c->tp.on && !SW(c, ADVCT_SPLIT)) {            // tiles, the library's own exchange: see k_advct_edge
     pomgpu_transport &T = c->tp;
     const size_t ne = 2 * (size_t)P.kbm1 * P.jm, nn = 2 * (size_t)P.kbm1 * P.im;
-    launch_advct_edge(c, T.nbr[1] >= 0 ? T.send[1] : NULL, T.nbr[3] >= 0 ? T.send[3] : NULL);
     const size_t sc[8] = {0, T.nbr[1] >= 0 ? ne : 0, 0, T.nbr[3] >= 0 ? nn : 0, 0, 0, 0, 0};
     const size_t rc[8] = {T.nbr[0] >= 0 ? ne : 0, 0, T.nbr[2] >= 0 ? nn : 0, 0, 0, 0, 0, 0};
-    if (pomgpu_tp_move(c, sc, rc)) return;
+    // rim round R1: the lines and their round on the side stream, beside the column kernel (which does not read them); the side
+    // stream's staging buffers hold them until k_advct_fix has run (the next side round forks off the main stream behind it)
+    const bool side = rim_side(c);                            // (pomgpu_set_wide_external sized the side stream's buffers for any exchange point)
+    double *const *snd = side ? T.send2 : T.send, *const *rcv = side ? T.recv2 : T.recv;
+    if (side) side_begin(c);
+    launch_advct_edge(c, T.nbr[1] >= 0 ? snd[1] : NULL, T.nbr[3] >= 0 ? snd[3] : NULL);
+    const int rcm = side ? pomgpu_tp_move_side(c, sc, rc) : pomgpu_tp_move(c, sc, rc);
+    if (side) side_end(c, c->ev_r1);
+    if (rcm) return;
     launch_advct_col(c, sum2d);
-    launch_advct_fix(c, T.nbr[0] >= 0 ? T.recv[0] : NULL, T.nbr[2] >= 0 ? T.recv[2] : NULL);
+    if (side) (void)hipStreamWaitEvent(c->stream, c->ev_r1, 0);
+    launch_advct_fix(c, T.nbr[0] >= 0 ? rcv[0] : NULL, T.nbr[2] >= 0 ? rcv[2] : NULL);
     if (sum2d) launch_advct_fix2d(c, T.nbr[0] >= 0, T.nbr[2] >= 0);
     if (!defer_xch) xch(c, 2, D3(c, advx), P.kb, D3(c, advy), P.kb);   // :315, :405
     return;
@@ -837,6 +850,45 @@ static void side_end(pomgpu_ctx *c, hipEvent_t ev) {
 static void side_join(pomgpu_ctx *c) {                        // everything the side stream holds, before the main stream goes on
   if (c->early_started) (void)hipStreamWaitEvent(c->stream, c->ev_early, 0);
   if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }
+  if (c->r2_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r2, 0); c->r2_pending = 0; }
+  if (c->r8_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r8, 0); c->r8_pending = 0; }
+}
+// ---- rim rounds: exchange points on the side stream, beside the kernels of the main stream ------------------------------------------
+// north_star: "halo exchange ... overlapped with interior stencil compute on a second HIP stream".  Four of the step's exchange points
+// have a consumer that either does not need the ghost cells at once or needs them on the ghost lines only; their pack -> message round
+// -> unpack run on the side stream over its own communicator and staging buffers, and the main stream waits for an event where the
+// first reader of those ghost cells starts:
+//   R1  advct's edge lines (seq_advct)                     beside k_advct_col; k_advct_fix waits
+//   R2  advx, advy, aam (advance.f:137, solver.f:315,405)  beside the vertical integrals, the wide exchange and the whole external mode;
+//                                                          mode_internal's 3-D part waits (aam2d's ghost lines follow the round, k_vint)
+//   R7  wubot, wvbot, uf, vf (advance.f:466-467)           beside the Asselin filter, which leaves the ghost lines alone: there it ends in
+//                                                          u = uf, v = vf (:511-514), written from the same message
+//   R8  ub, vb, level kb of u, uf, v, vf (:516-521)        beside the 2-D tail, check_velocity and the NEXT step's baropg, which moves
+//                                                          in front of advct for it; advct (the next reader of u, v) waits
+// All ranks post the same rounds in the same order on either communicator: whether this path is taken depends on nothing but the
+// agreed side stream (pomgpu_tp_side_ok) and the collective switch set (POMGPU_RIM_MAIN keeps the four rounds on the main stream).
+static int rim_side(pomgpu_ctx *c) { return c->tp.on && c->exch && c->wide.on && c->wide.split && !SW(c, RIM_MAIN); }
+static void rim_wait_r2(pomgpu_ctx *c) { if (c->r2_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r2, 0); c->r2_pending = 0; } }
+static void rim_wait_r8(pomgpu_ctx *c) { if (c->r8_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r8, 0); c->r8_pending = 0; } }
+// one exchange point on the side stream (the caller has called side_begin): `dev2`, if given, is a second list of arrays of the same
+// shapes that receive the same ghost values (u, v behind uf, vf)
+static int rim_exchange(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *dev2 = NULL) {
+  const KP &P = c->P;
+  pomgpu_transport &T = c->tp;
+  size_t total = 0;
+  for (int a = 0; a < count; a++) total += (size_t)nz[a];
+  const size_t len[8] = {(size_t)P.jm, (size_t)P.jm, (size_t)P.im, (size_t)P.im, 1, 1, 1, 1};
+  size_t cnt[8];
+  for (int d = 0; d < 8; d++) {
+    cnt[d] = T.nbr[d] >= 0 ? total * len[d] : 0;
+    if (cnt[d] > T.cap2[d]) return fail(c, POMGPU_EINVAL, "exchange (side stream): %zu doubles exceed the staging buffer", cnt[d]);
+  }
+  if (launch_halo_pack8(c, dev, nz, count, T.send2)) return fail(c, POMGPU_EINVAL, "exchange (side stream): bad array list");
+  const int rc = pomgpu_tp_move_side(c, cnt, cnt);
+  if (rc) return rc;
+  (void)launch_halo_unpack8(c, dev, nz, count, (const double *const *)T.recv2);
+  if (dev2) (void)launch_halo_unpack8(c, dev2, nz, count, (const double *const *)T.recv2);
+  return POMGPU_OK;
 }
 static void early_invalidate(pomgpu_ctx *c) {
   if (c->early_started) { (void)hipStreamWaitEvent(c->stream, c->ev_early, 0); c->early_started = 0; }
@@ -846,11 +898,15 @@ int pomgpu_side_stream(pomgpu_ctx *c) {
   if (c->side) return 1;
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = NULL; return 0; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_r1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_r2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_r8, hipEventDisableTiming) != hipSuccess) {
     (void)hipStreamDestroy(c->side);
     c->side = NULL;
     return 0;
   }
+#ifdef POMGPU_EMU
+  emu_stream_defer(c->side);                                  // tests: the side stream's work at the LATEST moment the device could run it (tests/emu/hip/hip_runtime.h)
+#endif
   return 1;
 }
 #define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
@@ -883,15 +939,33 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      
   KP &P = c->P;
   if (P.mode != 2) {
     const bool lib_x = c->tp.on && c->exch && !SW(c, ADVCT_SPLIT);
+    auto pressure_gradient = [&]() {
+      if (P.npg == 1) seq_baropg(c, sum2d, defer_rt);
+      else if (P.npg == 2) seq_baropg_mcc(c, sum2d, defer_rt);
+      else {                                                  // advance.f:117-120
+        fprintf(stderr, "\nError: invalid value for npg\n");
+        c->con.error_status = 1;
+      }
+    };
+    // rim round R8 of the step before (the ghost cells of u, v, ub, vb) may still be in flight: baropg reads none of them and
+    // shares nothing with advct, so it goes first and advct waits
+    const bool pg_first = c->r8_pending != 0;
+    if (pg_first) pressure_gradient();
+    rim_wait_r8(c);
     seq_advct(c, sum2d, lib_x);                               // lib_x: advx, advy travel with aam below
-    if (P.npg == 1) seq_baropg(c, sum2d, defer_rt);
-    else if (P.npg == 2) seq_baropg_mcc(c, sum2d, defer_rt);
-    else {                                                    // advance.f:117-120
-      fprintf(stderr, "\nError: invalid value for npg\n");
-      c->con.error_status = 1;
-    }
+    if (!pg_first) pressure_gradient();
     launch_aam(c);
-    if (lib_x) xch(c, 3, D3(c, advx), P.kb, D3(c, advy), P.kb, D3(c, aam), P.kbm1);   // solver.f:315,405 + :137 in one round
+    if (lib_x && sum2d && rim_side(c)) {                      // rim round R2: solver.f:315,405 + :137 on the side stream
+      double *arr[3] = {D3(c, advx), D3(c, advy), D3(c, aam)};
+      const int nz[3] = {P.kb, P.kb, P.kbm1};
+      side_begin(c);
+      const int rc2 = rim_exchange(c, arr, nz, 3);
+      if (!rc2) launch_vint(c, 1, -1);                        // aam2d on the ghost lines (advance.f:158-168), from the aam that has just arrived
+      side_end(c, c->ev_r2);
+      c->r2_pending = 1;
+      if (rc2) return rc2;
+    }
+    else if (lib_x) xch(c, 3, D3(c, advx), P.kb, D3(c, advy), P.kb, D3(c, aam), P.kbm1);   // solver.f:315,405 + :137 in one round
     else xch(c, 1, D3(c, aam), P.kbm1);                       // :137
   }
   return POMGPU_OK;
@@ -909,7 +983,9 @@ static int wide_begin(pomgpu_ctx *c);
 static int mode_interaction(pomgpu_ctx *c, int sums_done) {   // advance.f:144-202
   NEED_HOT(c);
   if (c->wide.on) {                                           // one wide exchange instead of ~180 narrow ones
-    if (c->P.mode != 2) launch_vint(c, sums_done);            // :152-168
+    // :152-168; while rim round R2 is in flight aam's ghost lines are not there yet: this launch leaves aam2d's alone, the side stream
+    // fills them behind the round (lateral_viscosity)
+    if (c->P.mode != 2) launch_vint(c, sums_done, sums_done && c->r2_pending ? 1 : 0);
     return wide_begin(c);                                     // :170-199 on the extended tile
   }
   if (c->P.mode != 2) {
@@ -1343,6 +1419,8 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
     // the wr exchange of the end of the step shares these buffers (same stream, so never at the same time)
     const size_t wrn[8] = {(size_t)P.kb * P.jm, (size_t)P.kb * P.jm, (size_t)P.kb * P.im, (size_t)P.kb * P.im, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb};
     for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < wrn[d8]) need2[d8] = wrn[d8];
+    // ... and so do the rim rounds (the exchange points that run on the side stream): what an ordinary exchange point may need (pomgpu_tp_setup)
+    for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < 8 * wrn[d8]) need2[d8] = 8 * wrn[d8];
     if ((rc = pomgpu_tp_reserve2(c, need2))) { wide_free(c); return rc; }
     JobList epk, eup, lpk, lup;
     wide_jobs(c, WIDE_HALO_EARLY, NEL(WIDE_HALO_EARLY), WIDE_LOCAL, NEL(WIDE_LOCAL), true, epk, eup, Wd.e_scount, Wd.e_rcount, T.send2, T.recv2);
@@ -1450,7 +1528,7 @@ extern "C" int pomgpu_mode_external(pomgpu_ctx *c) {
 // output file), so realvertvl itself may run there as well (with_kernel: beside the NEXT step's external substeps, below)
 static int wr_on_side(pomgpu_ctx *c, int with_kernel) {
   const KP &P = c->P;
-  side_join(c);                                               // at most one piece of side work outstanding per event
+  if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }   // at most one piece of side work outstanding per event
   side_begin(c);
   if (with_kernel) launch_realvertvl(c);
   double *arr[1] = {D3(c, wr)};
@@ -1474,6 +1552,8 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
   NEED_HOT(c);
   KP &P = c->P;
   const pom_blkcon &k = c->con;
+  rim_wait_r2(c);                                             // advx, advy, aam: ghost cells from the side stream (advq, advt2 read aam's)
+  rim_wait_r8(c);                                             // (a step whose lateral_viscosity did not run: nothing else has waited)
   if ((k.iint != 1 || k.time0 != 0.) && k.mode != 2) {
     launch_int_uvmean(c);                                     // :365-393
     launch_vertvl(c, 1);                                      // :396-398
@@ -1549,6 +1629,26 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
     }
     if (!lib_x) xch(c, 2, D2(c, wubot), 1, D2(c, wvbot), 1);  // solver.f:1777, :1874
     launch_bcondorl3(c);                                      // :464 (does not read wubot, wvbot)
+    const bool rim78 = lib_x && !SW(c, UV_FULL_EXCHANGE) && rim_side(c);
+    if (rim78) {
+      // rim rounds R7 and R8: both of the step's last velocity exchanges on the side stream.  R7 brings uf, vf (and wubot, wvbot); the
+      // filter below runs on the cells this tile OWNS and leaves the ghost lines alone -- there :469-514 ends in u = uf, v = vf
+      // (levels 1..kbm1; ub, vb and level kb of the ghost lines come with R8 as before), which R7's message writes as well.
+      const int top = P.kb - 1;
+      double *a7[4] = {D2(c, wubot), D2(c, wvbot), D3(c, uf), D3(c, vf)}, *b7[4] = {D2(c, wubot), D2(c, wvbot), D3(c, u), D3(c, v)};
+      const int n7[4] = {1, 1, P.kbm1, P.kbm1};
+      side_begin(c);
+      int rcs = rim_exchange(c, a7, n7, 4, b7);               // solver.f:1777,1874 + :466-467
+      side_end(c, c->ev_r8);
+      launch_uv_filter(c, 1);                                 // :469-514 on owned cells, beside R7
+      double *a8[6] = {D3(c, ub), D3(c, vb), LEV3(c, D3(c, u), top), LEV3(c, D3(c, uf), top), LEV3(c, D3(c, v), top), LEV3(c, D3(c, vf), top)};
+      const int n8[6] = {P.kb, P.kb, 1, 1, 1, 1};
+      side_begin(c);                                          // behind the filter: R8 sends what it wrote
+      if (!rcs) rcs = rim_exchange(c, a8, n8, 6);             // :516-521
+      side_end(c, c->ev_r8);
+      c->r8_pending = 1;
+      if (rcs) return rcs;
+    } else {
     if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
     else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);     // :466-467
     launch_uv_filter(c);                                      // :469-514
@@ -1563,6 +1663,7 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
     } else {
       xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
     }
+    }
   }
   launch_int_tail(c);                                         // :525-531, and the derived coefficients of the new dt (k_coef_dt's) in the same pass
   const bool side_wr = c->tp.on && c->exch && c->wide.split && c->tp.wr_side;   // wr_side: no rank asked for POMGPU_WR_MAIN (agreed with side_agreed)
@@ -1570,6 +1671,7 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
     c->wr_deferred = 1;                                       // :534 and solver.f:2055 beside the next step's external substeps
     return POMGPU_OK;
   }
+  rim_wait_r8(c);                                             // realvertvl reads u, v of the eastern / northern ghost line
   launch_realvertvl(c);                                       // :534
   // solver.f:2055 on the side stream: the round runs beside check_velocity and the next step's lateral_viscosity; the next
   // step's early gather follows it on the same stream, and whoever looks at the state waits for it (side_join)

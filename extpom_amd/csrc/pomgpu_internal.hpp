@@ -445,7 +445,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN)
+  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN) X(RIM_MAIN)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
@@ -476,7 +476,7 @@ static inline void pomgpu_switches_read(pomgpu_switches &s) {
 // rounds exist and on which stream / communicator they run): the ranks compare it before any collective depends on it
 static inline unsigned pomgpu_switches_collective_digest(const pomgpu_switches &s) {
   static const int coll[] = {SW_ADVCT_SPLIT, SW_ADVQ_EXCHANGE, SW_PROD_FULL, SW_QFILTER_SPLIT, SW_UV_FULL_EXCHANGE, SW_NO_OVERLAP,
-                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT, SW_WR_NODEFER};
+                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT, SW_WR_NODEFER, SW_RIM_MAIN};
   unsigned h = 2166136261u;
   for (size_t n = 0; n < sizeof coll / sizeof coll[0]; n++) {
     h = (h ^ (unsigned)(s.on[coll[n]] ? 1 + coll[n] : 0)) * 16777619u;
@@ -504,6 +504,7 @@ struct pomgpu_transport {
   size_t cap[8];             // capacity of each staging buffer, doubles
   double *send2[8], *recv2[8];   // staging buffers of the side stream's rounds (they overlap rounds on the main stream)
   size_t cap2[8];
+  int fn_ordered;            // the callback mover enqueues on pomgpu_current_stream() itself (pomgpu_transport_stream_ordered)
   int side_agreed;           // EVERY rank of the decomposition can serve rounds on the side stream (collective decision, transport.hip)
   int wr_side;               // ... and none of them asked for the wr exchange on the main stream (POMGPU_WR_MAIN)
   long rounds_side;          // message rounds served on the side stream
@@ -541,6 +542,11 @@ struct pomgpu_ctx {
   // the main stream except while work for the side stream is being enqueued.
   hipStream_t cur, side;
   hipEvent_t ev_fork, ev_early, ev_side;
+  // Message rounds of exchange points that run on the side stream beside the main stream's kernels (pomgpu_api.hip "rim rounds"):
+  // ev_r1 = advct's edge lines have arrived, ev_r2 = advx, advy, aam have their ghost cells (r2_pending: the main stream has not
+  // waited yet), ev_r8 = the velocity rounds that end mode_internal (uf, vf, wubot, wvbot; then ub, vb and level kb of u, uf, v, vf)
+  hipEvent_t ev_r1, ev_r2, ev_r8;
+  int r2_pending, r8_pending;
   int early_started;         // this step's early part of the wide exchange is in flight on the side stream (ev_early ends it)
   double *tune_block;        // pomgpu_tune_placement: blk3d and the 3-D scratch arrays live in ONE allocation with room in front ...
   size_t tune_front;         // ... and start this many doubles into it
@@ -681,7 +687,7 @@ void launch_advuv_col(pomgpu_ctx *c);
 int launch_profuv_reg(pomgpu_ctx *c);   // 0 when kb is outside the instantiated range
 void launch_advave_m2a(pomgpu_ctx *c);
 void launch_advave_m2b(pomgpu_ctx *c);
-void launch_vint(pomgpu_ctx *c, int only_aam);
+void launch_vint(pomgpu_ctx *c, int only_aam, int ghost = 0);   // ghost: +1 = every cell but the ghost lines (aam2d only), -1 = the ghost lines alone
 void launch_modeint_tail(pomgpu_ctx *c);
 void launch_ext_elf(pomgpu_ctx *c);
 void launch_ext_uvaf(pomgpu_ctx *c, int interior);
@@ -741,7 +747,7 @@ void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *
 int launch_proft2(pomgpu_ctx *c, double *f0, const double *wfsurf0, const double *fsurf0, int nbc0, double *f1, const double *wfsurf1, const double *fsurf1, int nbc1);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
 void launch_advv_profv(pomgpu_ctx *c, int do_adv, int do_prof);
-void launch_uv_filter(pomgpu_ctx *c);
+void launch_uv_filter(pomgpu_ctx *c, int own = 0);   // own: the ghost lines are left to the exchange (k_vert.hip)
 // k_tile.hip
 void launch_coef_static(pomgpu_ctx *c);
 void launch_coef_dt(pomgpu_ctx *c);

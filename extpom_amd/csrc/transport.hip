@@ -88,6 +88,7 @@ void pomgpu_tp_free(pomgpu_ctx *c) {
   T.on = 0;
   T.side_agreed = 0;
   T.wr_side = 0;
+  T.fn_ordered = 0;
 }
 
 // grow the staging buffers to at least need[d] doubles (directions without a neighbour stay empty)
@@ -154,6 +155,12 @@ extern "C" int pomgpu_transport_side_capable(pomgpu_ctx *c) {
 }
 // the digest of the switches every rank of a decomposition must share (pomgpu_internal.hpp): hosts with a callback mover
 // compare it over their ranks before the first step (RCCL: pomgpu_rccl_init does it over the communicator)
+extern "C" int pomgpu_transport_stream_ordered(pomgpu_ctx *c, int ordered) {
+  if (!c) return POMGPU_EINVAL;
+  if (!c->tp.on || !c->tp.fn) return pomgpu_fail(c, POMGPU_EINVAL, "transport_stream_ordered: set a callback transport first");
+  c->tp.fn_ordered = ordered ? 1 : 0;
+  return POMGPU_OK;
+}
 extern "C" unsigned pomgpu_switch_digest(pomgpu_ctx *c) { return c ? pomgpu_switches_collective_digest(c->sw) : 0u; }
 extern "C" int pomgpu_transport_side_agree(pomgpu_ctx *c, int agreed) {
   if (!c) return POMGPU_EINVAL;
@@ -177,8 +184,8 @@ int pomgpu_tp_move_side(pomgpu_ctx *c, const size_t *scount, const size_t *rcoun
   T.rounds_side++;
   const int slot = c->prof_on ? pomgpu_prof_slot(c, "msg_round_side") : -1;
   if (slot >= 0) pomgpu_prof_pre(c);                          // c->cur is the side stream here
-  if (T.fn) {                                                 // test movers work on the stream they know: hand the data over completed
-    (void)hipStreamSynchronize(c->side);
+  if (T.fn) {                                                 // movers that stage through the host: hand the data over completed
+    if (!T.fn_ordered) (void)hipStreamSynchronize(c->side);   // (a mover that enqueues on pomgpu_current_stream() orders itself)
     T.fn(T.user, T.send2, scount, T.recv2, rcount);
     if (slot >= 0) pomgpu_prof_post(c, slot);
     return POMGPU_OK;
@@ -354,7 +361,7 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
   if (v[2] != -v[3])                                          // every rank sees the same two minima: all of them refuse together
     return give_up("the ranks were started with different POMGPU_* switch sets",
                    "ADVCT_SPLIT ADVQ_EXCHANGE PROD_FULL QFILTER_SPLIT UV_FULL_EXCHANGE NO_OVERLAP NO_SIDE_COMM WR_MAIN WIDE_W WIDE_FULL EXT_SPLIT "
-                   "ADVAVE_SEPARATE EDGE_SPLIT WR_NODEFER choose which message rounds exist: give every rank the same environment");
+                   "ADVAVE_SEPARATE EDGE_SPLIT WR_NODEFER RIM_MAIN choose which message rounds exist: give every rank the same environment");
   int agreed[2] = {v[0], v[1]};
   if (agreed[0]) {
     // the side stream's communicator: the same ranks, split off the first -- collective, entered by ALL ranks or by none

@@ -51,6 +51,7 @@ _SIGS = {
     "pomgpu_last_error": (ctypes.c_char_p, [_P]),
     "pomgpu_sync": (_I, [_P]),
     "pomgpu_stream": (_P, [_P]),
+    "pomgpu_current_stream": (_P, [_P]),
     "pomgpu_upload": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "pomgpu_download": (_I, [_P, _P, _P, _P, _P, _P]),
     "pomgpu_upload_2d": (_I, [_P, _I, _P]),
@@ -73,6 +74,7 @@ _SIGS = {
     "pomgpu_rccl_init": (_I, [_P, _P, _I, _I, ctypes.POINTER(_I), ctypes.c_char_p]),
     "pomgpu_transport_side_capable": (_I, [_P]),
     "pomgpu_transport_side_agree": (_I, [_P, _I]),
+    "pomgpu_transport_stream_ordered": (_I, [_P, _I]),
     "pomgpu_switch_digest": (ctypes.c_uint, [_P]),
     "pomgpu_rccl_nranks": (_I, [_P]),
     "pomgpu_debug_switch": (_I, [_P, ctypes.c_char_p, ctypes.c_char_p]),

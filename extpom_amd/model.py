@@ -110,6 +110,10 @@ class PomGpu:
     def sync(self):
         self._chk(self.L.pomgpu_sync(self.h), "sync")
 
+    def current_stream(self) -> int:
+        """the hipStream_t the library is enqueueing on right now: inside a transport callback, the stream of the round being served"""
+        return int(self.L.pomgpu_current_stream(self.h) or 0)
+
     def device_ptr(self, name: str) -> int:
         if name in P3:
             return self.L.pomgpu_device_3d(self.h, P3[name])
@@ -128,8 +132,10 @@ class PomGpu:
         """ranks in the C ABI's direction order W E S N SW SE NW NE"""
         return [tile.n_west, tile.n_east, tile.n_south, tile.n_north, tile.n_sw, tile.n_se, tile.n_nw, tile.n_ne]
 
-    def set_transport(self, tile, fn, agree=None):
+    def set_transport(self, tile, fn, agree=None, stream_ordered=False):
         """callback mover (tests): fn(send, scount, recv, rcount), each a list of eight (device address, doubles).
+        stream_ordered: fn enqueues its copies on self.current_stream() (pomgpu_transport_stream_ordered): rounds of the library's second
+        stream reach it without that stream having been completed first.
         agree: the host's reduction over ALL ranks -- agree(mine: int) -> min over the ranks -- through which the ranks
         settle whether message rounds may run on the library's second stream (all of them or none, pomgpu.h); without
         it every round stays on the main stream."""
@@ -138,6 +144,8 @@ class PomGpu:
         self._tp_cb = _lib.TRANSPORT_FN(cb)
         nb = (ctypes.c_int * 8)(*self.neighbours8(tile))
         self._chk(self.L.pomgpu_set_transport(self.h, nb, self._tp_cb, None), "set_transport")
+        if stream_ordered:
+            self._chk(self.L.pomgpu_transport_stream_ordered(self.h, 1), "transport_stream_ordered")
         if agree is not None:
             self.side_agree(agree)
 

@@ -53,6 +53,12 @@ void pomgpu_destroy(pomgpu_ctx *ctx);
 const char *pomgpu_last_error(const pomgpu_ctx *ctx);
 int  pomgpu_sync(pomgpu_ctx *ctx);
 void *pomgpu_stream(pomgpu_ctx *ctx);
+/* The stream the library is enqueueing on at this moment.  Outside a callback this is pomgpu_stream(); inside a transport
+ * callback it is the stream of the message round being served -- pomgpu_stream(), or the library's second stream for the rounds
+ * that run beside the kernels (the early part of the wide exchange, the rim rounds, wr): a mover that enqueues its copies must
+ * enqueue them THERE (or complete them before it returns), else the unpack kernel that follows on that stream does not wait
+ * for them. */
+void *pomgpu_current_stream(pomgpu_ctx *ctx);
 
 /* ---- state transfer (pomgpu_upload_state / pomgpu_download_state of SURVEY 8b) ---------- */
 /* Whole blocks; any pointer may be NULL to skip that block.  `bdry` is the bdry block
@@ -152,7 +158,8 @@ int pomgpu_halo_unpack8(pomgpu_ctx *ctx, double *const *dev, const int *nz, int 
  * pomgpu_set_transport: a callback mover for hosts without RCCL between the ranks (tests: ranks sharing one GPU,
  * host threads).  It must deliver send[d][0..scount[d]) to neighbour d -- which receives it as recv[OPP(d)] --
  * and fill recv[d][0..rcount[d]) with what neighbour d sent towards OPP(d); buffers are device memory, the work
- * must be ordered after what is already enqueued on pomgpu_stream() and before what follows.  fn == NULL removes
+ * must be ordered after what is already enqueued on pomgpu_current_stream() (the stream of the round: pomgpu_stream(), or the
+ * library's second stream, whose earlier work has completed when the callback is called) and before what follows there.  fn == NULL removes
  * the transport (and the wide-halo external mode with it). */
 typedef void (*pomgpu_transport_fn)(void *user, const double *const *send, const size_t *scount, double *const *recv,
                                     const size_t *rcount);
@@ -161,7 +168,8 @@ int pomgpu_rccl_available(const char *librccl_path);   /* POMGPU_OK if librccl o
 int pomgpu_rccl_unique_id(void *id128, const char *librccl_path);
 int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, const int *neighbours8,
                      const char *librccl_path);
-/* Message rounds on the library's SECOND stream (the early part of the wide exchange, wr) are a decision every rank of
+/* Message rounds on the library's SECOND stream (the early part of the wide exchange; the rim rounds: advct's edge lines, advx + advy + aam,
+ * the two velocity exchanges that end mode_internal; wr) are a decision every rank of
  * the decomposition must take alike: a rank that kept them on the first stream while its neighbours moved them would post
  * its rounds in another order on another communicator, and the job would hang.  pomgpu_rccl_init agrees on it itself,
  * BEFORE anything collective depends on a rank's own answer: one ncclAllReduce(min) over the first communicator of every
@@ -176,12 +184,17 @@ int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, c
  * is accepted with any transport.  pomgpu_switch_digest: the digest of (c), for such hosts to compare over their ranks. */
 int pomgpu_transport_side_capable(pomgpu_ctx *ctx);
 int pomgpu_transport_side_agree(pomgpu_ctx *ctx, int agreed);
+/* A callback mover that ENQUEUES its work on pomgpu_current_stream() (device-to-device copies between contexts that share a GPU,
+ * ordered by events) says so here (ordered = 1, after pomgpu_set_transport): the library then calls it for a round of the second
+ * stream without completing that stream first -- such a mover runs beside the kernels like the RCCL transport does.  Default 0:
+ * the callback finds the second stream's earlier work completed (movers that stage through the host). */
+int pomgpu_transport_stream_ordered(pomgpu_ctx *ctx, int ordered);
 unsigned pomgpu_switch_digest(pomgpu_ctx *ctx);
 /* how many ranks RCCL itself reports for the communicator (ncclCommCount): 0 without the RCCL transport, -1 if unknown */
 int pomgpu_rccl_nranks(pomgpu_ctx *ctx);
 /* message rounds served by the transport since it was set (measurement) */
 long pomgpu_exchange_rounds(pomgpu_ctx *ctx);
-/* ... of them on the library's second stream (the early part of the wide exchange, wr): beside kernels, not between them */
+/* ... of them on the library's second stream (the early part of the wide exchange, the rim rounds, wr): beside kernels, not between them */
 long pomgpu_exchange_rounds_side(pomgpu_ctx *ctx);
 
 /* Wide-halo external mode (needs a transport).  It starts in pomgpu_mode_interaction and ends with the

@@ -110,20 +110,35 @@ def run_split(a, grid, im, jm, kb, nml, nx, ny, steps, libpath, dev):
             w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
 
             def mover(send, scount, recv, rcount):
-                ts.synchronize()                      # what the library packed is in the staging buffers
+                # ASYNCHRONOUS, like the RCCL transport: nothing here waits for the device.  The copies are enqueued on the stream of the
+                # round (pomgpu_current_stream: the kernels' stream or the library's second one) behind an event the neighbour recorded
+                # after its pack; the host threads only meet at two barriers to hand the events over.  The rounds on the second stream
+                # therefore really run beside the kernels of the first, and a main-stream kernel that does not wait for the round it
+                # depends on reads stale ghost cells here as it would between GPUs.
+                cs = torch.cuda.ExternalStream(g.current_stream())
+                packed = torch.cuda.Event()
+                packed.record(cs)
                 for d in range(8):
                     if nb[d] >= 0 and scount[d]:
-                        board.box[(r, nb[d], d)] = (send[d], scount[d])
+                        board.box[(r, nb[d], d)] = (send[d], scount[d], packed)
                 board.barrier.wait()
-                for d in range(8):
-                    if nb[d] >= 0 and rcount[d]:
-                        p, n = board.box[(nb[d], r, OPP[d])]
-                        assert n == rcount[d], (r, d, n, rcount[d])
-                        w(recv[d], n).copy_(w(p, n))
-                ts.synchronize()
-                board.barrier.wait()                  # nobody repacks a buffer a neighbour is still reading
+                with torch.cuda.stream(cs):
+                    for d in range(8):
+                        if nb[d] >= 0 and rcount[d]:
+                            p, n, ev = board.box[(nb[d], r, OPP[d])]
+                            assert n == rcount[d], (r, d, n, rcount[d])
+                            cs.wait_event(ev)                  # the neighbour's pack kernel has filled its staging buffer
+                            w(recv[d], n).copy_(w(p, n), non_blocking=True)
+                taken = torch.cuda.Event()
+                taken.record(cs)
+                board.box[("taken", r)] = taken
+                board.barrier.wait()
+                for d in range(8):                            # nobody repacks a buffer a neighbour is still reading: this stream's next pack waits
+                    if nb[d] >= 0 and scount[d]:
+                        cs.wait_event(board.box[("taken", nb[d])])
+                board.barrier.wait()                          # ... and nobody overwrites a mailbox entry a neighbour has yet to read
 
-            g.set_transport(tile, mover, agree=lambda mine: board.allmin(r, mine))
+            g.set_transport(tile, mover, agree=lambda mine: board.allmin(r, mine), stream_ordered=True)
             assert g.set_wide_external(True, min(t.im for t in tiles), min(t.jm for t in tiles))
             gpu_finish(st, g)
             board.barrier.wait()

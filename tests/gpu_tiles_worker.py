@@ -77,7 +77,7 @@ def worker(rank, world, split, port, out, nml):
     dist.barrier()
     g.download()
     np.savez(os.path.join(out, f"tile{rank}.npz"), i_off=tile.i_off, j_off=tile.j_off, im=tile.im, jm=tile.jm,
-             n=(halo.count if mode == "hook" else g.exchange_rounds()), kernels=np.array(kernels), **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
+             n=(halo.count if mode == "hook" else g.exchange_rounds() + g.exchange_rounds_side()), kernels=np.array(kernels), **{n: st.field(n) for n in BLK2D + BLK3D if n not in SCRATCH})
     g.close()
     dist.barrier()
     dist.destroy_process_group()

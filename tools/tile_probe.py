@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-wide", action="store_true")
     ap.add_argument("--tune", action="store_true", help="pomgpu_tune_placement before the measurement")
+    ap.add_argument("--ab", default="", help="NAME=V[,NAME=V...]: developer switches set on the LIVE context for every other block of steps -- "
+                                             "the step with and without them, interleaved in one context (placement moves a kernel more than most changes do)")
+    ap.add_argument("--ab-rounds", type=int, default=6)
     a = ap.parse_args()
     import torch
     import bench
@@ -43,17 +46,18 @@ def main():
     w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
 
     def mover(send, scount, recv, rcount):
-        for d in range(8):
-            o = OPP[d]
-            if nb[d] >= 0 and rcount[d]:
-                if nb[o] >= 0 and scount[o] == rcount[d]:
-                    w(recv[d], rcount[d]).copy_(w(send[o], scount[o]))
-                elif scount[d] == rcount[d]:
-                    w(recv[d], rcount[d]).copy_(w(send[d], scount[d]))
-                else:                                   # one-way message without a matching buffer of the tile's own
-                    w(recv[d], rcount[d]).zero_()
+        with torch.cuda.stream(torch.cuda.ExternalStream(g.current_stream())):   # the stream of the round (pomgpu.h): the kernels' or the second one
+            for d in range(8):
+                o = OPP[d]
+                if nb[d] >= 0 and rcount[d]:
+                    if nb[o] >= 0 and scount[o] == rcount[d]:
+                        w(recv[d], rcount[d]).copy_(w(send[o], scount[o]))
+                    elif scount[d] == rcount[d]:
+                        w(recv[d], rcount[d]).copy_(w(send[d], scount[d]))
+                    else:                               # one-way message without a matching buffer of the tile's own
+                        w(recv[d], rcount[d]).zero_()
 
-    g.set_transport(tile, mover, agree=lambda mine: mine)    # a stand-in for N identical ranks: this rank's answer is everybody's
+    g.set_transport(tile, mover, agree=lambda mine: mine, stream_ordered=True)    # a stand-in for N identical ranks: this rank's answer is everybody's; the mover enqueues on the round's stream, nothing waits for the device (as with RCCL)
     wide = False
     if not a.no_wide:
         tiles = [pdist.tile_for_rank(r, a.tiles, im, jm) for r in range(a.tiles)]
@@ -70,12 +74,28 @@ def main():
     g.sync()
     dt = (time.perf_counter() - t0) / a.steps
     rounds = (g.exchange_rounds() - r0) / a.steps
+    ab = None
+    if a.ab:
+        sw = dict(kv.split("=", 1) for kv in a.ab.split(","))
+        acc = {"default": [], a.ab: []}
+        for _ in range(a.ab_rounds):
+            for tag in acc:
+                for k, v in sw.items():
+                    g.switch(k, v if tag != "default" else None)
+                g.run(1); g.sync()
+                t1 = time.perf_counter()
+                g.run(a.steps)
+                g.sync()
+                acc[tag].append((time.perf_counter() - t1) / a.steps * 1e3)
+        for k in sw:
+            g.switch(k, None)
+        ab = {tag: {"min": round(min(v), 3), "median": round(sorted(v)[len(v) // 2], 3)} for tag, v in acc.items()}
     prof.pop("phase_step", None); prof.pop("phase_external", None)     # brackets around other brackets (pomgpu.h): not kernels
     msg = prof.pop("msg_round", (0, 0.0))
     msg_side = prof.pop("msg_round_side", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
     print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
-                      "wide": bool(wide), "placement": tuned, "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
+                      "wide": bool(wide), "placement": tuned, "ab_ms_per_step_wall": ab, "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
                       "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
                       "message_rounds_on_side_stream_per_step": g.exchange_rounds_side() / (a.steps + 3), "stand_in_mover_side_ms": round(msg_side[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
