@@ -97,6 +97,15 @@ def _libc_version():
         return "unknown"
 
 
+def _tile_probe_bounds(workload):
+    """profiles/tile_probe_bounds.json (tools/make_tile_bounds.py): ms per step of one tile of the 2 / 4 / 8-tile split and of the single GPU in the same job"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "tile_probe_bounds.json")) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
 def build_state(workload, tile):
     from extpom_amd.cases import make_case
     case, im, jm, kb, _ = WORKLOADS[workload]
@@ -443,6 +452,12 @@ def supervise(args):
     if alt and not args.no_alternate:
         plan.append(dict(tiles=alt, overlap=None))              # None: whichever of the first two was faster
     if args.only_pass is not None:
+        if not 0 <= args.only_pass < len(plan):                 # e.g. pass 2 where no alternate grid exists: say so instead of an IndexError on every rank
+            if rank == 0:
+                print(f"bench: --only-pass {args.only_pass}: this run has passes 0..{len(plan) - 1} (tiles {prim}" + (f", alternate {alt}" if alt and not args.no_alternate else ", no alternate grid") + ")",
+                      file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            return 2
         plan = [plan[args.only_pass]]
     results = []
     for k, ps in enumerate(plan):
@@ -539,6 +554,9 @@ def supervise(args):
         if ok and rank != 0:
             res.update(ms_per_step=0.0, value=0.0)
         results.append(res)
+        if rank == 0:
+            import shutil
+            shutil.rmtree(tmpd, ignore_errors=True)             # the pass's phase files
         msbox = [res.get("ms_per_step"), res["wall_s"]]
         dist.broadcast_object_list(msbox, src=0)                # every supervisor plans the next pass from the same numbers
         res["ms_per_step"], res["wall_s"] = msbox
@@ -850,9 +868,12 @@ def measure(args):
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
-                       "overlap": (("second stream + second communicator for the early part of the wide exchange and wr" if overlap_on
+                       "overlap": (("second stream + second communicator: the early part of the wide exchange, advct's edge lines, advx + advy + aam, the two velocity exchanges that end mode_internal, wr" if overlap_on
                                     else "off: every message round on the kernels' stream (POMGPU_NO_OVERLAP)") if world > 1 else None),
-                       "placement": placement,                      # N = 1: start offsets of blk3d inside its allocation that were tried (MiB), ms per step of each, which was kept
+                       # N = 1: start offsets of blk3d inside its allocation that were tried (MiB), ms per step of each, which was kept.  N > 1: the tiles run where
+                       # the allocator put them ("untuned": every rank would have to try the same number of layouts for their message rounds to match, and an 8-tile
+                       # gains nothing) -- a scaling efficiency is therefore read against n1_untuned_ms_per_step of the N = 1 line, like against like
+                       "placement": placement if world == 1 else "untuned",
                        "rccl_nranks": rccl_nranks,                  # what ncclCommCount reports for the library's communicator (0: no RCCL transport)
                        "message_rounds_ms_rank0": round(msg_ms, 3),
                        "message_rounds_per_step": (g.exchange_rounds() - rounds0) / args.steps if world > 1 else 0,
@@ -876,6 +897,12 @@ def measure(args):
             "kernel_time_share": {k: round(v / tot, 3) for k, v in share[:8]},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in share[:40]},
             "error_status": err,
+            # N = 1: the step as the allocator placed the arrays -- the tuner's first trial is that layout (three steps, events on the kernels' stream); what an
+            # N > 1 line, whose tiles are not tuned, should be compared with
+            "n1_untuned_ms_per_step": (placement["ms_per_step"][0] if (world == 1 and placement and placement.get("tried")) else (round(ms, 3) if world == 1 else None)),
+            # what ONE tile of the N-tile split costs outside the transfers, measured on one GPU through the multi-tile code path (tools/tile_probe.py, committed
+            # under profiles/): the efficiency a measured scaling curve can at most reach, to be read beside it
+            "efficiency_bound_from_tile_probe": _tile_probe_bounds(args.workload),
             "host_libc": _libc_version(),     # bit-parity with the reference leans on this libm's pow (THIRD_PARTY_NOTICES.md)
         }
         if not args.no_cpu_baseline and world == 1:

@@ -15,6 +15,14 @@
 // with swrad != 0) -- not in the benchmarked configuration (nbct = 1).
 #pragma once
 #include <math.h>
+// The error-free transformations below need every operation as written: a compiler that fuses `a.h * b.l + a.l * b.h` or a Horner step
+// into FMAs of its own choosing computes another (not wrong, but different) double-double, and host and device would no longer evaluate
+// the same operations.  The library (__graft_entry__.py) and the host check (tools/check_dd_exp.cpp, tests/test_host_logic.py) are both
+// built with -ffp-contract=off; clang-based compilers (hipcc) also get it here, whatever their command line says (from this header
+// to the end of the translation unit -- which is built with contraction off anyway).  The FMAs that ARE wanted are written as fma().
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 #ifdef __HIPCC__
 #define DDX_HD __host__ __device__ __forceinline__
 #else

@@ -588,6 +588,7 @@ extern "C" double *pomgpu_device_2d(pomgpu_ctx *c, int s) {
 extern "C" double *pomgpu_device_3d(pomgpu_ctx *c, int s) {
   if (!c || s < 0 || s >= POM_NBLK3D) return NULL;
   restore_materialize(c);
+  c->dev3_handed = 1;                                         // pomgpu_tune_placement would leave this address dangling: it refuses from now on (pomgpu.h)
   return SLOT3(c, s);
 }
 extern "C" int pomgpu_bind_host(pomgpu_ctx *c, const double *h2, const double *h3) {
@@ -909,7 +910,7 @@ int pomgpu_side_stream(pomgpu_ctx *c) {
 #endif
   return 1;
 }
-#define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; (void)hipSetDevice((c)->device)
+#define NEED_RAW(c) if (!(c)) return POMGPU_EINVAL; if ((c)->broken) return POMGPU_EHIP; (void)hipSetDevice((c)->device)
 static void wide_flush(pomgpu_ctx *c);
 #define NEED_HOT(c) NEED_RAW(c); ext_canonical(c); wide_flush(c)   /* the entry points pomgpu_advance strings together */
 #define NEED(c) NEED_HOT(c); side_join(c); restore_materialize(c)
@@ -973,7 +974,9 @@ static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      
 static int wide_early_start(pomgpu_ctx *c);
 // The reference's own sequence (advance.f:14-21: surface_forcing, lateral_bc, lateral_viscosity, mode_interaction) gets the
 // early part of the wide exchange beside lateral_viscosity like pomgpu_advance does: the step's forcing is in place when the
-// host calls this (anything that touches the state in between joins the side stream first, and wide_begin then gathers all)
+// host calls this.  What the early part has moved is NOT moved again: between this call and pomgpu_mode_interaction the host leaves the
+// 2-D state alone (pomgpu.h says so); the two calls that may come in between -- pomgpu_upload, pomgpu_upload_2d, made by every rank
+// alike -- end the early part's validity themselves (early_invalidate) and wide_begin then gathers everything in one round.
 extern "C" int pomgpu_lateral_viscosity(pomgpu_ctx *c) {
   NEED_HOT(c);
   const int rc = wide_early_start(c);
@@ -1933,6 +1936,8 @@ extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, doub
 #else
   KP &P = c->P;
   if ((c->flags & POMGPU_CTX_2D) || !P.b3 || steps < 1 || max_try < 1) return fail(c, POMGPU_EINVAL, "tune_placement: a context with 3-D arrays, steps >= 1, max_try >= 1");
+  if (c->dev3_handed)                                         // the arrays are about to move (and the allocations they lived in to be freed)
+    return fail(c, POMGPU_EINVAL, "tune_placement: pomgpu_device_3d has handed out addresses of the 3-D arrays, which this call would leave dangling -- tune first, take addresses afterwards");
   // several tiles: the trial steps post message rounds -- every rank calls this alike (same steps, same max_try), each keeps its own best
   if (P.n3 * sizeof(double) < ((size_t)64 << 20) && !SW(c, TUNE_FORCE)) return POMGPU_OK;
   const size_t unit = 2 * P.n3;                               // start offsets: multiples of two arrays
@@ -1970,9 +1975,11 @@ extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, doub
   }
   // (start offset in units of two arrays, wider distance?) in the order they are tried
   static const int KS[20][2] = {{0, 0}, {3, 0}, {10, 0}, {0, 1}, {3, 1}, {10, 1}, {5, 0}, {5, 1}, {2, 0}, {1, 0}, {7, 0}, {4, 0}, {7, 1}, {2, 1}, {15, 0}, {20, 0}, {25, 0}, {30, 0}, {15, 1}, {20, 1}};
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
+  hipEvent_t e0 = NULL, e1 = NULL;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    return fail(c, POMGPU_EHIP, "tune_placement: hipEventCreate failed");   // nothing has moved yet
+  }
   int n = 0, best = 0, rc = POMGPU_OK;
   TuneLay lay[20];
   double ms[20];
@@ -1994,9 +2001,16 @@ extern "C" int pomgpu_tune_placement(pomgpu_ctx *c, int steps, int max_try, doub
     n++;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (rc) return rc;
-  if (n && (rc = tune_relayout(c, lay[best]))) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!rc && n) rc = tune_relayout(c, lay[best]);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, POMGPU_EHIP, "tune_placement: hipStreamSynchronize failed");
+  if (rc) {
+    // a move that stopped half way leaves some arrays in the old layout and some in the new one while P.b3 / P.a3 describe one of them:
+    // the device mirrors no longer hold the state.  Say so once and for all -- error_status = 1 (the reference's convention), and every
+    // hot-path entry point of this context refuses from here on; the host uploads its state into a fresh context.
+    c->broken = 1;
+    c->con.error_status = 1;
+    return rc;
+  }
   for (int q = 0; q < n; q++) {
     if (ms_out) ms_out[q] = ms[q];
     if (front_mib_out) front_mib_out[q] = (long)(lay[q].f * sizeof(double) >> 20);

@@ -552,6 +552,8 @@ struct pomgpu_ctx {
   size_t tune_front;         // ... and start this many doubles into it
   int tune_kmax;             // the room in front: this many units of two arrays
   size_t tune_a0, tune_amax; // the distance between the arrays of blk3d as it was, and the wider one the allocation has room for
+  int dev3_handed;           // pomgpu_device_3d has given out an address of a 3-D array: pomgpu_tune_placement, which moves them, refuses from then on
+  int broken;                // a relayout of the 3-D arrays failed half way (pomgpu_tune_placement): the mirrors no longer hold the state, every hot-path entry point refuses
   int wr_deferred;           // pomgpu_run: the last step's realvertvl + wr exchange are still to come (beside the next step's external substeps)
   int side_pending;          // work on the side stream that the main stream has not waited for yet (ev_side ends it)
   pom_blkcon con;            // host copy of blkcon (iint, iext, error_status live here)

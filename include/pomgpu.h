@@ -82,7 +82,8 @@ int pomgpu_bind_host(pomgpu_ctx *ctx, const double *host_blk2d, const double *ho
  * read_restore_ts_interior_pnetcdf(n,kb,tr,sr) (bounds_forcing.f:1040,1060): record n (1-based),
  * arrays dimensioned (im,jm,kb).  Copied to the device. */
 int pomgpu_set_restore_record(pomgpu_ctx *ctx, int n, const double *tr, const double *sr);
-/* Device address of a mirror (for halo exchange by the caller, e.g. RCCL send/recv). */
+/* Device address of a mirror (for halo exchange by the caller, e.g. RCCL send/recv).  An address of a 3-D array stays valid until
+ * pomgpu_destroy -- pomgpu_tune_placement, which moves those arrays, refuses once one has been handed out. */
 double *pomgpu_device_2d(pomgpu_ctx *ctx, int slot2d);
 double *pomgpu_device_3d(pomgpu_ctx *ctx, int slot3d);
 
@@ -217,10 +218,15 @@ int pomgpu_set_wide_external(pomgpu_ctx *ctx, int on, int min_im, int min_jm);
 /* ---- the hot path: orchestration (advance.f) -------------------------------------------- */
 int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
 /* With the wide-halo mode and side-stream rounds agreed, pomgpu_lateral_viscosity also starts the EARLY part of the wide
- * exchange on the second stream, and pomgpu_mode_interaction then sends only the late part.  Between the two calls nothing
- * may be called on ONE rank only that looks at the state (download, domain_stats, set_forcing_record ...): such a call joins
- * the side stream, after which that rank would gather everything in one round while its neighbours post the late part --
- * unequal message counts.  The reference's own sequence (advance.f:14-21) and pomgpu_advance satisfy this by construction. */
+ * exchange on the second stream, and pomgpu_mode_interaction then sends only the late part: what the early part has moved (ua, va,
+ * uab, vab, el, elb, d, the surface fluxes, wubot, wvbot, the open-boundary lines) is not moved again.  Between the two calls the host
+ * therefore leaves the 2-D state alone: no forcing setters (pomgpu_set_forcing_record / _lateral_record, pomgpu_surface_forcing,
+ * pomgpu_lateral_bc -- advance.f:14-18 runs them BEFORE lateral_viscosity), no writes through pomgpu_device_2d; pomgpu_upload and
+ * pomgpu_upload_2d are allowed if EVERY rank makes them (they end the early part's validity, and pomgpu_mode_interaction then gathers
+ * everything in one round -- on one rank only that would be unequal message counts).  The reference's own sequence (advance.f:14-21) and
+ * pomgpu_advance satisfy this by construction.
+ * pomgpu_lateral_viscosity and pomgpu_mode_internal also post the rim rounds (advct's edge lines; the two velocity exchanges that end
+ * mode_internal) on the second stream; whatever looks at the state afterwards waits for them by itself. */
 int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */
 int pomgpu_mode_interaction(pomgpu_ctx *ctx);    /* advance.f:144-202 */
 /* advance.f:205-353; uses blkcon.iext.  One call per substep, as the reference makes them (advance.f:27-29).  PAIRING: on a
@@ -283,7 +289,11 @@ int pomgpu_run(pomgpu_ctx *ctx, int nsteps);
  * tried (arrays below 64 MiB, no memory for the move).  On several tiles the trial steps post message rounds: every rank makes the
  * call alike (same steps, same max_try) and keeps its own best.  Needs the arrays' size plus the room again while it moves in.
  * The placement survives pomgpu_upload: a host that wants its run to start from an untouched state tunes on the initial state
- * and uploads it again (state and blkcon) before its first step. */
+ * and uploads it again (state and blkcon) before its first step.
+ * The call MOVES the 3-D arrays (and frees the allocations they lived in): every address obtained from pomgpu_device_3d before it
+ * would dangle, so the call refuses (POMGPU_EINVAL) once pomgpu_device_3d has been used on the context -- tune first, take addresses
+ * afterwards.  If a move fails half way (a HIP error inside it) the mirrors no longer hold the state: error_status = 1 and every later
+ * hot-path call on this context returns POMGPU_EHIP; destroy it and upload the state into a new one. */
 int pomgpu_tune_placement(pomgpu_ctx *ctx, int steps, int max_try, double *ms_out, long *front_mib_out, long *pad_mib_out, int *ntried, int *kept);
 
 /* ---- the hot path: kernels (solver.f, bounds_forcing.f), device-resident ---------------- */

@@ -6,7 +6,10 @@ arithmetic, the Thomas solves, the vertical integrals and the whole 2-D external
                       largest difference of every prognostic field, relative to the field's largest magnitude
   part B (GB/s):      2048x1536x50, the two builds interleaved in one process (tools/kbench.py's method): ms per kernel,
                       internal mode, algorithmic GB/s at 8 and at 4 bytes per 3-D value
-usage: python tools/fp32_study_gpu.py [--skip-speed] [--out gpurun_out/fp32_study.json]"""
+  part C (tolerance on the config's OWN grid): 2048x1536x50, both builds in one process (60 + 30 GB of the 288), after 1, 10, 100
+                      internal steps the largest difference of every prognostic field, relative to the field's largest magnitude
+                      (--full-drift [STEPS,...]; written to --drift-out, default profiles/round5_fp32_drift_basin2048.json)
+usage: python tools/fp32_study_gpu.py [--skip-speed] [--skip-small] [--full-drift [1,10,100]] [--out gpurun_out/fp32_study.json]"""
 import json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +31,49 @@ def rel(a, b, f):
     return float(np.abs(x - y).max() / max(np.abs(x).max(), 1e-300))
 
 
-for case, dims in (("seamount", (65, 49, 21)), ("basin", (256, 192, 50))):
+def full_size_drift(steps_list, fields=PROGNOSTIC, workload="basin2048", beat=lambda m: None):
+    """both builds from the same initial state of the bench grid; only the compared fields come back to the host"""
+    import ctypes
+    from extpom_amd.layout import P2, P3
+    cs, im, jm, kb, desc = bench.WORKLOADS[workload]
+    a = bench.build_state(workload, pdist.tile_for_rank(0, 1, im, jm))
+    g0 = bench.gpu_initialise(a, 0, None); g0.close()
+    b = a.copy()
+    beat("states built")
+    g64, g32 = PomGpu(a, device=0), PomGpu(b, device=0, libpath=L.LIBPATH_F32)
+
+    def fetch(g, st):
+        for f in fields:
+            dst = ctypes.c_void_p(st.field(f).ctypes.data)
+            g._chk((g.L.pomgpu_download_3d if f in P3 else g.L.pomgpu_download_2d)(g.h, (P3 if f in P3 else P2)[f], dst), "download " + f)
+    done, rows = 0, {}
+    for n in steps_list:
+        g64.run(n - done); g32.run(n - done); done = n
+        fetch(g64, a); fetch(g32, b)
+        g64.get_con(); g32.get_con()
+        rows[str(n)] = {f: rel(a, b, f) for f in fields}
+        rows[str(n)]["largest_magnitude_fp64"] = {f: float(np.abs(a.field(f)).max()) for f in fields}
+        rows[str(n)]["error_status"] = [int(a.error_status), int(b.error_status)]
+        beat(f"step {n} compared")
+        print(f"{workload} {im}x{jm}x{kb} step {n:5d}: " + "  ".join(f"{f}={rows[str(n)][f]:.2e}" for f in fields), flush=True)
+    out = {"workload": desc, "builds": {"fp64": g64.L.pomgpu_version().decode(), "fp32-storage": g32.L.pomgpu_version().decode()},
+           "what": "largest |fp32-storage - fp64| of a field after n internal steps from identical initial states, relative to the field's largest magnitude (fp64 run)",
+           "steps": rows}
+    g64.close(); g32.close()
+    return out
+
+
+if "--full-drift" in sys.argv:
+    k = sys.argv.index("--full-drift")
+    steps_list = [int(v) for v in sys.argv[k + 1].split(",")] if k + 1 < len(sys.argv) and sys.argv[k + 1][0].isdigit() else [1, 10, 100]
+    drift_out = sys.argv[sys.argv.index("--drift-out") + 1] if "--drift-out" in sys.argv else os.path.join(ROOT, "profiles", "round5_fp32_drift_basin2048.json")
+    d = full_size_drift(steps_list)
+    os.makedirs(os.path.dirname(drift_out) or ".", exist_ok=True)
+    json.dump(d, open(drift_out, "w"), indent=1)
+    print("wrote", drift_out)
+    res["tolerance_full_size"] = d
+
+for case, dims in (() if "--skip-small" in sys.argv else (("seamount", (65, 49, 21)), ("basin", (256, 192, 50)))):
     a = make_case(case, *dims, dte=6.0, isplit=30)
     gpu_finish_initial(a, device=0)
     b = a.copy()

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--ab", default="", help="NAME=V[,NAME=V...]: developer switches set on the LIVE context for every other block of steps -- "
                                              "the step with and without them, interleaved in one context (placement moves a kernel more than most changes do)")
     ap.add_argument("--ab-rounds", type=int, default=6)
+    ap.add_argument("--round-us", type=float, default=0.0, help="a MODEL of what a message round costs between GPUs: every round holds its stream for this "
+                                                                "many microseconds (a spinning kernel) before its copies -- rounds between kernels then cost it on the step, "
+                                                                "rounds on the second stream only if nothing runs beside them")
     a = ap.parse_args()
     import torch
     import bench
@@ -45,8 +48,17 @@ def main():
     nb = PomGpu.neighbours8(tile)
     w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=dev)
 
+    spin = 0
+    if a.round_us > 0:                                  # calibrate torch's spinning kernel: cycles per microsecond on this box
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000000); torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(10000000); e1.record(); torch.cuda.synchronize()
+        spin = int(a.round_us * 10000000 / (e0.elapsed_time(e1) * 1e3))
+
     def mover(send, scount, recv, rcount):
         with torch.cuda.stream(torch.cuda.ExternalStream(g.current_stream())):   # the stream of the round (pomgpu.h): the kernels' or the second one
+            if spin:
+                torch.cuda._sleep(spin)
             for d in range(8):
                 o = OPP[d]
                 if nb[d] >= 0 and rcount[d]:
@@ -68,12 +80,13 @@ def main():
     g.prof_begin()
     g.run(1)
     prof = g.prof_end()
-    r0 = g.exchange_rounds()
+    r0, r0s = g.exchange_rounds(), g.exchange_rounds_side()
     t0 = time.perf_counter()
     g.run(a.steps)
     g.sync()
     dt = (time.perf_counter() - t0) / a.steps
     rounds = (g.exchange_rounds() - r0) / a.steps
+    rounds_side = (g.exchange_rounds_side() - r0s) / a.steps
     ab = None
     if a.ab:
         sw = dict(kv.split("=", 1) for kv in a.ab.split(","))
@@ -94,10 +107,10 @@ def main():
     msg = prof.pop("msg_round", (0, 0.0))
     msg_side = prof.pop("msg_round_side", (0, 0.0))
     share = sorted(((k, v[0], v[1]) for k, v in prof.items()), key=lambda kv: -kv[2])
-    print(json.dumps({"workload": desc, "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
+    print(json.dumps({"workload": desc, "workload_key": a.workload, "library_build_id": g.L.pomgpu_build_id().decode(), "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
                       "wide": bool(wide), "placement": tuned, "ab_ms_per_step_wall": ab, "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
                       "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
-                      "message_rounds_on_side_stream_per_step": g.exchange_rounds_side() / (a.steps + 3), "stand_in_mover_side_ms": round(msg_side[1], 3),
+                      "message_rounds_on_side_stream_per_step": rounds_side, "modelled_round_latency_us": a.round_us, "stand_in_mover_side_ms": round(msg_side[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
     g.close()
 
