@@ -868,7 +868,7 @@ def measure(args):
             "data": "synthetic",
             "config": {"workload": desc + f", mode=3 nadv=2 nitera=1 npg=1 dte=6 isplit=30", "tiles": f"{tile.nproc_x}x{tile.nproc_y}",
                        "tile": f"{tile.im_local}x{tile.jm_local}x{kb}", "global_cells": cells, "exchange": exchange,
-                       "overlap": (("second stream + second communicator: the early part of the wide exchange, advct's edge lines, advx + advy + aam, the two velocity exchanges that end mode_internal, wr" if overlap_on
+                       "overlap": (("second stream + second communicator: nine of a step's ten message rounds (the early part of the wide exchange, advct's edge lines, advx + advy + aam, w, the turbulence arrays, T / S / rho, the two velocity exchanges that end mode_internal, wr); between kernels: the late part of the wide exchange" if overlap_on
                                     else "off: every message round on the kernels' stream (POMGPU_NO_OVERLAP)") if world > 1 else None),
                        # N = 1: start offsets of blk3d inside its allocation that were tried (MiB), ms per step of each, which was kept.  N > 1: the tiles run where
                        # the allocator put them ("untuned": every rank would have to try the same number of layouts for their message rounds to match, and an 8-tile

@@ -303,7 +303,8 @@ void launch_bcondorl3(pomgpu_ctx *c) {
 // st[a]: array a lives in the storage type of the 3-D arrays (blk3d, the 3-D scratch arrays: fp32 in the fp32-storage
 // variant), else it is a 2-D array of doubles.  The staging buffers always carry doubles: a stored fp32 value is widened
 // on the way out and rounds back to itself on the way in, so one message may mix 2-D and 3-D arrays.
-struct HaloArgs { double *ptr[8]; int nz[8]; size_t off[8]; int count; unsigned char st[8]; };
+#define HALO_MAXARR 12                                      /* arrays one exchange point may carry (the reference's largest: six, advance.f:516-521; rim round Rq: nine) */
+struct HaloArgs { double *ptr[HALO_MAXARR]; int nz[HALO_MAXARR]; size_t off[HALO_MAXARR]; int count; unsigned char st[HALO_MAXARR]; };
 #ifdef POMGPU_STORE_F32
 #define HGET(p, i, j, k) (A.st[a] ? (double)G3(p, i, j, k) : (p)[IX3(i, j, k)])
 #define HPUT(p, i, j, k, v) do { if (A.st[a]) G3(p, i, j, k) = (v); else (p)[IX3(i, j, k)] = (v); } while (0)
@@ -395,11 +396,11 @@ __global__ void k_halo_unpack8(KP P, HaloArgs A, Halo8 from) {
   }
 }
 static int halo_args(pomgpu_ctx *c, double *const *dev, const int *nz, int count, HaloArgs &A, int &nzmax) {
-  if (count < 1 || count > 8) return -1;
+  if (count < 1 || count > HALO_MAXARR) return -1;
   size_t off = 0;
   nzmax = 0;
   A.count = count;
-  for (int n = 0; n < 8; n++) { A.ptr[n] = NULL; A.nz[n] = 0; A.off[n] = 0; A.st[n] = 0; }
+  for (int n = 0; n < HALO_MAXARR; n++) { A.ptr[n] = NULL; A.nz[n] = 0; A.off[n] = 0; A.st[n] = 0; }
   for (int n = 0; n < count; n++) {
     if (!dev[n] || nz[n] < 1 || nz[n] > c->P.kb) return -1;
     A.ptr[n] = dev[n]; A.nz[n] = nz[n]; A.off[n] = off;

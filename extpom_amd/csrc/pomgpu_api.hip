@@ -396,6 +396,7 @@ extern "C" void pomgpu_destroy(pomgpu_ctx *c) {
   if (c->side) {
     (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_early); (void)hipEventDestroy(c->ev_side);
     (void)hipEventDestroy(c->ev_r1); (void)hipEventDestroy(c->ev_r2); (void)hipEventDestroy(c->ev_r8);
+    (void)hipEventDestroy(c->ev_rw); (void)hipEventDestroy(c->ev_rq); (void)hipEventDestroy(c->ev_rts);
     (void)hipStreamDestroy(c->side);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -853,6 +854,9 @@ static void side_join(pomgpu_ctx *c) {                        // everything the 
   if (c->side_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_side, 0); c->side_pending = 0; }
   if (c->r2_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r2, 0); c->r2_pending = 0; }
   if (c->r8_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r8, 0); c->r8_pending = 0; }
+  if (c->rw_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rw, 0); c->rw_pending = 0; }
+  if (c->rq_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rq, 0); c->rq_pending = 0; }
+  if (c->rts_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rts, 0); c->rts_pending = 0; }
 }
 // ---- rim rounds: exchange points on the side stream, beside the kernels of the main stream ------------------------------------------
 // north_star: "halo exchange ... overlapped with interior stencil compute on a second HIP stream".  Four of the step's exchange points
@@ -866,11 +870,27 @@ static void side_join(pomgpu_ctx *c) {                        // everything the 
 //                                                          u = uf, v = vf (:511-514), written from the same message
 //   R8  ub, vb, level kb of u, uf, v, vf (:516-521)        beside the 2-D tail, check_velocity and the NEXT step's baropg, which moves
 //                                                          in front of advct for it; advct (the next reader of u, v) waits
+// Three more exchange points of mode_internal have a consumer that needs the exchanged values on its GHOST lines only -- profq, proft and the
+// Asselin filters run over all i, j, ghost lines included (solver.f:1650-1661, advance.f:416-421,444-449), each column from its own operands --
+// and what they leave on a ghost line is what the neighbour computes on the line it owns: the same arithmetic on the same operands (that is
+// the reference's own invariant; every operand of those columns is either exchanged or was computed this way before).  Instead of
+// exchanging the INPUTS in front of the kernel (w + utau2 + uf(kb) + prod: solver.f:1289-1290,1374, advance.f:400; q2f / q2lf: :411-412;
+// tf / sf: solver.f:728, advance.f:436-437) the RESULTS travel behind it:
+//   Rw   w (advance.f:400)                                   beside advq and profq; the tracer advection (its first reader) waits
+//   Rq   q2, q2b, q2l, q2lb, km, kh, kq, l, dtef             beside the tracer step; profu / profv (km of the neighbour line) wait
+//   Rts  t, tb, s, sb, rho                                   beside advu ... the end of the step; the next step's baropg waits
+// The kernels run on every line as before; what they make of a ghost line's stale operands is overwritten by the round.  k_profq forms
+// its production term as on one tile (no lines kernel, no prod exchange).  More bytes (9 + 5 arrays x kb instead of ~6 x kb lines per
+// neighbour), no round between kernels: of a full step's ten rounds only the late part of the wide exchange stays on the kernels' stream.
+// POMGPU_RIM_RESULTS_MAIN keeps the reference's three input exchanges (on the kernels' stream).
 // All ranks post the same rounds in the same order on either communicator: whether this path is taken depends on nothing but the
 // agreed side stream (pomgpu_tp_side_ok) and the collective switch set (POMGPU_RIM_MAIN keeps the four rounds on the main stream).
 static int rim_side(pomgpu_ctx *c) { return c->tp.on && c->exch && c->wide.on && c->wide.split && !SW(c, RIM_MAIN); }
 static void rim_wait_r2(pomgpu_ctx *c) { if (c->r2_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r2, 0); c->r2_pending = 0; } }
 static void rim_wait_r8(pomgpu_ctx *c) { if (c->r8_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_r8, 0); c->r8_pending = 0; } }
+static void rim_wait_rw(pomgpu_ctx *c) { if (c->rw_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rw, 0); c->rw_pending = 0; } }
+static void rim_wait_rq(pomgpu_ctx *c) { if (c->rq_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rq, 0); c->rq_pending = 0; } }
+static void rim_wait_rts(pomgpu_ctx *c) { if (c->rts_pending) { (void)hipStreamWaitEvent(c->stream, c->ev_rts, 0); c->rts_pending = 0; } }
 // one exchange point on the side stream (the caller has called side_begin): `dev2`, if given, is a second list of arrays of the same
 // shapes that receive the same ghost values (u, v behind uf, vf)
 static int rim_exchange(pomgpu_ctx *c, double *const *dev, const int *nz, int count, double *const *dev2 = NULL) {
@@ -900,7 +920,9 @@ int pomgpu_side_stream(pomgpu_ctx *c) {
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = NULL; return 0; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_r1, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_r2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_r8, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_r2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_r8, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_rw, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_rq, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_rts, hipEventDisableTiming) != hipSuccess) {
     (void)hipStreamDestroy(c->side);
     c->side = NULL;
     return 0;
@@ -936,6 +958,7 @@ extern "C" int pomgpu_get_time(pomgpu_ctx *c) {               // advance.f:62-75
 // would otherwise gather by reading advx, advy, drhox, drhoy again (advance.f:152-168)
 static int lateral_viscosity(pomgpu_ctx *c, int sum2d, int defer_rt = 0) {      // advance.f:96-141
   NEED_HOT(c);
+  rim_wait_rts(c);                                            // rho's ghost lines (rim round Rts of the step before; posted ahead of R8 on the same stream)
   rho_materialize(c);                                         // a deferred round trip no step has consumed (baropg reads rho)
   KP &P = c->P;
   if (P.mode != 2) {
@@ -1423,7 +1446,7 @@ extern "C" int pomgpu_set_wide_external(pomgpu_ctx *c, int on, int min_im, int m
     const size_t wrn[8] = {(size_t)P.kb * P.jm, (size_t)P.kb * P.jm, (size_t)P.kb * P.im, (size_t)P.kb * P.im, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb, (size_t)P.kb};
     for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < wrn[d8]) need2[d8] = wrn[d8];
     // ... and so do the rim rounds (the exchange points that run on the side stream): what an ordinary exchange point may need (pomgpu_tp_setup)
-    for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < 8 * wrn[d8]) need2[d8] = 8 * wrn[d8];
+    for (int d8 = 0; d8 < 8; d8++) if (need2[d8] < 10 * wrn[d8]) need2[d8] = 10 * wrn[d8];   // (the largest: nine arrays of kb levels)
     if ((rc = pomgpu_tp_reserve2(c, need2))) { wide_free(c); return rc; }
     JobList epk, eup, lpk, lup;
     wide_jobs(c, WIDE_HALO_EARLY, NEL(WIDE_HALO_EARLY), WIDE_LOCAL, NEL(WIDE_LOCAL), true, epk, eup, Wd.e_scount, Wd.e_rcount, T.send2, T.recv2);
@@ -1563,7 +1586,18 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
     // :400 exchange3d_mpi(w): nothing reads w's ghost cells before advt / advu (advq takes w at the cell's own
     // column only), so on tiles it travels with profq's bottom-boundary exchange below -- one round less
     const bool lib_x = c->tp.on && c->exch;                   // the library's own exchange: rounds may be merged
-    if (!lib_x) xch(c, 1, D3(c, w), P.kb);
+    // rim rounds Rw, Rq, Rts (see "rim rounds" above): results behind the kernels instead of inputs in front of them
+    const bool rimr = lib_x && rim_side(c) && !SW(c, RIM_RESULTS_MAIN) && !SW(c, UV_FULL_EXCHANGE) && !SW(c, ADVQ_EXCHANGE) && !SW(c, PROD_FULL);
+    if (rimr) {
+      double *aw[1] = {D3(c, w)};
+      const int nw[1] = {P.kb};
+      side_begin(c);
+      const int rcw = rim_exchange(c, aw, nw, 1);             // :400
+      side_end(c, c->ev_rw);
+      c->rw_pending = 1;
+      if (rcw) return rcw;
+    }
+    else if (!lib_x) xch(c, 1, D3(c, w), P.kb);
     // :403-409 (uf = vf = 0 is folded into the advq step kernels)
     launch_coef_eta(c);                                       // etb/etf are final once the external mode is done
     // advq's exchange of xflux, yflux (solver.f:458-459) hands a tile the neighbour's xflux(2,j) as its
@@ -1586,11 +1620,26 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
       launch_advq_step(c, D3(c, q2l), D3(c, q2lb), D3(c, vf), x1, y1, 1);
     }
     const int qfuse = !SW(c, QFILTER_SPLIT);
-    seq_profq(c, qfuse, lib_x);                               // with the interior's Asselin filter (:416-421) on its way up
-    xch(c, 2, LEV3(c, D3(c, uf), 1), P.kbm2, LEV3(c, D3(c, vf), 1), P.kbm2);   // :411-412
+    if (rimr) {
+      launch_profq_bc(c);
+      launch_profq(c, 1, qfuse, c->rho_rt_pending);           // the production term as on one tile; ghost lines: stale operands, overwritten by Rq
+    } else {
+      seq_profq(c, qfuse, lib_x);                             // with the interior's Asselin filter (:416-421) on its way up
+      xch(c, 2, LEV3(c, D3(c, uf), 1), P.kbm2, LEV3(c, D3(c, vf), 1), P.kbm2);   // :411-412
+    }
     launch_bcond6_edges(c);                                   // :414
     if (qfuse) launch_q_filter_rim(c);                        // :416-421, edge lines
     else launch_q_filter(c, 1);
+    if (rimr) {
+      double *aq[9] = {D3(c, q2), D3(c, q2b), D3(c, q2l), D3(c, q2lb), D3(c, km), D3(c, kh), D3(c, kq), D3(c, l), D3(c, dtef)};
+      const int nq[9] = {P.kb, P.kb, P.kb, P.kb, P.kb, P.kb, P.kb, P.kb, P.kb};
+      side_begin(c);
+      const int rcq = rim_exchange(c, aq, nq, 9);
+      side_end(c, c->ev_rq);
+      c->rq_pending = 1;
+      if (rcq) return rcq;
+    }
+    rim_wait_rw(c);                                           // the tracer advection and advu / advv read w's ghost lines
     if (k.mode != 4) {
       if (k.nadv == 1) {
         seq_advt1(c, D3(c, tb), D3(c, t), D3(c, tclim), D3(c, uf));
@@ -1610,7 +1659,13 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
       } else {
         return fail(c, POMGPU_EINVAL, "Error: invalid value for nadv");
       }
-      xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);        // :436-437
+      // rim round Rts: T and S leave the tracer advection with stale ghost lines; proft, bcond(4) and the filter run on them as on any line
+      // and the round behind k_ts_update replaces what they made of them -- valid for the one-pass advection, whose own exchange is this one
+      const bool rts = rimr && k.nadv == 2 && P.nitera == 1 && !SW(c, ADVT2_SINGLE);
+      // (without Rts but with Rq: uf(:,:,kb) still holds profq's bottom boundary value, which the reference exchanges at solver.f:1290 and
+      // later copies into t(:,:,kb) with `t = uf` -- Rq does not carry it, so it rides here)
+      if (!rts) xch(c, 2, D3(c, uf), rimr ? P.kb : P.kbm1, D3(c, vf), P.kbm1);   // :436-437
+      if (!rts) rim_wait_rq(c);                               // ... and proft's ghost columns, which nothing will replace, need kh of the ghost lines
       if (!launch_proft2(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs)) {   // :439-440, T and S in one launch
         launch_proft(c, D3(c, uf), D2(c, wtsurf), D2(c, tsurf), k.nbct);
         launch_proft(c, D3(c, vf), D2(c, wssurf), D2(c, ssurf), k.nbcs);
@@ -1622,7 +1677,17 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
       launch_ts_update(c, fold, fnew, k.nadv == 2, 0);        // :444-454 in one pass; trstr/srstr/taurstr on demand
       c->rho_rt_pending = 0;                                  // dens has rewritten rho(1..kbm1)
       c->rst_pending = 1; c->rst_fold = fold; c->rst_fnew = fnew;
+      if (rts) {
+        double *at[5] = {D3(c, t), D3(c, tb), D3(c, s), D3(c, sb), D3(c, rho)};
+        const int nt[5] = {P.kb, P.kb, P.kb, P.kb, P.kb};
+        side_begin(c);
+        const int rct = rim_exchange(c, at, nt, 5);
+        side_end(c, c->ev_rts);
+        c->rts_pending = 1;
+        if (rct) return rct;
+      }
     }
+    rim_wait_rq(c);                                           // profu / profv average km with the neighbour line's
     if (c->P.kb >= 6 && c->P.kb <= 64 && !SW(c, THOMAS_SCRATCH)) {
       launch_advuv_col(c);                                    // :459-460 advu, advv in one pass
       launch_profuv_reg(c);                                   // :461-462 profu, profv with register-resident elimination vectors

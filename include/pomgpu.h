@@ -169,8 +169,9 @@ int pomgpu_rccl_available(const char *librccl_path);   /* POMGPU_OK if librccl o
 int pomgpu_rccl_unique_id(void *id128, const char *librccl_path);
 int pomgpu_rccl_init(pomgpu_ctx *ctx, const void *id128, int rank, int nranks, const int *neighbours8,
                      const char *librccl_path);
-/* Message rounds on the library's SECOND stream (the early part of the wide exchange; the rim rounds: advct's edge lines, advx + advy + aam,
- * the two velocity exchanges that end mode_internal; wr) are a decision every rank of
+/* Message rounds on the library's SECOND stream (the early part of the wide exchange; the rim rounds: advct's edge lines, advx + advy + aam, w,
+ * the turbulence arrays and T / S / rho behind the kernels that produce them, the two velocity exchanges that end mode_internal; wr -- nine of
+ * a full step's ten rounds) are a decision every rank of
  * the decomposition must take alike: a rank that kept them on the first stream while its neighbours moved them would post
  * its rounds in another order on another communicator, and the job would hang.  pomgpu_rccl_init agrees on it itself,
  * BEFORE anything collective depends on a rank's own answer: one ncclAllReduce(min) over the first communicator of every
@@ -225,8 +226,8 @@ int pomgpu_get_time(pomgpu_ctx *ctx);            /* advance.f:62-75  */
  * pomgpu_upload_2d are allowed if EVERY rank makes them (they end the early part's validity, and pomgpu_mode_interaction then gathers
  * everything in one round -- on one rank only that would be unequal message counts).  The reference's own sequence (advance.f:14-21) and
  * pomgpu_advance satisfy this by construction.
- * pomgpu_lateral_viscosity and pomgpu_mode_internal also post the rim rounds (advct's edge lines; the two velocity exchanges that end
- * mode_internal) on the second stream; whatever looks at the state afterwards waits for them by itself. */
+ * pomgpu_lateral_viscosity and pomgpu_mode_internal also post the rim rounds (advct's edge lines; w, the turbulence arrays, T / S / rho and
+ * the two velocity exchanges of mode_internal) on the second stream; whatever looks at the state afterwards waits for them by itself. */
 int pomgpu_lateral_viscosity(pomgpu_ctx *ctx);   /* advance.f:96-141 */
 int pomgpu_mode_interaction(pomgpu_ctx *ctx);    /* advance.f:144-202 */
 /* advance.f:205-353; uses blkcon.iext.  One call per substep, as the reference makes them (advance.f:27-29).  PAIRING: on a

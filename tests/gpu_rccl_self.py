@@ -64,7 +64,7 @@ def main():
     for mover, wide, overlap, split_fails in (("rccl", False, True, False), ("copy", True, True, False), ("rccl", True, True, False), ("rccl", True, False, False),
                                               ("rccl", True, True, True)):
         # overlap: the early part of the wide exchange and the wr round on the library's second stream, over the second
-        # (split) communicator, and the rim rounds -- six of a step's ten rounds beside the kernels; POMGPU_NO_OVERLAP keeps one stream.
+        # (split) communicator, and the rim rounds -- nine of a step's ten rounds beside the kernels; POMGPU_NO_OVERLAP keeps one stream.
         # split_fails: the rank behaves as if ncclCommSplit had failed -- the ranks' agreement (ncclAllReduce(min) inside
         # pomgpu_rccl_init) then keeps every round on the main stream
         if overlap:
@@ -79,8 +79,9 @@ def main():
         bad = [f for f in ref if not np.array_equal(ref[f], got[f])]
         assert err == 0 and not bad, (mover, wide, err, bad[:10])
         # on the second stream: every step the early part of the wide exchange, advct's edge lines, advx + advy + aam and wr; from the second
-        # step on (the first skips mode_internal's 3-D body) the two velocity rounds that end mode_internal (pomgpu_api.hip, "rim rounds")
-        assert ns == (4 + 6 * (STEPS - 1) if wide and overlap and not split_fails else 0), (mover, wide, overlap, split_fails, ns)
+        # step on (the first skips mode_internal's 3-D body) w, the turbulence arrays, T / S / rho and the two velocity rounds that end
+        # mode_internal (pomgpu_api.hip, "rim rounds")
+        assert ns == (4 + 9 * (STEPS - 1) if wide and overlap and not split_fails else 0), (mover, wide, overlap, split_fails, ns)
         print(f"{mover} wide={wide} overlap={overlap} split_fails={split_fails}: {n} message rounds on the kernels' stream + {ns} on the side stream "
               f"(per-point, copy mover: {n_ref}), fields identical")
     print("RCCL-SELF-OK")

@@ -157,8 +157,8 @@ def test_fortran_mpi_ranks_hash_to_the_references_own_mpi_run(tmp_path, name):
     """Four MPI ranks of the FORTRAN host on one GPU (pom_gpu_mpi_main: pomgpu_host_connect_mpi -> the neighbour arithmetic of
     pomgpu_host_neighbours -> libpomgpu_mpi.so's MPI mover -> pomgpu_set_wide_external), every rank's restart-list fields over
     its (jm, im) cells -- ghost cells included -- against the digests of the reference's own four-process MPICH run
-    (tests/golden/tiles_65x49x21_2x2.json; parallel_mpi.f:34-351).  isplit = 10: the wide-halo external mode with five rounds
-    per step on the second stream; isplit = 30 (island): the tiles are narrower than w + 3, pomgpu_set_wide_external declines
+    (tests/golden/tiles_65x49x21_2x2.json; parallel_mpi.f:34-351).  isplit = 10: the wide-halo external mode with eight of a step's
+    ten rounds on the second stream; isplit = 30 (island): the tiles are narrower than w + 3, pomgpu_set_wide_external declines
     on every rank and the per-point exchanges serve the external mode."""
     import json
     from extpom_amd import decomp
@@ -203,11 +203,11 @@ def test_fortran_mpi_ranks_hash_to_the_references_own_mpi_run(tmp_path, name):
     line = [l for l in r.stdout.splitlines() if l.startswith("message rounds per step")][0].split()
     total, side = int(line[line.index("total") + 1]), int(line[-1])
     if cfg["nml"]["isplit"] == 10:
-        # wide mode under the reference's own call sequence: per step 5 rounds between kernels (advx + advy + aam, the late part of the wide
-        # exchange, profq's boundary values, q2 / q2l, T / S) and 5 beside them on the second stream (the early part of the wide exchange,
-        # advct's edge lines, the two velocity rounds that end mode_internal -- not in the first step, which skips its 3-D body -- and wr)
-        # (+ the one-off static gather)
-        assert side == 5 * checks[-1] - 2 and total < 8 * checks[-1] + 30, (total, side)
+        # wide mode under the reference's own call sequence: per step 2 rounds between kernels (advx + advy + aam, the late part of the wide
+        # exchange) and 8 beside them on the second stream (the early part of the wide exchange, advct's edge lines, wr, and -- not in the
+        # first step, which skips mode_internal's 3-D body -- w, the turbulence arrays, T / S / rho and the two velocity rounds that end
+        # mode_internal: pomgpu_api.hip, "rim rounds") (+ the one-off static gather)
+        assert side == 8 * checks[-1] - 5 and total < 4 * checks[-1] + 30, (total, side)
     else:                                                     # tiles too narrow for w = 34: ~200 rounds per step, none on the second stream
         assert side == 0 and total > 150 * checks[-1], (total, side)
 

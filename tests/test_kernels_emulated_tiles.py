@@ -147,16 +147,19 @@ def transport(board, tile, send, scount, recv, rcount):
 OPP8 = (1, 0, 3, 2, 7, 6, 5, 4)
 
 
-def side_rounds(steps):
-    """message rounds the library serves on its second stream in `steps` internal steps from a cold start: every step the early part of the
-    wide exchange, advct's edge lines (R1), advx + advy + aam (R2) and wr; every step but the first (which skips mode_internal's 3-D body,
-    advance.f:362) also the two velocity rounds that end mode_internal (R7, R8) -- pomgpu_api.hip, "rim rounds" there"""
-    return 4 + 6 * (steps - 1)
+def side_rounds(steps, nml=None):
+    """message rounds the library serves on its second stream in `steps` internal steps from a cold start (pomgpu_api.hip, "rim rounds"): every
+    step the early part of the wide exchange, advct's edge lines (R1), advx + advy + aam (R2) and wr; every step but the first (which skips
+    mode_internal's 3-D body, advance.f:362) also w (Rw), the turbulence arrays (Rq), T / S / rho (Rts: only behind the one-pass tracer
+    advection, nadv = 2 with nitera = 1) and the two velocity rounds that end mode_internal (R7, R8)"""
+    nml = nml or {}
+    rts = nml.get("nadv", 2) == 2 and nml.get("nitera", 1) == 1 and nml.get("mode", 3) != 4
+    return 4 + (8 + (1 if rts else 0)) * (steps - 1)
 
 
 def main_rounds_saved(steps):
-    """how many rounds fewer the kernels' own stream carries for it: all of the above, less the late part of the wide exchange that stays there"""
-    return 3 + 5 * (steps - 1)
+    """how many rounds fewer the kernels' own stream carries for it (default namelist): all of a full step's ten but the late part of the wide exchange"""
+    return 3 + 8 * (steps - 1)
 
 
 def run_tiles(nx, ny, nml, single_round=False, library_exchange=False, wide=False, grid=None, isplit=10, case="island", steps=None,
@@ -257,7 +260,7 @@ def test_tiles_match_single_tile_oracle(nx, ny, nml, single_round):
     compare_with_single_tile(out, nml)
 
 
-def compare_with_single_tile(out, nml, grid=None, isplit=10, case="island", steps=None, min_rounds=50, ghosts=False):
+def compare_with_single_tile(out, nml, grid=None, isplit=10, case="island", steps=None, min_rounds=20, ghosts=False):
     IMg, JMg = grid or (IM, JM)
     g = make_case(case, IMg, JMg, KB, dte=6.0, isplit=isplit, **nml)
     oracle_finish_initial(g)
@@ -304,9 +307,9 @@ def test_wide_halo_external_mode(nx, ny, case, nml):
     else:
         grid = WIDE_GRID
     narrow = run_tiles(nx, ny, nml, library_exchange=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
-    n_narrow = compare_with_single_tile(narrow, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=50)
+    n_narrow = compare_with_single_tile(narrow, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=20)
     wide = run_tiles(nx, ny, nml, library_exchange=True, wide=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
-    n_wide = compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=5)
+    n_wide = compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=2)
     assert n_wide[0] < n_narrow[0] - 6 * WIDE_ISPLIT * STEPS + 3 * STEPS + 8, (n_wide, n_narrow)
     # ghost cells too: the tile's arrays are what the per-point exchanges leave there
     for r in wide:
@@ -325,11 +328,11 @@ def test_baselines_own_2x4_split_and_a_tile_with_eight_neighbours(nx, ny, grid, 
     the wide-halo mode with its second-stream rounds against the single-tile oracle, owned cells bit for bit; and the two paths
     against each other on every cell, ghost cells included."""
     lib = run_tiles(nx, ny, nml, library_exchange=True, grid=grid, isplit=WIDE_ISPLIT, case=case)
-    compare_with_single_tile(lib, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=50)
+    compare_with_single_tile(lib, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=20)
     side = {}
     wide = run_tiles(nx, ny, nml, library_exchange=True, wide=True, grid=grid, isplit=WIDE_ISPLIT, case=case, side_rounds=side)
-    compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=5)
-    assert set(side.values()) == {side_rounds(STEPS)}, side
+    compare_with_single_tile(wide, nml, grid=grid, isplit=WIDE_ISPLIT, case=case, min_rounds=2)
+    assert set(side.values()) == {side_rounds(STEPS, nml)}, side
     tiles = [wide[r][0] for r in sorted(wide)]
     if ny == 4:
         assert {t.jm for t in tiles if t.py == 3} == {tiles[0].jm_local - 3} and all(t.jm == t.jm_local for t in tiles if t.py < 3)
@@ -348,7 +351,7 @@ def test_side_stream_rounds_are_a_collective_decision():
     """Rounds on the library's second stream (the early part of the wide exchange, wr) run on all ranks or on none: one rank of
     2x2 that reports it cannot serve them (a failed ncclCommSplit / hipStreamCreate in production) keeps EVERY rank on the
     main stream -- no rank posts a round its neighbours do not expect --, the results stay bit-identical, and the step
-    has one round less per step (the wide exchange in one piece).  With every rank able, six of a full step's ten rounds run on the
+    has one round less per step (the wide exchange in one piece).  With every rank able, nine of a full step's ten rounds run on the
     second stream (side_rounds above)."""
     counts = {}
     for fail in (None, 2):
@@ -358,8 +361,8 @@ def test_side_stream_rounds_are_a_collective_decision():
         counts[fail] = ({r: v[2] for r, v in out.items()}, side)
     (main_all, side_all), (main_one, side_one) = counts[None], counts[2]
     assert set(side_one.values()) == {0}, side_one                     # nobody went to the second stream
-    assert set(side_all.values()) == {side_rounds(STEPS)}, side_all    # early gather, R1, R2, wr every step, R7 + R8 from the second step on: every rank
-    for r in main_all:       # per full step: 4 rounds between kernels + 6 beside them, or 9 between kernels (the gather one round instead of early + late)
+    assert set(side_all.values()) == {side_rounds(STEPS)}, side_all    # early gather, R1, R2, wr every step, Rw, Rq, Rts, R7, R8 from the second step on: every rank
+    for r in main_all:       # per full step: 1 round between kernels + 9 beside them, or 9 between kernels (the gather one round instead of early + late)
         assert main_one[r] == main_all[r] + main_rounds_saved(STEPS), (main_one, main_all, side_all)
 
 
@@ -376,13 +379,13 @@ def test_ranks_with_different_switch_sets_are_refused_together():
     side = {}
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, rank_switches={1: {"PROFQ_ROWS2": "1", "NO_LIN": "1"}},
                     side_rounds=side)
-    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=5, ghosts=False)
+    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=2, ghosts=False)
     assert set(side.values()) == {side_rounds(STEPS)}, side
     # the same switch on EVERY rank is an agreement, not a difference: all of them keep their rounds on the main stream
     side = {}
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT,
                     rank_switches={r: {"NO_SIDE_COMM": "1"} for r in range(4)}, side_rounds=side)
-    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=5, ghosts=False)
+    compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=2, ghosts=False)
     assert set(side.values()) == {0}, side
 
 
@@ -392,7 +395,7 @@ def test_wide_halo_too_narrow_shows_up(monkeypatch):
     monkeypatch.setenv("POMGPU_WIDE_W", str(WIDE_ISPLIT - 2))
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT)
     with pytest.raises(AssertionError):
-        compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=5)
+        compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=2)
 
 
 @pytest.mark.parametrize("nx,ny,case,nml", [(3, 2, "seamount", {}), (2, 2, "island", dict(npg=2))])
@@ -421,7 +424,7 @@ def test_wide_halo_mode_under_the_reference_call_sequence():
     check_velocity one by one (advance.f:6-59): the wide-halo mode starts in mode_interaction and ends with the last
     mode_external, same results, same few message rounds"""
     out = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, by_routine=True)
-    rounds = compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=5)
+    rounds = compare_with_single_tile(out, {}, grid=WIDE_GRID, isplit=WIDE_ISPLIT, min_rounds=2)
     assert rounds[0] < 12 * STEPS, rounds
 
 

@@ -78,8 +78,8 @@ def worker(rank, world, port, out, name, mode):
         for f in GOLD["fields"]:
             if digest(st.field(f)[..., :tile.jm, :tile.im]) != want[f]:
                 bad.append((step, f))
-    if mode == "wide":      # on the library's second stream: four rounds per internal step and two more from the second step on (pomgpu_api.hip, "rim rounds")
-        assert g.exchange_rounds_side() == 6 * done - 2, (g.exchange_rounds_side(), done)
+    if mode == "wide":      # on the library's second stream: four rounds per internal step and five more from the second step on (pomgpu_api.hip, "rim rounds")
+        assert g.exchange_rounds_side() == 9 * done - 5, (g.exchange_rounds_side(), done)
     with open(os.path.join(out, f"rank{rank}.json"), "w") as fh:
         json.dump(bad, fh)
     dist.barrier()
