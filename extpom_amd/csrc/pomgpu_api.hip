@@ -1898,7 +1898,9 @@ static int advance(pomgpu_ctx *c, int more_steps_follow) {    // advance.f:6-59
   // the vertical integrals of advx, advy, drhox, drhoy come out of advct / baropg themselves: on one tile, and on
   // tiles with the wide-halo external mode (there only the owned cells of adx2d ... are used)
   const bool tiles_fused = c->wide.on && c->tp.on && !SW(c, ADVCT_SPLIT);
-  const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2));
+  // (POMGPU_SUM2D_OFF: k_vint forms the integrals from the stored arrays as the reference does, advance.f:152-168 -- the same bits in fp64; in the
+  // fp32-storage study variant it is what makes one tile and several tiles round alike, tests/gpu_tiles_threads.py)
+  const int sum2d = ((!c->exch || tiles_fused) && c->P.mode != 2 && (c->P.npg == 1 || c->P.npg == 2)) && !SW(c, SUM2D_OFF);
   const int ph_step = prof_phase_open(c);                     // "phase_step": this whole step on the kernels' stream
   if ((rc = wide_early_start(c))) return rc;                  // most of the wide exchange, beside lateral_viscosity
   // rho's round trip is left to k_profq when this step will rewrite rho (mode 3: dens at the end of mode_internal)

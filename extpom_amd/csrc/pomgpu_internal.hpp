@@ -445,7 +445,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN) X(RIM_MAIN) X(RIM_RESULTS_MAIN)
+  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN) X(RIM_MAIN) X(RIM_RESULTS_MAIN) X(SUM2D_OFF)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
@@ -476,7 +476,7 @@ static inline void pomgpu_switches_read(pomgpu_switches &s) {
 // rounds exist and on which stream / communicator they run): the ranks compare it before any collective depends on it
 static inline unsigned pomgpu_switches_collective_digest(const pomgpu_switches &s) {
   static const int coll[] = {SW_ADVCT_SPLIT, SW_ADVQ_EXCHANGE, SW_PROD_FULL, SW_QFILTER_SPLIT, SW_UV_FULL_EXCHANGE, SW_NO_OVERLAP,
-                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT, SW_WR_NODEFER, SW_RIM_MAIN, SW_ADVT2_SINGLE, SW_RIM_RESULTS_MAIN};
+                             SW_NO_SIDE_COMM, SW_WR_MAIN, SW_WIDE_W, SW_WIDE_FULL, SW_EXT_SPLIT, SW_ADVAVE_SEPARATE, SW_EDGE_SPLIT, SW_WR_NODEFER, SW_RIM_MAIN, SW_ADVT2_SINGLE, SW_RIM_RESULTS_MAIN, SW_SUM2D_OFF};
   unsigned h = 2166136261u;
   for (size_t n = 0; n < sizeof coll / sizeof coll[0]; n++) {
     h = (h ^ (unsigned)(s.on[coll[n]] ? 1 + coll[n] : 0)) * 16777619u;

@@ -361,7 +361,7 @@ int pomgpu_tp_rccl(pomgpu_ctx *c, const void *id128, int rank, int nranks, const
   if (v[2] != -v[3])                                          // every rank sees the same two minima: all of them refuse together
     return give_up("the ranks were started with different POMGPU_* switch sets",
                    "ADVCT_SPLIT ADVQ_EXCHANGE PROD_FULL QFILTER_SPLIT UV_FULL_EXCHANGE NO_OVERLAP NO_SIDE_COMM WR_MAIN WIDE_W WIDE_FULL EXT_SPLIT "
-                   "ADVAVE_SEPARATE EDGE_SPLIT WR_NODEFER RIM_MAIN RIM_RESULTS_MAIN ADVT2_SINGLE choose which message rounds exist: give every rank the same environment");
+                   "ADVAVE_SEPARATE EDGE_SPLIT WR_NODEFER RIM_MAIN RIM_RESULTS_MAIN ADVT2_SINGLE SUM2D_OFF choose which message rounds exist: give every rank the same environment");
   int agreed[2] = {v[0], v[1]};
   if (agreed[0]) {
     // the side stream's communicator: the same ranks, split off the first -- collective, entered by ALL ranks or by none

@@ -279,22 +279,25 @@ class StagedMover:
     def __call__(self, send, scount, recv, rcount):
         from .lib import OPP  # noqa: F401
         w = lambda p, n: torch.as_tensor(_DevPtr(p, (n,)), device=self.device)
-        torch.cuda.current_stream().synchronize()
-        ops, staged = [], []
-        for d in range(8):
-            if self.nb[d] >= 0 and scount[d]:
-                ops.append(dist.P2POp(dist.isend, w(send[d], scount[d]).cpu(), self.nb[d], group=self.group, tag=d))
-        for d in range(8):
-            if self.nb[d] >= 0 and rcount[d]:
-                host = torch.empty(rcount[d], dtype=torch.float64)
-                staged.append((host, w(recv[d], rcount[d])))
-                ops.append(dist.P2POp(dist.irecv, host, self.nb[d], group=self.group, tag=OPP[d]))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for host, dev in staged:
-            dev.copy_(host)
-        torch.cuda.current_stream().synchronize()
+        # the stream of THIS round (pomgpu_current_stream: the kernels' stream, or the library's second one, beside which the kernels' stream keeps running)
+        cs = torch.cuda.ExternalStream(self.g.current_stream(), device=self.device)
+        with torch.cuda.stream(cs):
+            cs.synchronize()
+            ops, staged = [], []
+            for d in range(8):
+                if self.nb[d] >= 0 and scount[d]:
+                    ops.append(dist.P2POp(dist.isend, w(send[d], scount[d]).cpu(), self.nb[d], group=self.group, tag=d))
+            for d in range(8):
+                if self.nb[d] >= 0 and rcount[d]:
+                    host = torch.empty(rcount[d], dtype=torch.float64)
+                    staged.append((host, w(recv[d], rcount[d])))
+                    ops.append(dist.P2POp(dist.irecv, host, self.nb[d], group=self.group, tag=OPP[d]))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for host, dev in staged:
+                dev.copy_(host)
+            cs.synchronize()
 
 
 def dist_allmin(group=None):
