@@ -73,13 +73,16 @@ def main():
     splits = [tuple(int(v) for v in sp.split("x")) if "x" in sp else (1, int(sp)) for sp in (sys.argv[2] if len(sys.argv) > 2 else "4").split(",")]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     libpath = _lib.LIBPATH_F32 if "f32" in sys.argv[4:] else None
-    # "sum2d_off": every context is created under POMGPU_SUM2D_OFF (the vertical integrals of advance.f:152-168 formed from the STORED arrays by
-    # k_vint instead of from the registers of advct / baropg).  In fp64 that changes nothing.  In the fp32-storage variant it removes the one place
-    # where tiles and the single tile round differently (on tiles two lines of adx2d, ady2d are re-summed from stored, i.e. fp32-rounded, values
-    # after the neighbour's edge lines have arrived, k_advct_fix2d) -- with it the variant is decomposition-invariant bit for bit, which is asserted
-    exact = libpath is None or "sum2d_off" in sys.argv[4:]
-    if "sum2d_off" in sys.argv[4:]:
+    # "stored_only": every context is created under POMGPU_SUM2D_OFF (the vertical integrals of advance.f:152-168 formed from the STORED arrays by
+    # k_vint instead of from the registers of advct / baropg) and POMGPU_QFILTER_SPLIT (the Asselin filter of q2, q2l as a kernel of its own that
+    # reads the stored q2f, instead of inside k_profq's walk up, which holds it in fp64).  In fp64 neither changes a bit.  In the fp32-storage
+    # variant they remove the places where tiles and the single tile round differently -- a tile's first and last owned rows are filtered by the
+    # edge-line kernel (stored values) where the single tile's fused kernel has the unrounded ones, and two lines of adx2d, ady2d are re-summed
+    # from stored values after the neighbour's edge lines have arrived -- and with them the variant is decomposition-invariant bit for bit
+    exact = libpath is None or "stored_only" in sys.argv[4:]
+    if "stored_only" in sys.argv[4:]:
         os.environ["POMGPU_SUM2D_OFF"] = "1"
+        os.environ["POMGPU_QFILTER_SPLIT"] = "1"
     im, jm, kb = (int(v) for v in grid.split("x"))
     nml = dict(dte=6.0, isplit=30, mode=3, nadv=2, nitera=1, npg=1)
     dev = torch.device("cuda", 0)
@@ -165,6 +168,9 @@ def run_split(a, grid, im, jm, kb, nml, nx, ny, steps, libpath, dev, exact):
                 if exact:
                     if not np.array_equal(ref.view(np.int64), got.view(np.int64)):     # the bits, the sign of a zero included
                         bad.append((r, n, float(np.abs(ref - got).max())))
+                        if os.environ.get("POM_TILES_VERBOSE"):                         # developer: where (local indices of the compared block) and how many
+                            d = np.argwhere(ref.view(np.int64) != got.view(np.int64))
+                            print(f"  tile {r} {n}: {len(d)} cells differ, index ranges {d.min(axis=0).tolist()} .. {d.max(axis=0).tolist()}, first {d[0].tolist()}", flush=True)
                 else:
                     # the fp32-storage study variant is NOT decomposition-invariant bit for bit: a fused kernel integrates the values it has
                     # in registers (fp64) where the tile path's edge-line kernels re-read them from memory (rounded to fp32) -- storage

@@ -702,9 +702,10 @@ def test_fp32_storage_variant_on_tiles():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiles_threads.py"), "256x192x50", "4", "6", "f32"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "TILES-THREADS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    # the cause, asserted: with the vertical integrals formed from the stored arrays on both sides (POMGPU_SUM2D_OFF) one tile and four tiles of
-    # the fp32-storage variant carry the SAME bits on every owned cell of every array
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiles_threads.py"), "256x192x50", "4", "6", "f32", "sum2d_off"], capture_output=True,
+    # the cause, asserted: with the q2 / q2l filter and the vertical integrals working from the STORED arrays on both sides (POMGPU_QFILTER_SPLIT,
+    # POMGPU_SUM2D_OFF: the places where a tile's edge-line kernels re-read fp32-rounded values that the single tile's fused kernels hold
+    # unrounded) one tile and four tiles of the fp32-storage variant carry the SAME bits on every owned cell of every array
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_tiles_threads.py"), "256x192x50", "4", "6", "f32", "stored_only"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "TILES-THREADS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -169,7 +169,8 @@ def test_bench_multi_gpu_passes_survive_a_hang_and_a_dead_rank():
     pass whose rank hangs (here: rank 1 of the overlapped pass never posts) is ended at its limit and named, a pass whose rank
     dies (rank 2 of the alternate-grid pass) ends at once on every rank -- and the line still carries the passes that completed,
     ONE line, with the tile grids BASELINE names (2x4 beside 1x8 would be --gpus 8: four ranks here)."""
-    r, lines = _bench_selftest({"hang": [1, 1], "fail": [2, 2]}, 4, ["--workload", "basin2048"], limit="6")
+    # (limit: a healthy stand-in pass is four python processes importing torch and meeting on gloo -- 2-3 s on an idle box, more on a busy one)
+    r, lines = _bench_selftest({"hang": [1, 1], "fail": [2, 2]}, 4, ["--workload", "basin2048"], limit="15")
     assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
     out = lines[0]
     ps = out["passes"]
@@ -177,7 +178,7 @@ def test_bench_multi_gpu_passes_survive_a_hang_and_a_dead_rank():
     assert out["config"]["tiles"] == "1x4" and out["config"]["tiles_primary"] == "1x4" and ps[0]["primary"]
     assert out["config"]["no_overlap_env"] == "1"                       # pass 0 ran with POMGPU_NO_OVERLAP=1
     assert "no result within" in ps[1]["failed"]["first"] and set(ps[1]["failed"]["phase_by_rank"].values()) == {"connect"}
-    assert ps[2]["failed"]["why_by_rank"]["2"] == "exit code 9" and ps[2]["wall_s"] < 6.0      # the dead rank ended the pass at once, not at the limit
+    assert ps[2]["failed"]["why_by_rank"]["2"] == "exit code 9" and ps[2]["wall_s"] < 12.0     # the dead rank ended the pass at once, not at the limit (15 s)
     # everything healthy: the faster pass (overlap on, in the stand-in's numbers) is the line's value, the alternate grid under it
     r, lines = _bench_selftest({}, 2, ["--workload", "basin1024", "--tiles", "2x1"])
     assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
