@@ -541,7 +541,10 @@ struct LevB { double e1, g1, e2, g2, qb, qlb, q, ql; };
 #define PROFQ_BIG 8                                         /* rows per workgroup on large grids */
 #endif
 template <int FP, int FF, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
+// jfirst, jlast: the rows this launch covers (1..jm: everything).  On tiles whose ghost lines are filled by a message round behind this
+// kernel (pomgpu_api.hip, rim round Rq) the ghost rows are left out: a 2048x194 tile is 25 row blocks x 32 = 800 workgroups for the 768 that
+// are resident at once -- a fourth, nearly empty round -- and 24 x 32 = 768 without its two ghost rows
+__global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace, int jfirst, int jlast) {
 #ifndef POMGPU_EMU
   // 8-row workgroups (one per CU): 19 levels = 152 KB.  NOT 20 = the whole 160 KB: a library that merely CONTAINS a kernel with
   // 163840 bytes of LDS made processes that share one GPU (tests, rehearsals: bench.py --gpus 4 on one card) run one after the
@@ -552,7 +555,8 @@ __global__ void __launch_bounds__(64 * ROWS) k_profq(KP P, int rho_rt_pace) {
   // it wrote itself: no barrier): 2 x 20 x 8 bytes per column is all that 160 KB per CU could hold at 512 columns per CU
   __shared__ double evec[2 * KL][ROWS][64];
 #endif
-  COL2
+  const int i = TID_I, j = TID_J + jfirst - 1;
+  if (i > P.iml || j > P.jml || j > jlast) return;
   const int rho_rt = rho_rt_pace & 1, pace = rho_rt_pace & 2;
   const int ty = (int)threadIdx.y, tx = (int)threadIdx.x;
   if (i > P.im || j > P.jm) return;
@@ -1658,7 +1662,9 @@ void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt) {
   const int len = P.im > P.jm ? P.im : P.jm;
   LAUNCH(c, k_profq_prod_lines, dim3((len + 63) / 64, 8, P.kb), dim3(64, 1, 1), c->P, rho_rt);
 }
-void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt, int jfirst, int jlast) {
+  if (jlast < jfirst) { jfirst = 1; jlast = c->P.jml; }      // (default arguments 0, -1: every row)
+  const int nrows = jlast - jfirst + 1;
   // 8 paced rows per workgroup (one workgroup per CU at 2 waves per SIMD) where that still leaves every CU three workgroups
   // (a 514x769 tile of an 8-tile split: 3.4 per CU, k_profq 1.27 -> 1.22 ms, the tile's step 7.15 -> 6.9)
   // (developer switches: POMGPU_PROFQ_ROWS8 / _ROWS2 force a shape, POMGPU_PROFQ_NOPACE drops the barrier)
@@ -1666,8 +1672,8 @@ void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt) {
   rho_rt = (rho_rt ? 1 : 0) | (SW(c, PROFQ_NOPACE) ? 0 : 2);
 #define PQ(FP, FF)                                                                                                                       \
   do {                                                                                                                                   \
-    if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, PROFQ_BIG>), dim3((c->P.iml + 63) / 64, (c->P.jml + PROFQ_BIG - 1) / PROFQ_BIG, 1), dim3(64, PROFQ_BIG, 1), c->P, rho_rt); \
-    else LAUNCHN(c, "k_profq", (k_profq<FP, FF, 2>), dim3((c->P.iml + 63) / 64, (c->P.jml + 1) / 2, 1), dim3(64, 2, 1), c->P, rho_rt);       \
+    if (rows8) LAUNCHN(c, "k_profq", (k_profq<FP, FF, PROFQ_BIG>), dim3((c->P.iml + 63) / 64, (nrows + PROFQ_BIG - 1) / PROFQ_BIG, 1), dim3(64, PROFQ_BIG, 1), c->P, rho_rt, jfirst, jlast); \
+    else LAUNCHN(c, "k_profq", (k_profq<FP, FF, 2>), dim3((c->P.iml + 63) / 64, (nrows + 1) / 2, 1), dim3(64, 2, 1), c->P, rho_rt, jfirst, jlast);       \
   } while (0)
   if (fuse_filter) { if (fuse_prod == 0) PQ(0, 1); else if (fuse_prod == 1) PQ(1, 1); else PQ(2, 1); }
   else { if (fuse_prod == 0) PQ(0, 0); else if (fuse_prod == 1) PQ(1, 0); else PQ(2, 0); }

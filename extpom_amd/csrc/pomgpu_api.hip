@@ -1622,7 +1622,9 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
     const int qfuse = !SW(c, QFILTER_SPLIT);
     if (rimr) {
       launch_profq_bc(c);
-      launch_profq(c, 1, qfuse, c->rho_rt_pending);           // the production term as on one tile; ghost lines: stale operands, overwritten by Rq
+      // the production term as on one tile.  Ghost ROWS are left out (Rq fills them: 24 instead of 25 row blocks on a 2048x194 tile, three
+      // full rounds of workgroups instead of three and a nearly empty fourth); ghost COLUMNS are computed from stale operands and overwritten.
+      launch_profq(c, 1, qfuse, c->rho_rt_pending, P.S ? 1 : 2, P.N ? P.jm : P.jmm1);
     } else {
       seq_profq(c, qfuse, lib_x);                             // with the interior's Asselin filter (:416-421) on its way up
       xch(c, 2, LEV3(c, D3(c, uf), 1), P.kbm2, LEV3(c, D3(c, vf), 1), P.kbm2);   // :411-412

@@ -745,7 +745,7 @@ void launch_int_uvmean(pomgpu_ctx *c);
 void launch_vertvl(pomgpu_ctx *c, int mask);
 void launch_profq_bc(pomgpu_ctx *c);
 void launch_profq_prod(pomgpu_ctx *c, int lines_only, int rho_rt = 0);
-void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt = 0);
+void launch_profq(pomgpu_ctx *c, int fuse_prod, int fuse_filter, int rho_rt = 0, int jfirst = 0, int jlast = -1);   // rows jfirst..jlast (default: all)
 void launch_proft(pomgpu_ctx *c, double *f, const double *wfsurf, const double *fsurf, int nbc);
 int launch_proft2(pomgpu_ctx *c, double *f0, const double *wfsurf0, const double *fsurf0, int nbc0, double *f1, const double *wfsurf1, const double *fsurf1, int nbc1);
 void launch_advu_profu(pomgpu_ctx *c, int do_adv, int do_prof);
