@@ -10,7 +10,13 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lines = [json.load(open(p)) for p in sys.argv[1:]]
+args = sys.argv[1:]
+tuned = None                                         # --tuned-ms X: ms per step of bench.py's N = 1 line (placement tuned) of the same round, to be read beside
+if "--tuned-ms" in args:
+    k = args.index("--tuned-ms")
+    tuned = float(args[k + 1])
+    args = args[:k] + args[k + 2:]
+lines = [json.load(open(p)) for p in args]
 out = {}
 for wl in sorted({l["workload_key"] for l in lines}):
     mine = [l for l in lines if l["workload_key"] == wl]
@@ -20,6 +26,9 @@ for wl in sorted({l["workload_key"] for l in lines}):
            "stand-in mover (device copies on the round's stream, no link latency): tools/tile_probe.py", "tiles": {}}
     if one:
         rec["single_gpu_ms_per_step"] = one[0]["ms_per_step_wall"]
+        rec["single_gpu_note"] = "the single tile through the same tool in the same job, its 3-D arrays where the allocator put them (like the tiles)"
+    if tuned:
+        rec["bench_n1_tuned_ms_per_step"] = tuned
     for l in sorted(mine, key=ntiles):
         n = ntiles(l)
         if n == 1:
@@ -28,6 +37,8 @@ for wl in sorted({l["workload_key"] for l in lines}):
              "message_rounds_on_second_stream": l["message_rounds_on_side_stream_per_step"]}
         if one:
             e["efficiency_bound"] = round(one[0]["ms_per_step_wall"] / (n * l["ms_per_step_wall"]), 3)
+        if tuned:
+            e["efficiency_bound_against_tuned_n1"] = round(tuned / (n * l["ms_per_step_wall"]), 3)
         rec["tiles"][str(n)] = e
     out[wl] = rec
 with open(os.path.join(ROOT, "profiles", "tile_probe_bounds.json"), "w") as f:

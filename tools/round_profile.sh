@@ -3,7 +3,7 @@
 # (separate --pmc passes, never mixed with trace domains other than --kernel-trace).  Two parts, one gpurun call each:
 #   tools/round_profile.sh r4 A   the bench lines, kernel stats, counters, traffic.json of THIS build and the line that quotes it
 #   tools/round_profile.sh r4 B   one tile of the 2 / 4 / 8-tile split, the multi-rank rehearsals on one GPU, the fp32-storage study lines
-TAG=${1:-r4}
+TAG=${1:-r5}
 PART=${2:-A}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
@@ -23,9 +23,15 @@ if [ $PART = A ]; then
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
   find $O -name "*kernel_stats.csv" | head -3
 else
-  for n in 8 4 2; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) --tune > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  # one tile of the N-tile split (and the single tile through the same tool, for the bounds of profiles/tile_probe_bounds.json: tools/make_tile_bounds.py)
+  for n in 1 2 4 8; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) --steps 10 > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 0 --steps 10 > $O/tile_probe_8tiles_first_tile.json 2> $O/tile_8_0.err
+  # a MODEL of link latency: every message round holds its stream for 30 us; nine rounds hidden against six (POMGPU_RIM_RESULTS_MAIN) and two (POMGPU_RIM_MAIN)
+  timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_RESULTS_MAIN=1 > $O/tile_probe_8tiles_round30us_results_rounds.json 2> $O/tile_8_m1.err
+  timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_MAIN=1 > $O/tile_probe_8tiles_round30us_rim_rounds.json 2> $O/tile_8_m2.err
   POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_2ranks_one_gpu_basin1024.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
   POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin1024.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
+  POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin2048 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin2048.json 2> $O/rehearse4b.err; echo "rehearse4 basin2048 rc=$?"
   timeout -k 10 300 python bench.py --storage f32 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_f32_storage_study.json 2> $O/f32.err; echo "f32 rc=$?"
   POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --storage f32 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline --no-alternate > $O/rehearsal_2ranks_one_gpu_basin1024_f32_storage.json 2> $O/rehearse2f32.err; echo "rehearse2 f32 rc=$?"
 fi
