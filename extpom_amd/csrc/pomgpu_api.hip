@@ -1719,20 +1719,20 @@ static int mode_internal(pomgpu_ctx *c, int defer_wr) {       // advance.f:356-5
       c->r8_pending = 1;
       if (rcs) return rcs;
     } else {
-    if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
-    else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);     // :466-467
-    launch_uv_filter(c);                                      // :469-514
-    if (lib_x && !SW(c, UV_FULL_EXCHANGE)) {
-      // :516-521 exchange all kb levels of ub, u, uf, vb, v, vf.  For u, uf, v, vf the levels 1..kbm1 are redundant: uf, vf
-      // were exchanged at :466-467 and not written since, and u = uf, v = vf are copies.  What is not valid in a ghost
-      // column is their level kb (profu / profv write it on owned columns only).  ub, vb are needed in full: the filter
-      // (:469-509) runs on ghost columns too, but from a u whose western / southern ghost cells missed the depth-mean
-      // correction (:365-393 starts at i = 2, j = 2 and is not followed by an exchange).  2 x kb + 4 planes instead of 6 x kb.
-      const int top = P.kb - 1;
-      xch(c, 6, D3(c, ub), P.kb, D3(c, vb), P.kb, LEV3(c, D3(c, u), top), 1, LEV3(c, D3(c, uf), top), 1, LEV3(c, D3(c, v), top), 1, LEV3(c, D3(c, vf), top), 1);
-    } else {
-      xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
-    }
+      if (lib_x) xch(c, 4, D2(c, wubot), 1, D2(c, wvbot), 1, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // solver.f:1777,1874 + :466-467
+      else xch(c, 2, D3(c, uf), P.kbm1, D3(c, vf), P.kbm1);   // :466-467
+      launch_uv_filter(c);                                    // :469-514
+      if (lib_x && !SW(c, UV_FULL_EXCHANGE)) {
+        // :516-521 exchange all kb levels of ub, u, uf, vb, v, vf.  For u, uf, v, vf the levels 1..kbm1 are redundant: uf, vf
+        // were exchanged at :466-467 and not written since, and u = uf, v = vf are copies.  What is not valid in a ghost
+        // column is their level kb (profu / profv write it on owned columns only).  ub, vb are needed in full: the filter
+        // (:469-509) runs on ghost columns too, but from a u whose western / southern ghost cells missed the depth-mean
+        // correction (:365-393 starts at i = 2, j = 2 and is not followed by an exchange).  2 x kb + 4 planes instead of 6 x kb.
+        const int top = P.kb - 1;
+        xch(c, 6, D3(c, ub), P.kb, D3(c, vb), P.kb, LEV3(c, D3(c, u), top), 1, LEV3(c, D3(c, uf), top), 1, LEV3(c, D3(c, v), top), 1, LEV3(c, D3(c, vf), top), 1);
+      } else {
+        xch(c, 6, D3(c, ub), P.kb, D3(c, u), P.kb, D3(c, uf), P.kb, D3(c, vb), P.kb, D3(c, v), P.kb, D3(c, vf), P.kb);   // :516-521
+      }
     }
   }
   launch_int_tail(c);                                         // :525-531, and the derived coefficients of the new dt (k_coef_dt's) in the same pass

@@ -847,3 +847,27 @@ def test_tune_placement_moves_the_arrays_and_keeps_the_bits(monkeypatch):
     assert not bad, bad
     assert a.iint == b.iint
     g.close()
+
+
+@pytest.mark.gpu
+def test_tune_placement_refuses_once_a_3d_address_has_been_handed_out(monkeypatch):
+    """pomgpu_tune_placement moves blk3d and frees the allocations it lived in: an address obtained from pomgpu_device_3d before would
+    dangle (a host's device pointer, a torch tensor wrapped around it, an exchange hook's cache).  The call therefore refuses from
+    the first pomgpu_device_3d on (include/pomgpu.h), the state is untouched, and the context goes on stepping with the oracle's bits."""
+    from extpom_amd.lib import PomGpuError
+    OracleTile, oracle_finish_initial = _oracle()
+    monkeypatch.setenv("POMGPU_TUNE_FORCE", "1")
+    a = make_case("seamount", 65, 49, 21, dte=6.0, isplit=30)
+    oracle_finish_initial(a)
+    b = a.copy()
+    oa, g = OracleTile(a), _gpu(b)
+    g.run(2)
+    assert g.device_ptr("aam") != 0
+    with pytest.raises(PomGpuError, match="pomgpu_device_3d"):
+        g.tune_placement(1, 2)
+    g.run(2)                                          # (the refusal also raised error_status, the reference's convention; the arrays are what they were)
+    g.download()
+    oa.run(4)
+    assert int(b.error_status) == 1 and not diff(a, b), diff(a, b)
+    g.close()
+
