@@ -473,10 +473,14 @@ __global__ void k_advct_fix(KP P, const double *from_w, const double *from_s) {
 // sum2d: also leave the vertical integrals adx2d, ady2d of advance.f:152-168 (k_vint) -- the column is here anyway
 // Operands of a level, all five shared through the workgroup's LDS slab (rows j-1, j, j+1): u, v, ub, vb, aam.
 // Loop discipline and row sharing as in k_advt2_col.
-struct LevCa { double c[5], h[ROWSHARE_SLOTS(5)]; };
-__global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
-  constexpr int NS = 5, NH = ROWSHARE_SLOTS(NS), U = 0, V = 1, UB = 2, VB = 3, AM = 4;
-  HALO_XCD_DECODE_R(LDS_ROWS)                                           // i0: 1-based column of this lane (0 for the very first halo lane)
+// ROWS rows per workgroup: 8 (LDS_ROWS) on large grids; 4 on low tiles, where a launch is only three or four rounds of workgroups and two
+// workgroups per compute unit leave the last round fuller (launch_advct_col)
+template <int ROWS> struct LevCaT { double c[5], h[(2 * 5 + ROWS - 1) / ROWS]; };
+template <int ROWS>
+__global__ void __launch_bounds__(64 * ROWS) k_advct_col(KP P, int sum2d) {
+  constexpr int NS = 5, NH = (2 * NS + ROWS - 1) / ROWS, U = 0, V = 1, UB = 2, VB = 3, AM = 4;
+  typedef LevCaT<ROWS> LevCa;
+  HALO_XCD_DECODE_R(ROWS)                                               // i0: 1-based column of this lane (0 for the very first halo lane)
 #ifdef POMGPU_WGTIME                                        // developer build (tools/wg_times.py): when does each workgroup run, and where?
   const unsigned long long wgt0 = wall_clock64();
 #endif
@@ -518,13 +522,13 @@ __global__ void __launch_bounds__(64 * LDS_ROWS) k_advct_col(KP P, int sum2d) {
 #pragma unroll
   for (int x = 0; x < NS; x++) bs[x] = BUF3(ps[x]);
   const BufA bax = BUF3(A3(advx)), bay = BUF3(A3(advy));
-  const RowShare<NS> S = rowshare_setup<NS>(P, r, j, j0w, i);
+  const RowShare<NS, ROWS> S = rowshare_setup<NS, ROWS>(P, r, j, j0w, i);
 #pragma unroll
   for (int q = 0; q < NH; q++) bh[q] = BUF3(rowshare_pick<NS>(ps, S.hop[q]));
   const unsigned oc = BOFF2(i, jc), lvb = LVB;
   const unsigned ost = (out && jrow) ? oc : BOFF_NONE;      // rim rows are zeroed after the loop
 #ifndef POMGPU_EMU
-  __shared__ double slab[2][NS][ROWSHARE_ROWS][64];
+  __shared__ double slab[2][NS][ROWS + 3][64];
 #else
   const unsigned os = BOFF2(i, js), on = BOFF2(i, jn);
 #endif
@@ -802,7 +806,10 @@ void launch_advq2_col(pomgpu_ctx *c, const double *q, const double *qb, double *
   LAUNCHN(c, "k_advq2_col", (k_advq_col<2>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, A, zero_else);
 }
 void launch_advct_col(pomgpu_ctx *c, int sum2d) {
-  LAUNCH(c, k_advct_col, grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, sum2d);
+  // low tiles (a tile of an 8- or 4-tile split of 2048x1536): 4-row workgroups, two per compute unit
+  const bool rows4 = SW(c, ADVCT_ROWS4) || (!SW(c, ADVCT_ROWS8) && c->P.jml <= 400 && c->exch);
+  if (rows4) LAUNCHN(c, "k_advct_col", (k_advct_col<4>), grid1_halo_r(c->P, 4), blk_col_r(4), c->P, sum2d);
+  else LAUNCHN(c, "k_advct_col", (k_advct_col<LDS_ROWS>), grid1_halo_r(c->P, LDS_ROWS), blk_col_r(LDS_ROWS), c->P, sum2d);
 }
 // with sum2d the column kernel has left adx2d, ady2d (advance.f:152-168) from its own advx(2,:), advy(:,2): redo the
 // two lines from the corrected values, in the column kernel's order of summation

@@ -294,28 +294,30 @@ static inline void bst2(const BufA &b, unsigned voff, unsigned soff, double x) {
 #endif
 #define ROWSHARE_SLOTS(NS) ((2 * (NS) + LDS_ROWS - 1) / LDS_ROWS)
 #define ROWSHARE_ROWS (LDS_ROWS + 3)
-template <int NS> struct RowShare {
+// ROWS: the rows of the workgroup (LDS_ROWS everywhere but in k_advct_col's 4-row shape for low tiles)
+template <int NS, int ROWS = LDS_ROWS> struct RowShare {
+  static constexpr int SLOTS = (2 * NS + ROWS - 1) / ROWS;
   int r;                                   // this wavefront's row inside the workgroup (scalar)
   int ss, sn;                              // slab rows holding the southern / northern neighbour row of this wavefront's row
-  int hop[ROWSHARE_SLOTS(NS)];             // halo jobs of this wavefront: which shared operand ...
-  int hrow[ROWSHARE_SLOTS(NS)];            // ... into which slab row ...
-  unsigned hoff[ROWSHARE_SLOTS(NS)];       // ... from which cell (per-lane byte offset inside a level; BOFF_NONE = no job)
+  int hop[SLOTS];                          // halo jobs of this wavefront: which shared operand ...
+  int hrow[SLOTS];                         // ... into which slab row ...
+  unsigned hoff[SLOTS];                    // ... from which cell (per-lane byte offset inside a level; BOFF_NONE = no job)
 };
 // j: the wavefront's row (may lie beyond jml in the last workgroup: such rows shadow row jml and store nothing),
 // jc = min(j, jml), j0w: first row of the workgroup, i: the lane's (clamped) column
-template <int NS> __device__ __forceinline__ RowShare<NS> rowshare_setup(const KP &P, int r, int j, int j0w, int i) {
-  RowShare<NS> S;
+template <int NS, int ROWS = LDS_ROWS> __device__ __forceinline__ RowShare<NS, ROWS> rowshare_setup(const KP &P, int r, int j, int j0w, int i) {
+  RowShare<NS, ROWS> S;
   S.r = r;
   S.ss = (j > 1 && j <= P.jml) ? r : r + 1;
   S.sn = (j < P.jml) ? r + 2 : r + 1;
-  const int jsouth = j0w > 1 ? j0w - 1 : 1, jnorth = j0w + LDS_ROWS <= P.jml ? j0w + LDS_ROWS : P.jml;
+  const int jsouth = j0w > 1 ? j0w - 1 : 1, jnorth = j0w + ROWS <= P.jml ? j0w + ROWS : P.jml;
 #pragma unroll
-  for (int q = 0; q < ROWSHARE_SLOTS(NS); q++) {
-    const int job = q * LDS_ROWS + r;
+  for (int q = 0; q < RowShare<NS, ROWS>::SLOTS; q++) {
+    const int job = q * ROWS + r;
     const bool valid = job < 2 * NS;
     const int side = valid ? job / NS : 0;
     S.hop[q] = valid ? job % NS : 0;
-    S.hrow[q] = valid ? (side ? LDS_ROWS + 1 : 0) : LDS_ROWS + 2;
+    S.hrow[q] = valid ? (side ? ROWS + 1 : 0) : ROWS + 2;
     S.hoff[q] = valid ? BOFF2(i, side ? jnorth : jsouth) : BOFF_NONE;
   }
   return S;
@@ -445,7 +447,7 @@ static inline dim3 grid2_halo(const KP &P) { return dim3((P.iml + 61) / 62, (P.j
   X(NO_LIN) X(ADVQ_SINGLE) X(ADVT2_SINGLE) X(REALVERTVL_CELLS) X(RHO_ROUNDTRIP) X(TAU_ARRAYS) X(PROFQ_ROWS8) X(PROFQ_ROWS2)    \
   X(PROFQ_NOPACE) X(COL_STRIP) X(BAND_BYTES) X(PAD3) X(IO_SYNC) X(ADVCT_SPLIT) X(ADVQ_EXCHANGE) X(PROD_FULL) X(QFILTER_SPLIT) \
   X(UV_FULL_EXCHANGE) X(NO_OVERLAP) X(NO_SIDE_COMM) X(WR_MAIN) X(WIDE_W) X(WIDE_FULL) X(DEBUG_ALLOC) X(TEST_SPLIT_FAIL_RANK)  \
-  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN) X(RIM_MAIN) X(RIM_RESULTS_MAIN) X(SUM2D_OFF)
+  X(EDGE_SPLIT) X(WR_NODEFER) X(EXT_RING_FIRST) X(TUNE_FORCE) X(NO_TWIN) X(RIM_MAIN) X(RIM_RESULTS_MAIN) X(SUM2D_OFF) X(ADVCT_ROWS4) X(ADVCT_ROWS8)
 enum pomgpu_sw {
 #define POMGPU_SW_(name) SW_##name,
   POMGPU_SWITCHES(POMGPU_SW_)
