@@ -389,6 +389,28 @@ def test_ranks_with_different_switch_sets_are_refused_together():
     assert set(side.values()) == {0}, side
 
 
+@pytest.mark.parametrize("switch,per_full_step,first_step", [("RIM_RESULTS_MAIN", 6, 4), ("RIM_MAIN", 2, 2)])
+def test_rim_rounds_can_be_kept_on_the_kernels_stream(switch, per_full_step, first_step):
+    """POMGPU_RIM_RESULTS_MAIN keeps the reference's three input exchanges of profq / proft (between kernels) instead of the result rounds
+    Rw, Rq, Rts; POMGPU_RIM_MAIN keeps every rim round on the kernels' stream (the early part of the wide exchange and wr stay beside
+    them): the same bits on every cell, ghost cells included, as the default (nine rounds of ten on the second stream) -- where a
+    round runs and whether inputs or results travel changes nothing but the schedule.  Both switches belong to the collective digest."""
+    side_a, side_b = {}, {}
+    a = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, case="seamount", side_rounds=side_a)
+    b = run_tiles(2, 2, {}, library_exchange=True, wide=True, grid=WIDE_GRID, isplit=WIDE_ISPLIT, case="seamount", side_rounds=side_b,
+                  rank_switches={r: {switch: "1"} for r in range(4)})
+    assert set(side_a.values()) == {side_rounds(STEPS)} and set(side_b.values()) == {first_step + per_full_step * (STEPS - 1)}, (side_a, side_b)
+    bad = []
+    for r in a:
+        t = a[r][0]
+        for n in BLK2D + BLK3D:
+            if n not in SCRATCH and not np.array_equal(a[r][1].field(n)[..., :t.jm, :t.im], b[r][1].field(n)[..., :t.jm, :t.im]):
+                bad.append((r, n))
+    assert not bad, bad[:10]
+    for r in a:                                                        # the total number of rounds does not change
+        assert a[r][2] + side_a[r] == b[r][2] + side_b[r], (r, a[r][2], side_a[r], b[r][2], side_b[r])
+
+
 def test_wide_halo_too_narrow_shows_up(monkeypatch):
     """the stale rim of the extended tile grows by one cell per substep: with fewer than isplit - 1 extra cells it
     reaches owned cells and the comparison with the single-tile oracle must fail"""
