@@ -29,6 +29,9 @@ else
   # a MODEL of link latency: every message round holds its stream for 30 us; nine rounds hidden against six (POMGPU_RIM_RESULTS_MAIN) and two (POMGPU_RIM_MAIN)
   timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_RESULTS_MAIN=1 > $O/tile_probe_8tiles_round30us_results_rounds.json 2> $O/tile_8_m1.err
   timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_MAIN=1 > $O/tile_probe_8tiles_round30us_rim_rounds.json 2> $O/tile_8_m2.err
+  # the REAL transport on the one GPU: an RCCL communicator of one rank whose tile is its own neighbour -- grouped ncclSend / ncclRecv on both streams
+  # (RCCL prints a banner on stdout: the JSON line is the one that starts with a brace)
+  for sw in RIM_MAIN RIM_RESULTS_MAIN; do timeout -k 10 300 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --rccl-self --ab POMGPU_$sw=1 2> $O/tile_8_rccl_$sw.err | grep "^{" > $O/tile_probe_8tiles_rccl_self_$sw.json; done
   POM_BENCH_REHEARSE=1 timeout -k 10 500 python3 bench.py --gpus 2 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_2ranks_one_gpu_basin1024.json 2> $O/rehearse2.err; echo "rehearse2 rc=$?"
   POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin1024 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin1024.json 2> $O/rehearse4.err; echo "rehearse4 rc=$?"
   POM_BENCH_REHEARSE=1 timeout -k 10 600 python3 bench.py --gpus 4 --workload basin2048 --steps 3 --warmup 1 --no-cpu-baseline > $O/rehearsal_4ranks_one_gpu_basin2048.json 2> $O/rehearse4b.err; echo "rehearse4 basin2048 rc=$?"

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--ab", default="", help="NAME=V[,NAME=V...]: developer switches set on the LIVE context for every other block of steps -- "
                                              "the step with and without them, interleaved in one context (placement moves a kernel more than most changes do)")
     ap.add_argument("--ab-rounds", type=int, default=6)
+    ap.add_argument("--rccl-self", action="store_true", help="the REAL transport instead of the stand-in mover: an RCCL communicator of one rank whose tile is its own "
+                                                             "neighbour (periodic), so every round is a grouped ncclSend / ncclRecv on the kernels' or the second stream "
+                                                             "-- RCCL's own launch path and kernels, without a link")
     ap.add_argument("--round-us", type=float, default=0.0, help="a MODEL of what a message round costs between GPUs: every round holds its stream for this "
                                                                 "many microseconds (a spinning kernel) before its copies -- rounds between kernels then cost it on the step, "
                                                                 "rounds on the second stream only if nothing runs beside them")
@@ -40,6 +43,11 @@ def main():
     from extpom_amd.model import PomGpu
     case, im, jm, kb, desc = bench.WORKLOADS[a.workload]
     tile = pdist.tile_for_rank(a.rank, a.tiles, im, jm)
+    if a.rccl_self:                                     # every neighbour the tile has is the one rank itself
+        import dataclasses
+        me = lambda n: 0 if n >= 0 else -1
+        tile = dataclasses.replace(tile, rank=0, n_west=me(tile.n_west), n_east=me(tile.n_east), n_south=me(tile.n_south), n_north=me(tile.n_north),
+                                   n_sw=me(tile.n_sw), n_se=me(tile.n_se), n_nw=me(tile.n_nw), n_ne=me(tile.n_ne))
     st = bench.build_state(a.workload, tile)
     ts = torch.cuda.Stream()
     torch.cuda.set_stream(ts)
@@ -69,7 +77,12 @@ def main():
                     else:                               # one-way message without a matching buffer of the tile's own
                         w(recv[d], rcount[d]).zero_()
 
-    g.set_transport(tile, mover, agree=lambda mine: mine, stream_ordered=True)    # a stand-in for N identical ranks: this rank's answer is everybody's; the mover enqueues on the round's stream, nothing waits for the device (as with RCCL)
+    if a.rccl_self:
+        from extpom_amd.halo import rccl_library_path
+        lib = rccl_library_path()
+        g.rccl_init(tile, g.rccl_unique_id(lib), 0, 1, lib)
+    else:
+        g.set_transport(tile, mover, agree=lambda mine: mine, stream_ordered=True)    # a stand-in for N identical ranks: this rank's answer is everybody's; the mover enqueues on the round's stream, nothing waits for the device (as with RCCL)
     wide = False
     if not a.no_wide:
         tiles = [pdist.tile_for_rank(r, a.tiles, im, jm) for r in range(a.tiles)]
@@ -110,7 +123,7 @@ def main():
     print(json.dumps({"workload": desc, "workload_key": a.workload, "library_build_id": g.L.pomgpu_build_id().decode(), "tiles": f"{tile.nproc_x}x{tile.nproc_y}", "rank": a.rank, "tile": f"{tile.im}x{tile.jm}x{kb}",
                       "wide": bool(wide), "placement": tuned, "ab_ms_per_step_wall": ab, "ms_per_step_wall": round(dt * 1e3, 3), "message_rounds_per_step": rounds,
                       "kernel_ms_sum": round(sum(v[2] for v in share), 3), "stand_in_mover_ms": round(msg[1], 3),
-                      "message_rounds_on_side_stream_per_step": rounds_side, "modelled_round_latency_us": a.round_us, "stand_in_mover_side_ms": round(msg_side[1], 3),
+                      "message_rounds_on_side_stream_per_step": rounds_side, "modelled_round_latency_us": a.round_us, "transport": "RCCL, one rank that is its own neighbour" if a.rccl_self else "stand-in mover (device copies on the round's stream)", "stand_in_mover_side_ms": round(msg_side[1], 3),
                       "kernels": {k: [n, round(ms, 3)] for k, n, ms in share[:45]}}))
     g.close()
 
