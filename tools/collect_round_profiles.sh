@@ -5,7 +5,7 @@ TAG=${1:-r5}; N=${TAG#r}; O=gpurun_out/$TAG; P=profiles
 set -e
 for f in bench_basin2048 bench_basin2048_with_traffic bench_seamount256 bench_basin1024 bench_line_under_rocprofv3_kernel_trace bench_line_under_rocprofv3_kernel_trace_one_layout \
          bench_basin2048_f32_storage_study rehearsal_2ranks_one_gpu_basin1024 rehearsal_4ranks_one_gpu_basin1024 rehearsal_4ranks_one_gpu_basin2048 rehearsal_2ranks_one_gpu_basin1024_f32_storage \
-         tile_probe_1tiles tile_probe_2tiles tile_probe_4tiles tile_probe_8tiles tile_probe_8tiles_first_tile tile_probe_8tiles_round30us_results_rounds tile_probe_8tiles_round30us_rim_rounds tile_probe_8tiles_rccl_self_RIM_MAIN tile_probe_8tiles_rccl_self_RIM_RESULTS_MAIN; do
+         tile_probe_1tiles tile_probe_2tiles tile_probe_4tiles tile_probe_8tiles tile_probe_8tiles_first_tile tile_probe_8tiles_stand_in_mover tile_probe_8tiles_2x4 tile_probe_8tiles_same_box_as_2x4 tile_probe_8tiles_round30us_results_rounds tile_probe_8tiles_round30us_rim_rounds tile_probe_8tiles_rccl_self_RIM_MAIN tile_probe_8tiles_rccl_self_RIM_RESULTS_MAIN; do
   [ -s $O/$f.json ] && cp $O/$f.json $P/round${N}_$f.json || echo "missing $f"
 done
 cp "$(find $O/stats -name '*kernel_stats.csv' | head -1)" $P/round${N}_kernel_stats_basin2048.csv

@@ -23,9 +23,17 @@ if [ $PART = A ]; then
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_basin2048_with_traffic.json 2>/dev/null; tail -c 400 $O/bench_basin2048_with_traffic.json; echo
   find $O -name "*kernel_stats.csv" | head -3
 else
-  # one tile of the N-tile split (and the single tile through the same tool, for the bounds of profiles/tile_probe_bounds.json: tools/make_tile_bounds.py)
-  for n in 1 2 4 8; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) --steps 10 > $O/tile_probe_${n}tiles.json 2> $O/tile_$n.err; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  # one tile of the N-tile split (and the single tile through the same tool, for the bounds of profiles/tile_probe_bounds.json: tools/make_tile_bounds.py).
+  # Interior tiles (4, 8 tiles) under the REAL transport -- an RCCL communicator of one rank whose tile is its own neighbour: grouped ncclSend / ncclRecv on
+  # both streams, no Python per round (RCCL prints a banner on stdout: the JSON line is the one that starts with a brace); 2 tiles have no interior tile
+  # and run under the stand-in mover, which the 8-tile line is also given beside the RCCL one
+  timeout -k 10 200 python tools/tile_probe.py --tiles 1 --rank 0 --steps 10 > $O/tile_probe_1tiles.json 2> $O/tile_1.err
+  timeout -k 10 200 python tools/tile_probe.py --tiles 2 --rank 1 --steps 10 > $O/tile_probe_2tiles.json 2> $O/tile_2.err
+  for n in 4 8; do timeout -k 10 200 python tools/tile_probe.py --tiles $n --rank $((n/2)) --steps 10 --rccl-self 2> $O/tile_$n.err | grep "^{" > $O/tile_probe_${n}tiles.json; tail -c 200 $O/tile_probe_${n}tiles.json; echo; done
+  timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 > $O/tile_probe_8tiles_stand_in_mover.json 2> $O/tile_8s.err
   timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 0 --steps 10 > $O/tile_probe_8tiles_first_tile.json 2> $O/tile_8_0.err
+  POM_TILE_GRID=2x4 timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 3 --steps 10 --rccl-self 2> $O/tile_2x4.err | grep "^{" > $O/tile_probe_8tiles_2x4.json
+  timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --rccl-self 2>/dev/null | grep "^{" > $O/tile_probe_8tiles_same_box_as_2x4.json
   # a MODEL of link latency: every message round holds its stream for 30 us; nine rounds hidden against six (POMGPU_RIM_RESULTS_MAIN) and two (POMGPU_RIM_MAIN)
   timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_RESULTS_MAIN=1 > $O/tile_probe_8tiles_round30us_results_rounds.json 2> $O/tile_8_m1.err
   timeout -k 10 200 python tools/tile_probe.py --tiles 8 --rank 4 --steps 10 --round-us 30 --ab POMGPU_RIM_MAIN=1 > $O/tile_probe_8tiles_round30us_rim_rounds.json 2> $O/tile_8_m2.err

@@ -45,6 +45,8 @@ def main():
     tile = pdist.tile_for_rank(a.rank, a.tiles, im, jm)
     if a.rccl_self:                                     # every neighbour the tile has is the one rank itself
         import dataclasses
+        # (a direction without its opposite -- an edge tile, a 2-wide grid -- pairs with itself: messages between one pair of ranks match in the order
+        # they are posted, and what leaves towards d has the size of what arrives from d)
         me = lambda n: 0 if n >= 0 else -1
         tile = dataclasses.replace(tile, rank=0, n_west=me(tile.n_west), n_east=me(tile.n_east), n_south=me(tile.n_south), n_north=me(tile.n_north),
                                    n_sw=me(tile.n_sw), n_se=me(tile.n_se), n_nw=me(tile.n_nw), n_ne=me(tile.n_ne))
